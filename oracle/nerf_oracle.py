@@ -1,0 +1,320 @@
+"""CPU/GPU oracle for the nerf-pytorch volumetric-rendering hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``nerf-pytorch_amd/`` imports this
+file; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg
+of ``bench.py`` may use it, and only as the checker / baseline.
+
+It is a functional restatement (plain ``torch`` ops, explicit parameter dict,
+explicit random tensors) of the reference algorithm.  Each function cites the
+reference lines it follows (paths relative to /root/reference):
+
+  posenc            run_nerf_helpers.py:15-63   (Embedder / get_embedder)
+  field_mlp         run_nerf_helpers.py:96-119  (NeRF.forward, use_viewdirs=True)
+  query_field       run_nerf.py:27-51           (batchify + run_network)
+  composite         run_nerf.py:262-305         (raw2outputs)
+  inverse_cdf       run_nerf_helpers.py:196-239 (sample_pdf)
+  trace_rays        run_nerf.py:308-418         (render_rays)
+  trace_in_chunks   run_nerf.py:54-66           (batchify_rays)
+  assemble_rays     run_nerf.py:95-123          (ray-batch assembly inside render())
+
+Parity pin: ``oracle/pin_against_reference.py`` imports the real reference
+(with imageio/cv2 stubbed) in the build container and asserts that every
+function here returns bit-identical fp32 results on CPU, and
+``tests/golden/make_golden.py`` records reference outputs as fixtures for the
+GPU box (where /root/reference does not exist).  The reference ships no tests
+of its own in this tree (README.md:115-121), so "parity pinned by running the
+reference itself", not by reference-owned golden vectors.
+
+Random numbers are never drawn here: ``t_rand`` (stratified jitter,
+run_nerf.py:371), ``u`` (CDF samples, helpers:208) and ``noise_c``/``noise_f``
+(density noise, run_nerf.py:285) are inputs, which is the explicit form of the
+reference's ``pytest=`` hook.
+"""
+import math
+import torch
+
+# --------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------
+# state_dict layout of reference NeRF(D=8, W=256, input_ch=63, input_ch_views=27,
+# skips=[4], use_viewdirs=True)  (run_nerf_helpers.py:68-94)
+def param_shapes(D=8, W=256, in_xyz=63, in_dir=27, skip=4):
+    shapes = []
+    for i in range(D):
+        fan_in = in_xyz if i == 0 else (W + in_xyz if (i - 1) == skip else W)
+        shapes.append((f"pts_linears.{i}.weight", (W, fan_in)))
+        shapes.append((f"pts_linears.{i}.bias", (W,)))
+    shapes.append(("views_linears.0.weight", (W // 2, W + in_dir)))
+    shapes.append(("views_linears.0.bias", (W // 2,)))
+    shapes.append(("feature_linear.weight", (W, W)))
+    shapes.append(("feature_linear.bias", (W,)))
+    shapes.append(("alpha_linear.weight", (1, W)))
+    shapes.append(("alpha_linear.bias", (1,)))
+    shapes.append(("rgb_linear.weight", (3, W // 2)))
+    shapes.append(("rgb_linear.bias", (3,)))
+    return shapes
+
+
+def make_params(seed, dtype=torch.float32, device="cpu", gain=1.0, sigma_gain=1.0, sigma_bias=0.0):
+    """Deterministic, version-independent parameters (numpy MT19937, not torch RNG).
+
+    He-uniform weights so activations keep O(1) scale through the 8 layers and
+    the density head produces non-trivial opacity (an untrained default-init
+    network gives sigma ~ 0 everywhere, which exercises nothing)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name, shp in param_shapes():
+        if name.endswith("weight"):
+            bound = gain * math.sqrt(6.0 / shp[1])
+            a = rs.uniform(-bound, bound, size=shp)
+            if name == "alpha_linear.weight":
+                a = a * sigma_gain
+        else:
+            a = rs.uniform(-0.1, 0.1, size=shp)
+            if name == "alpha_linear.bias":
+                a = a + sigma_bias
+        out[name] = torch.tensor(a, dtype=dtype, device=device)
+    return out
+
+
+def scene_params(seed=0, dtype=torch.float32, device="cpu"):
+    """The (coarse, fine) parameter pair every test / bench / fixture uses:
+    density heads scaled so rays see empty space, semi-transparent shells and
+    opaque hits (sigma roughly in [-25, 27])."""
+    pc = make_params(11 + 2 * seed, dtype, device, sigma_gain=12.0, sigma_bias=-5.0)
+    pf = make_params(12 + 2 * seed, dtype, device, sigma_gain=12.0, sigma_bias=-8.0)
+    return pc, pf
+
+
+# --------------------------------------------------------------------------
+# field model
+# --------------------------------------------------------------------------
+def posenc(x, n_freqs):
+    """[x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]
+    (helpers:21-45; freq bands 2**linspace(0, L-1, L) are exact powers of two)."""
+    bands = 2.0 ** torch.linspace(0.0, n_freqs - 1, steps=n_freqs)
+    parts = [x]
+    for f in bands:
+        parts.append(torch.sin(x * f))
+        parts.append(torch.cos(x * f))
+    return torch.cat(parts, -1)
+
+
+def field_mlp(P, feats, in_xyz=63, in_dir=27, D=8, skip=4, return_hidden=False):
+    """helpers:96-119.  feats [M, in_xyz+in_dir] -> [M,4] = (rgb pre-sigmoid, sigma pre-relu)."""
+    lin = torch.nn.functional.linear
+    xyz, dirs = torch.split(feats, [in_xyz, in_dir], dim=-1)
+    hidden = []
+    h = xyz
+    for i in range(D):
+        h = torch.relu(lin(h, P[f"pts_linears.{i}.weight"], P[f"pts_linears.{i}.bias"]))
+        hidden.append(h)
+        if i == skip:
+            h = torch.cat([xyz, h], -1)
+    sigma = lin(h, P["alpha_linear.weight"], P["alpha_linear.bias"])
+    feat = lin(h, P["feature_linear.weight"], P["feature_linear.bias"])
+    hv = torch.relu(lin(torch.cat([feat, dirs], -1), P["views_linears.0.weight"], P["views_linears.0.bias"]))
+    rgb = lin(hv, P["rgb_linear.weight"], P["rgb_linear.bias"])
+    out = torch.cat([rgb, sigma], -1)
+    if return_hidden:
+        return out, hidden, feat, hv
+    return out
+
+
+def query_field(P, pts, viewdirs, multires=10, multires_views=4, netchunk=1024 * 64):
+    """run_nerf.py:37-51 (+ batchify :27-34): encode, broadcast the ray's view
+    direction to every sample, run the MLP in netchunk-row slices."""
+    flat = torch.reshape(pts, [-1, pts.shape[-1]])
+    emb = posenc(flat, multires)
+    d = viewdirs[:, None].expand(pts.shape)
+    emb_d = posenc(torch.reshape(d, [-1, d.shape[-1]]), multires_views)
+    feats = torch.cat([emb, emb_d], -1)
+    outs = [field_mlp(P, feats[i:i + netchunk]) for i in range(0, feats.shape[0], netchunk)]
+    out = torch.cat(outs, 0)
+    return torch.reshape(out, list(pts.shape[:-1]) + [out.shape[-1]])
+
+
+# --------------------------------------------------------------------------
+# compositing and sampling
+# --------------------------------------------------------------------------
+def composite(raw, z_vals, rays_d, noise=None, white_bkgd=False):
+    """run_nerf.py:262-305.  ``noise`` is the already-scaled additive density
+    noise (randn * raw_noise_std) or None."""
+    one = torch.ones((), dtype=raw.dtype, device=raw.device)
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    far_cap = torch.full_like(dists[..., :1], 1e10)
+    dists = torch.cat([dists, far_cap], -1)
+    dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
+    rgb = torch.sigmoid(raw[..., :3])
+    sigma = raw[..., 3] if noise is None else raw[..., 3] + noise
+    alpha = 1.0 - torch.exp(-torch.relu(sigma) * dists)
+    trans = torch.cumprod(torch.cat([one.expand(alpha.shape[0], 1), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+    weights = alpha * trans
+    rgb_map = torch.sum(weights[..., None] * rgb, -2)
+    depth_map = torch.sum(weights * z_vals, -1)
+    acc_map = torch.sum(weights, -1)
+    disp_map = 1.0 / torch.max(1e-10 * torch.ones_like(depth_map), depth_map / torch.sum(weights, -1))
+    if white_bkgd:
+        rgb_map = rgb_map + (1.0 - acc_map[..., None])
+    return rgb_map, disp_map, acc_map, weights, depth_map
+
+
+def inverse_cdf(bins, weights, n_samples, u=None):
+    """helpers:196-239.  u=None selects the deterministic linspace (det=True)."""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if u is None:
+        u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=cdf.dtype, device=cdf.device)
+        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+    u = u.contiguous()
+    idx = torch.searchsorted(cdf, u, right=True)
+    lo = torch.clamp(idx - 1, min=0)
+    hi = torch.clamp(idx, max=cdf.shape[-1] - 1)
+    pair = torch.stack([lo, hi], -1)
+    shape3 = [pair.shape[0], pair.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(shape3), 2, pair)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(shape3), 2, pair)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+
+
+# --------------------------------------------------------------------------
+# ray tracing (render_rays / batchify_rays / ray assembly)
+# --------------------------------------------------------------------------
+def trace_rays(rays, P_coarse, P_fine, n_coarse=64, n_fine=128, perturb=0.0, lindisp=False,
+               white_bkgd=False, raw_noise_std=0.0, retraw=False,
+               t_rand=None, u=None, noise_c=None, noise_f=None,
+               multires=10, multires_views=4, netchunk=1024 * 64):
+    """run_nerf.py:308-418.  rays [N,11] = (o3, d3, near, far, viewdir3).
+
+    perturb>0 requires t_rand [N,n_coarse] and u [N,n_fine]; raw_noise_std>0
+    requires noise_c [N,n_coarse] / noise_f [N,n_coarse+n_fine] (standard
+    normal draws; scaled here, run_nerf.py:285)."""
+    n_rays = rays.shape[0]
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    viewdirs = rays[:, -3:]
+    bounds = torch.reshape(rays[..., 6:8], [-1, 1, 2])
+    near, far = bounds[..., 0], bounds[..., 1]
+    t = torch.linspace(0.0, 1.0, steps=n_coarse, dtype=rays.dtype, device=rays.device)
+    if not lindisp:
+        z = near * (1.0 - t) + far * t
+    else:
+        z = 1.0 / (1.0 / near * (1.0 - t) + 1.0 / far * t)
+    z = z.expand([n_rays, n_coarse])
+    if perturb > 0.0:
+        mids = 0.5 * (z[..., 1:] + z[..., :-1])
+        upper = torch.cat([mids, z[..., -1:]], -1)
+        lower = torch.cat([z[..., :1], mids], -1)
+        z = lower + (upper - lower) * t_rand
+    pts = o[..., None, :] + d[..., None, :] * z[..., :, None]
+    q = lambda Pm, x: query_field(Pm, x, viewdirs, multires, multires_views, netchunk)
+    raw = q(P_coarse, pts)
+    nz = None if raw_noise_std <= 0.0 else noise_c * raw_noise_std
+    rgb_map, disp_map, acc_map, weights, _ = composite(raw, z, d, nz, white_bkgd)
+    out = {}
+    if n_fine > 0:
+        rgb0, disp0, acc0 = rgb_map, disp_map, acc_map
+        z_mid = 0.5 * (z[..., 1:] + z[..., :-1])
+        z_new = inverse_cdf(z_mid, weights[..., 1:-1], n_fine, None if perturb == 0.0 else u).detach()
+        z, _ = torch.sort(torch.cat([z, z_new], -1), -1)
+        pts = o[..., None, :] + d[..., None, :] * z[..., :, None]
+        raw = q(P_coarse if P_fine is None else P_fine, pts)
+        nz = None if raw_noise_std <= 0.0 else noise_f * raw_noise_std
+        rgb_map, disp_map, acc_map, weights, _ = composite(raw, z, d, nz, white_bkgd)
+        out.update(rgb0=rgb0, disp0=disp0, acc0=acc0,
+                   z_std=torch.std(z_new, dim=-1, unbiased=False))
+    out.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map)
+    if retraw:
+        out["raw"] = raw
+    out["_z_vals"] = z          # oracle-only extras (not part of the reference dict)
+    out["_weights"] = weights
+    return out
+
+
+def trace_in_chunks(rays, chunk, **kw):
+    """run_nerf.py:54-66.  Random tensors (if any) are sliced with the rays."""
+    rand_keys = ("t_rand", "u", "noise_c", "noise_f")
+    pieces = {}
+    for i in range(0, rays.shape[0], chunk):
+        kwi = dict(kw)
+        for k in rand_keys:
+            if kw.get(k) is not None:
+                kwi[k] = kw[k][i:i + chunk]
+        r = trace_rays(rays[i:i + chunk], **kwi)
+        for k, v in r.items():
+            pieces.setdefault(k, []).append(v)
+    return {k: torch.cat(v, 0) for k, v in pieces.items()}
+
+
+def assemble_rays(rays_o, rays_d, near, far):
+    """run_nerf.py:100-123 (use_viewdirs=True, no NDC): normalised view
+    directions, flattened [N,11] ray records."""
+    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    o = torch.reshape(rays_o, [-1, 3]).float()
+    d = torch.reshape(rays_d, [-1, 3]).float()
+    nr = near * torch.ones_like(d[..., :1])
+    fr = far * torch.ones_like(d[..., :1])
+    return torch.cat([o, d, nr, fr, viewdirs], -1)
+
+
+def ndc_warp(H, W, focal, near, rays_o, rays_d):
+    """run_nerf_helpers.py:175-192 (forward-facing NDC warp)."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1.0 / (W / (2.0 * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1.0 / (H / (2.0 * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1.0 + 2.0 * near / rays_o[..., 2]
+    d0 = -1.0 / (W / (2.0 * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1.0 / (H / (2.0 * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2.0 * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def pinhole_rays(H, W, K, c2w):
+    """run_nerf_helpers.py:153-162 (get_rays)."""
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
+    i = i.t()
+    j = j.t()
+    dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def mse(a, b):
+    return torch.mean((a - b) ** 2)
+
+
+def psnr(m):
+    return -10.0 * math.log10(float(m))
+
+
+# --------------------------------------------------------------------------
+# synthetic, seeded workloads shared by tests and bench
+# --------------------------------------------------------------------------
+def synthetic_rays(n, seed=0, near=2.0, far=6.0, dtype=torch.float32):
+    """o ~ N((0,0,4), 0.1^2), d = normalize(N(0,I)) pointing roughly at the origin."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    o = rs.normal(0.0, 0.1, size=(n, 3)) + np.array([0.0, 0.0, 4.0])
+    tgt = rs.normal(0.0, 0.6, size=(n, 3))
+    d = tgt - o
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    d = d * rs.uniform(0.8, 1.25, size=(n, 1))      # non-unit rays_d like get_rays() output
+    o = torch.tensor(o, dtype=dtype)
+    d = torch.tensor(d, dtype=dtype)
+    return assemble_rays(o, d, near, far).to(dtype)
+
+
+def synthetic_randoms(n, n_coarse, n_fine, seed=0, dtype=torch.float32):
+    import numpy as np
+    rs = np.random.RandomState(seed + 1000)
+    mk = lambda a: torch.tensor(a, dtype=dtype)
+    return dict(t_rand=mk(rs.rand(n, n_coarse)), u=mk(rs.rand(n, n_fine)),
+                noise_c=mk(rs.randn(n, n_coarse)), noise_f=mk(rs.randn(n, n_coarse + n_fine)))
