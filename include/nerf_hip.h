@@ -1,0 +1,106 @@
+/* nerf_hip.h -- C ABI of libnerf_hip.so, the MI355X (gfx950) implementation of the
+ * nerf-pytorch volumetric-rendering hot path.
+ *
+ * The reference (yenchenlin/nerf-pytorch) is pure Python and has no FFI: the seam this
+ * library plugs into is the call surface of its hot-path functions.  Every entry point
+ * below names the reference function (file:line under /root/reference) it replaces.
+ * A maintainer binds these with ctypes (INTEGRATION.md shows the stub); the in-repo
+ * binding is nerf-pytorch_amd/hip_backend.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data owned by the caller (torch tensors);
+ *     the library allocates nothing and keeps no pointer after return;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued asynchronously on it, no host synchronisation inside;
+ *   - return 0 on success, a negative NERF_E_* code for argument errors, a positive
+ *     hipError_t for runtime errors; nerf_last_error() describes the last failure of the
+ *     calling thread.  Nothing throws, nothing exits;
+ *   - rays are [n_rays][ray_stride] records (o3, d3, near, far, viewdir3), ray_stride = 11
+ *     (run_nerf.py:117-123);
+ *   - the field model is fixed to the reference architecture NeRF(D=8, W=256,
+ *     input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True)
+ *     (run_nerf_helpers.py:67-94); parameters are exchanged as ONE flat fp32 vector in
+ *     state_dict order (nerf_param_count() = 595,844 floats, layout: nerf_param_offset()).
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_ABI_VERSION 1
+#define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
+#define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
+
+int nerf_abi_version(void);
+const char* nerf_last_error(void);
+
+/* ---- parameter vector (replaces nn.Module storage, run_nerf_helpers.py:79-94) ---------- */
+int nerf_param_count(void);
+/* offset (floats) of tensor #idx of the state_dict (0..23: pts_linears.0.weight, .bias, ...,
+ * views_linears.0.*, feature_linear.*, alpha_linear.*, rgb_linear.*); returns -1 if idx is out of range.
+ * rows/cols receive the tensor shape (cols = 1 for biases). */
+int nerf_param_offset(int idx, int* rows, int* cols);
+/* size of the MFMA-fragment repack of one network (floats) */
+int nerf_packed_floats(void);
+/* canonical parameters -> fragment streams consumed by nerf_field_fwd / nerf_field_bwd.
+ * Call after every optimizer step. */
+int nerf_pack_params(const float* params, float* packed, void* stream);
+
+/* test hook (host only, no GPU): out_host[i] = index into the canonical vector that packed[i] is gathered
+ * from, or -1 for zero padding; nerf_packed_floats() entries. */
+int nerf_debug_pack_table(int* out_host);
+
+/* ---- Embedder.embed (run_nerf_helpers.py:15-45): x[n_pts][3] -> out[n_pts][3 + 6*n_freqs] */
+int nerf_embed(const float* x, long n_pts, int n_freqs, float* out, void* stream);
+
+/* ---- z_vals of render_rays (run_nerf.py:357-379).  t_vals = torch.linspace(0,1,n_samples);
+ * t_rand [n_rays][n_samples] uniform draws or NULL (perturb == 0). */
+int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int n_samples,
+                       int lindisp, const float* t_rand, float* z_vals, void* stream);
+
+/* ---- network_query_fn(pts, viewdirs, network_fn) with pts = o + d*z
+ * (run_nerf.py:381,385 -> run_network :37-51 -> Embedder :44-45 -> NeRF.forward helpers:96-119).
+ * raw[n_rays][n_samples][4] = (rgb pre-sigmoid, sigma pre-relu).
+ * act: NULL for inference; otherwise nerf_act_floats() floats that receive what the backward needs. */
+size_t nerf_act_floats(int n_rays, int n_samples);
+int nerf_field_fwd(const float* packed, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                   int n_samples, float* raw, float* act, void* stream);
+
+/* ---- raw2outputs (run_nerf.py:262-305).  rays_d points at the first direction component of ray 0,
+ * consecutive rays are dir_stride floats apart (3 for a bare [N,3] tensor, 11 for rays + 3).
+ * noise: standard-normal draws [n_rays][n_samples] or NULL; weights / depth_map may be NULL. */
+int nerf_raw2outputs(const float* raw, const float* z_vals, const float* rays_d, int dir_stride, int n_rays,
+                     int n_samples, const float* noise, float raw_noise_std, int white_bkgd, float* rgb_map,
+                     float* disp_map, float* acc_map, float* weights, float* depth_map, void* stream);
+/* autograd of raw2outputs w.r.t. raw: d_rgb[n_rays][3] required, d_acc / d_disp [n_rays] may be NULL. */
+int nerf_raw2outputs_bwd(const float* raw, const float* z_vals, const float* rays_d, int dir_stride, int n_rays,
+                         int n_samples, const float* noise, float raw_noise_std, int white_bkgd,
+                         const float* d_rgb, const float* d_acc, const float* d_disp, float* d_raw, void* stream);
+
+/* ---- hierarchical sampling (run_nerf.py:392-396,412 + sample_pdf, run_nerf_helpers.py:196-239):
+ * z_mid, sample_pdf(z_mid, weights[1:-1], n_fine, det = (u == NULL)), sort(cat(z_vals, z_samples)), z_std.
+ * u [n_rays][n_fine] uniform draws or NULL; u_lin = torch.linspace(0,1,n_fine) (read when u == NULL).
+ * z_all [n_rays][n_coarse+n_fine]; z_samples [n_rays][n_fine] may be NULL. */
+int nerf_sample_fine(const float* z_vals, const float* weights, int n_rays, int n_coarse, int n_fine,
+                     const float* u, const float* u_lin, float* z_all, float* z_samples, float* z_std, void* stream);
+
+/* ---- sample_pdf (run_nerf_helpers.py:196-239) in its standalone form: bins[n_rays][n_bins],
+ * weights[n_rays][n_bins-1] -> samples[n_rays][n_samples]; det = (u == NULL). */
+int nerf_sample_pdf(const float* bins, const float* weights, int n_rays, int n_bins, int n_samples,
+                    const float* u, const float* u_lin, float* samples, void* stream);
+
+/* ---- backward of nerf_field_fwd: d_raw[n_rays][n_samples][4] -> gradient of the flat parameter vector
+ * (autograd of run_nerf_helpers.py:96-119; parameters only).
+ * delta / partial: scratch of nerf_delta_floats() / nerf_wgrad_partial_floats() floats.
+ * accumulate != 0 adds into grad, otherwise grad is overwritten. */
+size_t nerf_delta_floats(int n_rays, int n_samples);
+size_t nerf_wgrad_partial_floats(int n_rays, int n_samples);
+int nerf_field_bwd(const float* packed, const float* act, const float* d_raw, int n_rays, int n_samples,
+                   float* delta, float* partial, float* grad, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,154 @@
+// extern "C" entry points of libnerf_hip.so (declared in include/nerf_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "nerf_common.h"
+#include "../../include/nerf_hip.h"
+
+#include "launchers.h"
+
+static thread_local char g_err[256] = "";
+
+static int fail_arg(const char* fn, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", fn, what);
+    return NERF_E_BADARG;
+}
+static int done(const char* fn, hipError_t e) {
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", fn, (int)e, hipGetErrorString(e));
+    return (int)e;
+}
+#define REQUIRE(cond, what) do { if (!(cond)) return fail_arg(__func__, what); } while (0)
+
+extern "C" {
+
+int nerf_abi_version(void) { return NERF_ABI_VERSION; }
+const char* nerf_last_error(void) { return g_err; }
+int nerf_param_count(void) { return nerf::N_PARAMS; }
+int nerf_packed_floats(void) { return nerf::PACKED_FLOATS; }
+
+int nerf_param_offset(int idx, int* rows, int* cols) {
+    constexpr nerf::Canon c = nerf::canon();
+    int off = -1, r = 0, cc = 1;
+    if (idx >= 0 && idx < 2 * nerf::D) {
+        const int l = idx / 2;
+        if (idx % 2 == 0) { off = c.w[l]; r = nerf::W; cc = nerf::fan_in(l); } else { off = c.b[l]; r = nerf::W; }
+    } else switch (idx) {
+        case 16: off = c.wv; r = nerf::WV; cc = nerf::W + nerf::IN_DIR; break;
+        case 17: off = c.bv; r = nerf::WV; break;
+        case 18: off = c.wf; r = nerf::W; cc = nerf::W; break;
+        case 19: off = c.bf; r = nerf::W; break;
+        case 20: off = c.wa; r = 1; cc = nerf::W; break;
+        case 21: off = c.ba; r = 1; break;
+        case 22: off = c.wr; r = 3; cc = nerf::WV; break;
+        case 23: off = c.br; r = 3; break;
+        default: break;
+    }
+    if (rows) *rows = r;
+    if (cols) *cols = cc;
+    return off;
+}
+
+int nerf_debug_pack_table(int* out_host) {
+    REQUIRE(out_host, "null pointer");
+    nerf::pack_table_host(out_host);
+    return 0;
+}
+
+int nerf_pack_params(const float* params, float* packed, void* stream) {
+    REQUIRE(params && packed, "null pointer");
+    return done(__func__, nerf::launch_pack(params, packed, (hipStream_t)stream));
+}
+
+int nerf_embed(const float* x, long n_pts, int n_freqs, float* out, void* stream) {
+    REQUIRE(x && out, "null pointer");
+    REQUIRE(n_pts >= 0 && n_freqs >= 0 && n_freqs <= 30, "bad size");
+    return done(__func__, nerf::launch_embed(x, n_pts, n_freqs, out, (hipStream_t)stream));
+}
+
+int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int n_samples,
+                       int lindisp, const float* t_rand, float* z_vals, void* stream) {
+    REQUIRE(rays && t_vals && z_vals, "null pointer");
+    REQUIRE(ray_stride >= 8 && n_rays >= 0 && n_samples >= 1, "bad size");
+    return done(__func__, nerf::launch_sample_coarse(rays, ray_stride, n_rays, t_vals, n_samples, lindisp, t_rand,
+                                                     z_vals, (hipStream_t)stream));
+}
+
+size_t nerf_act_floats(int n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    return nerf::act_layout((size_t)n_rays * n_samples, (size_t)n_rays).total;
+}
+size_t nerf_delta_floats(int n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    return nerf::delta_layout((size_t)n_rays * n_samples).total;
+}
+size_t nerf_wgrad_partial_floats(int n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    return nerf::wgrad_partial_floats((long)n_rays * n_samples);
+}
+
+int nerf_field_fwd(const float* packed, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                   int n_samples, float* raw, float* act, void* stream) {
+    REQUIRE(packed && rays && z_vals && raw, "null pointer");
+    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
+    return done(__func__, nerf::launch_field_fwd(packed, rays, ray_stride, z_vals, n_rays, n_samples, raw, act,
+                                                 (hipStream_t)stream));
+}
+
+int nerf_raw2outputs(const float* raw, const float* z_vals, const float* rays_d, int dir_stride, int n_rays,
+                     int n_samples, const float* noise, float raw_noise_std, int white_bkgd, float* rgb_map,
+                     float* disp_map, float* acc_map, float* weights, float* depth_map, void* stream) {
+    REQUIRE(raw && z_vals && rays_d && rgb_map && disp_map && acc_map, "null pointer");
+    REQUIRE(dir_stride >= 3 && n_rays >= 0 && n_samples >= 1 && n_samples <= 4096, "bad size");
+    nerf::CompositeArgs a{raw, z_vals, rays_d, raw_noise_std > 0.0f ? noise : nullptr, raw_noise_std,
+                          dir_stride, n_rays, n_samples, white_bkgd,
+                          rgb_map, disp_map, acc_map, weights, depth_map, nullptr, nullptr, nullptr, nullptr};
+    REQUIRE(!(raw_noise_std > 0.0f) || noise, "raw_noise_std > 0 needs noise draws");
+    return done(__func__, nerf::launch_composite(a, false, (hipStream_t)stream));
+}
+
+int nerf_raw2outputs_bwd(const float* raw, const float* z_vals, const float* rays_d, int dir_stride, int n_rays,
+                         int n_samples, const float* noise, float raw_noise_std, int white_bkgd,
+                         const float* d_rgb, const float* d_acc, const float* d_disp, float* d_raw, void* stream) {
+    REQUIRE(raw && z_vals && rays_d && d_rgb && d_raw, "null pointer");
+    REQUIRE(dir_stride >= 3 && n_rays >= 0 && n_samples >= 1 && n_samples <= 4096, "bad size");
+    REQUIRE(!(raw_noise_std > 0.0f) || noise, "raw_noise_std > 0 needs noise draws");
+    nerf::CompositeArgs a{raw, z_vals, rays_d, raw_noise_std > 0.0f ? noise : nullptr, raw_noise_std,
+                          dir_stride, n_rays, n_samples, white_bkgd,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, d_rgb, d_acc, d_disp, d_raw};
+    return done(__func__, nerf::launch_composite(a, true, (hipStream_t)stream));
+}
+
+int nerf_sample_fine(const float* z_vals, const float* weights, int n_rays, int n_coarse, int n_fine,
+                     const float* u, const float* u_lin, float* z_all, float* z_samples, float* z_std, void* stream) {
+    REQUIRE(z_vals && weights && z_all && z_std, "null pointer");
+    REQUIRE(u || u_lin, "need u or u_lin");
+    REQUIRE(n_rays >= 0 && n_coarse >= 3 && n_fine >= 1 && n_coarse + n_fine <= 8192, "bad size");
+    nerf::FineArgs a{z_vals, weights, u, u_lin, z_all, z_samples, z_std, n_rays, n_coarse, n_fine, 0};
+    return done(__func__, nerf::launch_sample_fine(a, (hipStream_t)stream));
+}
+
+int nerf_sample_pdf(const float* bins, const float* weights, int n_rays, int n_bins, int n_samples,
+                    const float* u, const float* u_lin, float* samples, void* stream) {
+    REQUIRE(bins && weights && samples, "null pointer");
+    REQUIRE(u || u_lin, "need u or u_lin");
+    REQUIRE(n_rays >= 0 && n_bins >= 2 && n_samples >= 1 && n_bins + n_samples <= 8192, "bad size");
+    nerf::FineArgs a{bins, weights, u, u_lin, nullptr, samples, nullptr, n_rays, n_bins, n_samples, 1};
+    return done(__func__, nerf::launch_sample_fine(a, (hipStream_t)stream));
+}
+
+int nerf_field_bwd(const float* packed, const float* act, const float* d_raw, int n_rays, int n_samples,
+                   float* delta, float* partial, float* grad, int accumulate, void* stream) {
+    REQUIRE(packed && act && d_raw && delta && partial && grad, "null pointer");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
+            "packed/act/d_raw/delta must be 16-byte aligned");
+    return done(__func__, nerf::launch_field_bwd(packed, act, d_raw, n_rays, n_samples, delta, partial, grad, accumulate,
+                                                 (hipStream_t)stream));
+}
+
+}  // extern "C"

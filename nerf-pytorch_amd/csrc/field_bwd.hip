@@ -1,0 +1,368 @@
+// Backward of the fused field evaluation (autograd of run_nerf_helpers.py:96-119
+// restricted to the parameter gradients the reference trains with, SURVEY §8 a-9:
+// no gradient flows into the encodings / ray points).
+//
+//   field_dgrad_kernel : d_raw[P,4] -> per-layer deltas (dL/d pre-activation),
+//                        same register-resident transposed MFMA chain as the
+//                        forward, fed by the transposed weight stream; ReLU masks
+//                        come from the bitmasks the forward saved.
+//   wgrad_kernel       : dW[n][k] = sum_p delta[p][n] * input[p][k]  and
+//                        db[n] = sum_p delta[p][n]  for all 13 (delta, input)
+//                        pairs of the network in ONE launch: LDS-tiled
+//                        v_mfma_f32_16x16x4_f32 GEMM, contraction over points,
+//                        split over point chunks; per-chunk partial gradients are
+//                        written in canonical layout and summed by
+//   wgrad_reduce_kernel (deterministic, no atomics).
+#include "field_device.h"
+
+#include "launchers.h"
+
+namespace nerf {
+
+// ------------------------------------------------------------------ dgrad chain
+struct FieldBwdArgs {
+    const float* packed;
+    const float* act;       // saved by field_fwd_kernel<true>
+    const float* d_raw;     // [P][4]
+    float* delta;           // delta_layout(P)
+    int n_rays, S;
+};
+
+template <int NV>
+__device__ inline void apply_mask(float (&d)[NV], const f32x4* acc, uint2 m) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned bit = i < 32 ? (m.x >> i) & 1u : (m.y >> (i - 32)) & 1u;
+        d[i] = bit ? acc[i >> 2][i & 3] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(FIELD_WAVES * 64) void field_dgrad_kernel(FieldBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4;
+    const size_t P = (size_t)a.n_rays * a.S;
+    const size_t p_raw = ((size_t)blockIdx.x * FIELD_WAVES + wave) * PTS_PER_WAVE + (lane & 15);
+    const bool valid = p_raw < P;
+    const size_t p = valid ? p_raw : P - 1;
+
+    WeightStream<false> ws;
+    ws.start(a.packed + BWD_VIEWS, lds, wave, lane);
+    stage_small(a.packed, lds);
+
+    const ActLayout al = act_layout(P, (size_t)a.n_rays);
+    const DeltaLayout dl = delta_layout(P);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);       // (d_rgb3, d_sigma)
+    uint2 msk[D + 1];
+    {
+        const uint2* mp = reinterpret_cast<const uint2*>(a.act + al.mask) + p * 4 + q;
+#pragma unroll
+        for (int l = 0; l <= D; ++l) msk[l] = mp[(size_t)l * P * 4];
+    }
+
+    // ---- rgb_linear^T (VALU) + ReLU mask of the view branch
+    float dhv[32];
+    {
+        const float* wr = small_ptr(lds, SM_WRGB) + 4 * q;
+        __syncthreads();                 // stage_small visible
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + 16 * nb);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + WV + 16 * nb);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 2 * WV + 16 * nb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = g[0] * w0[r] + g[1] * w1[r] + g[2] * w2[r];
+                dhv[4 * nb + r] = ((msk[D].x >> (4 * nb + r)) & 1u) ? v : 0.0f;
+            }
+        }
+        if (valid) {
+            float* o = a.delta + dl.hv + p * WV + 4 * q;
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb)
+                *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{dhv[4 * nb], dhv[4 * nb + 1], dhv[4 * nb + 2], dhv[4 * nb + 3]};
+        }
+    }
+
+    f32x4 acc[16];
+    float d[64];
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- views_linears.0^T (feature columns only): 128 -> 256, no activation on feature
+#pragma unroll
+    for (int nb = 0; nb < 16; ++nb) acc[nb] = zero4;
+    mma_chunk<16, 16, 0, 32>(acc, dhv, ws.acquire(), lane);
+    mma_chunk<16, 16, 16, 32>(acc, dhv, ws.acquire(), lane);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) d[i] = acc[i >> 2][i & 3];
+    if (valid) {
+        float* o = a.delta + dl.feat + p * W + 4 * q;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) *reinterpret_cast<f32x4*>(o + 16 * nb) = acc[nb];
+    }
+
+    // ---- feature_linear^T + alpha_linear^T, ReLU mask of layer 7
+    {
+        const float* wa = small_ptr(lds, SM_WALPHA) + 4 * q;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wa + 16 * nb);
+            acc[nb] = f32x4{g[3] * w[0], g[3] * w[1], g[3] * w[2], g[3] * w[3]};
+        }
+    }
+    mma_chunk<16, 16, 0, 64>(acc, d, ws.acquire(), lane);
+    mma_chunk<16, 16, 16, 64>(acc, d, ws.acquire(), lane);
+    mma_chunk<16, 16, 32, 64>(acc, d, ws.acquire(), lane);
+    mma_chunk<16, 16, 48, 64>(acc, d, ws.acquire(), lane);
+    apply_mask<64>(d, acc, msk[D - 1]);
+    if (valid) {
+        float* o = a.delta + dl.h[D - 1] + p * W + 4 * q;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb)
+            *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{d[4 * nb], d[4 * nb + 1], d[4 * nb + 2], d[4 * nb + 3]};
+    }
+
+    // ---- trunk: delta_{l-1} = (W_l^T delta_l) * relu'(h_{l-1}),  l = 7 .. 1
+#pragma unroll 1
+    for (int l = D - 1; l >= 1; --l) {
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) acc[nb] = zero4;
+        mma_chunk<16, 16, 0, 64>(acc, d, ws.acquire(), lane);
+        mma_chunk<16, 16, 16, 64>(acc, d, ws.acquire(), lane);
+        mma_chunk<16, 16, 32, 64>(acc, d, ws.acquire(), lane);
+        mma_chunk<16, 16, 48, 64>(acc, d, ws.acquire(), lane);
+        uint2 m = msk[0];
+#pragma unroll
+        for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];      // select without dynamic register indexing
+        apply_mask<64>(d, acc, m);
+        if (valid) {
+            float* o = a.delta + (size_t)(l - 1) * P * W + p * W + 4 * q;       // == dl.h[l-1]
+#pragma unroll
+            for (int nb = 0; nb < 16; ++nb)
+                *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{d[4 * nb], d[4 * nb + 1], d[4 * nb + 2], d[4 * nb + 3]};
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight gradients
+constexpr int WG_TILE = 128;        // output tile 128 (n) x 128 (k) per 256-thread workgroup
+constexpr int WG_STAGE = 32;        // points per LDS stage
+constexpr int WG_MAX_JOBS = 13;
+
+struct WgradJob {
+    const float* A; const float* B;
+    int lda, nA, ldb, nB, b_rowdiv;
+    int c_off, ldc, bias_off;       // offsets into the canonical gradient vector; bias_off < 0: none
+    int tiles_k, tile_base;         // tiles of this job: [tile_base, tile_base + tiles_n*tiles_k)
+    int vecA, vecB;                 // 16-byte aligned full-row loads allowed
+};
+struct WgradArgs {
+    WgradJob job[WG_MAX_JOBS];
+    int n_jobs, total_tiles;
+    long P;
+    int chunk_pts, n_chunks;
+    float* partial;                 // [n_chunks][N_PARAMS]
+};
+
+__device__ inline f32x4 load_row4(const float* base, int ld, long row, bool row_ok, int col, int ncols, int vec) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row_ok) {
+        const float* ptr = base + row * ld + col;
+        if (vec && col + 3 < ncols) v = *reinterpret_cast<const f32x4*>(ptr);
+        else {
+            if (col < ncols) v[0] = ptr[0];
+            if (col + 1 < ncols) v[1] = ptr[1];
+            if (col + 2 < ncols) v[2] = ptr[2];
+            if (col + 3 < ncols) v[3] = ptr[3];
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[2][WG_STAGE][WG_TILE];
+    __shared__ __attribute__((aligned(16))) float sB[2][WG_STAGE][WG_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave >> 1, wave_k = wave & 1;
+    const int tile = blockIdx.x % a.total_tiles;
+    const int chunk = blockIdx.x / a.total_tiles;
+    int ji = 0;
+#pragma unroll 1
+    for (int j = 1; j < a.n_jobs; ++j) if (tile >= a.job[j].tile_base) ji = j;
+    const WgradJob& jb = a.job[ji];
+    const int lt = tile - jb.tile_base;
+    const int tn = lt / jb.tiles_k, tk = lt % jb.tiles_k;
+    const int n0 = tn * WG_TILE, k0 = tk * WG_TILE;
+    const long p_begin = (long)chunk * a.chunk_pts;
+    const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
+    const int n_stages = (int)((p_end - p_begin + WG_STAGE - 1) / WG_STAGE);
+
+    // staging map: thread -> rows (tid>>5) + 8*i, columns 4*(tid&31)
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    const float* Ab = jb.A + n0;
+    const float* Bb = jb.B + k0;
+    const int nA = jb.nA - n0, nB = jb.nB - k0;          // valid columns left in this tile
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int st) {
+        const long r0 = p_begin + (long)st * WG_STAGE + srow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long r = r0 + 8 * i;
+            ra[i] = load_row4(Ab, jb.lda, r, r < p_end, scol, nA, jb.vecA);
+            rb[i] = load_row4(Bb, jb.ldb, jb.b_rowdiv > 1 ? r / jb.b_rowdiv : r, r < p_end, scol, nB, jb.vecB);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&sA[buf][srow + 8 * i][scol]) = ra[i];
+            *reinterpret_cast<f32x4*>(&sB[buf][srow + 8 * i][scol]) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int c = lane & 15, pp = lane >> 4;
+    for (int st = 0; st < n_stages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < n_stages) gload(st + 1);
+#pragma unroll
+        for (int ps = 0; ps < WG_STAGE / 4; ++ps) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&sA[buf][4 * ps + pp][wave_n * 64 + 4 * c]);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&sB[buf][4 * ps + pp][wave_k * 64 + 4 * c]);
+            bsum += av;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (st + 1 < n_stages) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    // acc[i][j][r] = dW[n0 + wave_n*64 + 4*(4*pp + r) + i][k0 + wave_k*64 + 4*c + j]
+    float* out = a.partial + (size_t)chunk * N_PARAMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = wave_n * 64 + 4 * (4 * pp + r) + i;
+            if (n < nA) {
+                float* row = out + jb.c_off + (size_t)(n0 + n) * jb.ldc + k0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = wave_k * 64 + 4 * c + j;
+                    if (k < nB) row[k] = acc[i][j][r];
+                }
+            }
+        }
+    if (jb.bias_off >= 0 && tk == 0 && wave_k == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int n = wave_n * 64 + 4 * c + i;
+            if (pp == 0 && n < nA) out[jb.bias_off + n0 + n] = v;
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N_PARAMS) return;
+    float s = 0.0f;
+    for (int cix = 0; cix < n_chunks; ++cix) s += partial[(size_t)cix * N_PARAMS + i];
+    grad[i] = accumulate ? grad[i] + s : s;
+}
+
+// ------------------------------------------------------------------ host side
+static int wgrad_chunks(long P, int* chunk_pts) {
+    long n = (P + 8191) / 8192;
+    if (n < 28) n = 28;
+    const long cap = (P + 255) / 256;
+    if (n > cap) n = cap;
+    if (n < 1) n = 1;
+    long pts = (P + n - 1) / n;
+    pts = (pts + WG_STAGE - 1) / WG_STAGE * WG_STAGE;
+    *chunk_pts = (int)pts;
+    return (int)((P + pts - 1) / pts);
+}
+
+size_t wgrad_partial_floats(long P) {
+    int pts;
+    const int n = wgrad_chunks(P, &pts);
+    return (size_t)n * N_PARAMS;
+}
+
+hipError_t launch_field_bwd(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
+                            float* delta, float* partial, float* grad, int accumulate, hipStream_t stream) {
+    const long P = (long)n_rays * S;
+    if (P <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    FieldBwdArgs ba{packed, act, d_raw, delta, n_rays, S};
+    const unsigned blocks = (unsigned)((P + PTS_PER_WG - 1) / PTS_PER_WG);
+    hipLaunchKernelGGL(field_dgrad_kernel, dim3(blocks), dim3(FIELD_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+
+    const ActLayout al = act_layout((size_t)P, (size_t)n_rays);
+    const DeltaLayout dl = delta_layout((size_t)P);
+    constexpr Canon cn = canon();
+    WgradArgs wa{};
+    int nj = 0, tiles = 0;
+    auto add = [&](const float* A, int lda, int nA, const float* B, int ldb, int nB, int rowdiv, int c_off, int ldc, int bias_off) {
+        WgradJob& j = wa.job[nj++];
+        j.A = A; j.B = B; j.lda = lda; j.nA = nA; j.ldb = ldb; j.nB = nB; j.b_rowdiv = rowdiv;
+        j.c_off = c_off; j.ldc = ldc; j.bias_off = bias_off;
+        const int tn = (nA + WG_TILE - 1) / WG_TILE;
+        j.tiles_k = (nB + WG_TILE - 1) / WG_TILE;
+        j.tile_base = tiles;
+        tiles += tn * j.tiles_k;
+        j.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && lda % 4 == 0) ? 1 : 0;
+        j.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && ldb % 4 == 0) ? 1 : 0;
+    };
+    const float* enc = act + al.enc;
+    add(delta + dl.h[0], W, W, enc, 64, IN_XYZ, 1, cn.w[0], IN_XYZ, cn.b[0]);
+    for (int l = 1; l < D; ++l) {
+        if (l == SKIP + 1) {
+            add(delta + dl.h[l], W, W, enc, 64, IN_XYZ, 1, cn.w[l], W + IN_XYZ, cn.b[l]);
+            add(delta + dl.h[l], W, W, act + al.h[l - 1], W, W, 1, cn.w[l] + IN_XYZ, W + IN_XYZ, -1);
+        } else {
+            add(delta + dl.h[l], W, W, act + al.h[l - 1], W, W, 1, cn.w[l], W, cn.b[l]);
+        }
+    }
+    add(delta + dl.feat, W, W, act + al.h[D - 1], W, W, 1, cn.wf, W, cn.bf);
+    add(d_raw + 3, 4, 1, act + al.h[D - 1], W, W, 1, cn.wa, W, cn.ba);
+    add(delta + dl.hv, WV, WV, act + al.feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
+    add(delta + dl.hv, WV, WV, act + al.dir, 32, IN_DIR, S, cn.wv + W, W + IN_DIR, -1);
+    add(d_raw, 4, 3, act + al.hv, WV, WV, 1, cn.wr, WV, cn.br);
+    wa.n_jobs = nj;
+    wa.total_tiles = tiles;
+    wa.P = P;
+    wa.n_chunks = wgrad_chunks(P, &wa.chunk_pts);
+    wa.partial = partial;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(tiles * wa.n_chunks)), dim3(256), 0, stream, wa);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, stream,
+                       (const float*)partial, wa.n_chunks, grad, accumulate);
+    return hipGetLastError();
+}
+
+}  // namespace nerf

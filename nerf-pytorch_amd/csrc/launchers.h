@@ -1,0 +1,50 @@
+// Host-side launch interface between api.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace nerf {
+
+struct CompositeArgs {
+    const float* raw;       // [N][S][4]
+    const float* z;         // [N][S]
+    const float* dirs;      // ray directions: dirs[r*dir_stride + 0..2]
+    const float* noise;     // [N][S] standard normal, nullable
+    float noise_std;
+    int dir_stride, n_rays, S, white_bkgd;
+    // forward outputs (weights / depth nullable)
+    float* rgb; float* disp; float* acc; float* weights; float* depth;
+    // backward inputs / output
+    const float* d_rgb;     // [N][3]
+    const float* d_acc;     // [N] nullable
+    const float* d_disp;    // [N] nullable
+    float* d_raw;           // [N][S][4]
+};
+
+struct FineArgs {
+    // direct == 0: in0 = coarse depths z[N][Sc], in1 = coarse weights[N][Sc]
+    //              bins = mid-points, pdf from weights[1:-1]               (run_nerf.py:392-393)
+    // direct == 1: in0 = bins[N][nb], in1 = weights[N][nb-1]               (sample_pdf as called standalone)
+    const float* in0; const float* in1;
+    const float* u;         // [N][Nf] uniform draws, nullable -> u_lin
+    const float* u_lin;     // [Nf] torch.linspace(0,1,Nf)
+    float* z_all;           // [N][Sc+Nf] sorted union (direct == 0 only), nullable
+    float* z_samples;       // [N][Nf] nullable
+    float* z_std;           // [N] nullable
+    int n_rays, n_in, Nf, direct;   // n_in = Sc (direct == 0) or nb (direct == 1)
+};
+
+hipError_t launch_pack(const float* canon_params, float* packed, hipStream_t stream);
+hipError_t launch_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int S,
+                                int lindisp, const float* t_rand, float* z_out, hipStream_t stream);
+hipError_t launch_embed(const float* x, long n_pts, int n_freqs, float* out, hipStream_t stream);
+hipError_t launch_composite(const CompositeArgs& a, bool bwd, hipStream_t stream);
+hipError_t launch_sample_fine(const FineArgs& a, hipStream_t stream);
+hipError_t launch_field_fwd(const float* packed, const float* rays, int ray_stride, const float* z_vals,
+                            int n_rays, int S, float* raw, float* act, hipStream_t stream);
+hipError_t launch_field_bwd(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
+                            float* delta, float* partial, float* grad, int accumulate, hipStream_t stream);
+size_t wgrad_partial_floats(long P);
+void pack_table_host(int* out);
+
+}  // namespace nerf

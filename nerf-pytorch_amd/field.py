@@ -1,0 +1,164 @@
+"""Field model host objects: ``Embedder`` / ``get_embedder`` / ``NeRF``.
+
+Same names, constructor arguments and ``state_dict`` layout as the reference
+(run_nerf_helpers.py:15-63, :67-119) so ``create_nerf`` / checkpoints /
+``torch.optim.Adam`` keep working unchanged -- but the arithmetic runs in the
+HIP library: ``NeRF`` keeps its 24 parameters as views into ONE flat fp32 vector
+(state_dict order) that the kernels read through a fragment repack, and
+``.grad`` of all of them are views into one flat gradient vector that a single
+RCCL all-reduce covers.
+"""
+import torch
+import torch.nn as nn
+
+from . import hip_backend as hb
+
+
+# --------------------------------------------------------------------------- positional encoding
+class Embedder:
+    """run_nerf_helpers.py:15-45.  Only the configuration get_embedder() builds is
+    supported (3 inputs, include_input, log-sampled power-of-two bands, [sin, cos])."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        d = kwargs["input_dims"]
+        n = kwargs["num_freqs"]
+        fns = list(kwargs.get("periodic_fns", []))
+        ok = (d == 3 and kwargs.get("include_input", True) and kwargs.get("log_sampling", True)
+              and kwargs["max_freq_log2"] == n - 1 and fns == [torch.sin, torch.cos])
+        if not ok:
+            raise NotImplementedError("Embedder: only get_embedder()'s configuration is implemented on gfx950")
+        self.num_freqs = n
+        self.out_dim = d + 2 * n * d
+
+    def embed(self, inputs):
+        return hb.embed(inputs.float(), self.num_freqs)
+
+
+def get_embedder(multires, i=0):
+    """run_nerf_helpers.py:48-63."""
+    if i == -1:
+        return nn.Identity(), 3
+    eo = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                  log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+    embed = lambda x, eo=eo: eo.embed(x)
+    embed.num_freqs = multires
+    return embed, eo.out_dim
+
+
+# --------------------------------------------------------------------------- the MLP
+class NeRF(nn.Module):
+    """Reference NeRF MLP (run_nerf_helpers.py:67-119), evaluated by fused HIP kernels.
+
+    Supported architecture = every BASELINE config: D=8, W=256, input_ch=63,
+    input_ch_views=27, skips=[4], use_viewdirs=True.  Anything else raises
+    (there is no eager fallback on the product path)."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
+        super().__init__()
+        if not (D == 8 and W == 256 and input_ch == 63 and input_ch_views == 27 and list(skips) == [4]
+                and use_viewdirs):
+            raise NotImplementedError(
+                "nerf-pytorch_amd implements NeRF(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], "
+                f"use_viewdirs=True); got D={D} W={W} input_ch={input_ch} input_ch_views={input_ch_views} "
+                f"skips={skips} use_viewdirs={use_viewdirs}")
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views = input_ch, input_ch_views
+        self.skips, self.use_viewdirs = skips, use_viewdirs
+        # same construction order as the reference => same default init from the same RNG state
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(input_ch, W)] + [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + input_ch, W)
+                                        for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        self.feature_linear = nn.Linear(W, W)
+        self.alpha_linear = nn.Linear(W, 1)
+        self.rgb_linear = nn.Linear(W // 2, 3)
+        self._flat = None
+        self._packed = None
+        self._packed_key = None
+        self.last_flat_grad = None      # set by the backward: flat gradient the .grad views live in
+        self._bind_flat()
+
+    # ---- flat parameter vector -------------------------------------------------
+    def _ordered_params(self):
+        sd = dict(self.named_parameters())
+        return [(nm, off, shape, sd[nm]) for nm, off, shape in _param_table()]
+
+    def _bind_flat(self):
+        """(Re)create the flat vector from the current parameter values and make every
+        parameter a view into it."""
+        params = self._ordered_params()
+        dev = params[0][3].device
+        flat = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for nm, off, shape, p in params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view(shape)
+        self._flat = flat
+        self._packed = None
+
+    def _is_bound(self):
+        base = self._flat.data_ptr()
+        for nm, off, shape, p in self._ordered_params():
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                return False
+        return True
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._bind_flat()
+        return out
+
+    def flat_params(self):
+        if self._flat is None or not self._is_bound():
+            self._bind_flat()
+        return self._flat
+
+    def packed_params(self):
+        """Fragment repack of the current parameters (cached on the parameters' versions)."""
+        flat = self.flat_params()
+        key = tuple(p._version for p in self.parameters()) + (flat.data_ptr(),)
+        if self._packed is None or key != self._packed_key:
+            # fresh tensor each time: a pending backward keeps a reference to the old one
+            self._packed = hb.pack_params(flat)
+            self._packed_key = key
+        return self._packed
+
+    def param_list(self):
+        return [p for _, _, _, p in self._ordered_params()]
+
+    # ---- reference call surface --------------------------------------------------
+    def forward(self, x):
+        """x [..., 90] = cat(embed(pts), embed(viewdirs)) as run_network builds it
+        (run_nerf.py:41-47).  The encoding is recomputed in-kernel from its identity
+        columns (x[..., 0:3] and x[..., 63:66]), so x must be a genuine embedding."""
+        from .render import query_points
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        out = query_points(self, x2[:, 0:3], x2[:, self.input_ch:self.input_ch + 3])
+        return out.reshape(*lead, 4)
+
+    def load_weights_from_keras(self, weights):
+        """run_nerf_helpers.py:121-148 (interop utility; copies into the flat vector)."""
+        import numpy as np
+        with torch.no_grad():
+            def put(lin, w, b):
+                lin.weight.copy_(torch.from_numpy(np.transpose(w)))
+                lin.bias.copy_(torch.from_numpy(np.transpose(b)))
+            for i in range(self.D):
+                put(self.pts_linears[i], weights[2 * i], weights[2 * i + 1])
+            put(self.feature_linear, weights[2 * self.D], weights[2 * self.D + 1])
+            put(self.views_linears[0], weights[2 * self.D + 2], weights[2 * self.D + 3])
+            put(self.rgb_linear, weights[2 * self.D + 4], weights[2 * self.D + 5])
+            put(self.alpha_linear, weights[2 * self.D + 6], weights[2 * self.D + 7])
+
+
+_TABLE = None
+
+
+def _param_table():
+    global _TABLE
+    if _TABLE is None:
+        _TABLE = hb.param_table()
+    return _TABLE

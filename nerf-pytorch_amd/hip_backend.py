@@ -1,0 +1,222 @@
+"""ctypes binding of libnerf_hip.so (C ABI: include/nerf_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function
+below hands raw device pointers of fp32 CUDA(ROCm) tensors to the library and
+enqueues HIP kernels on ``torch.cuda.current_stream()``.
+
+There is no fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+import torch  # import torch BEFORE loading the library: one HIP runtime per process (torch's bundled one)
+
+from . import build as _build
+
+_c_float_p = ctypes.c_void_p
+_LIB = None
+
+
+class NerfHipError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    i, l, f, p, sz = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+    sig = {
+        "nerf_abi_version": (i, []),
+        "nerf_last_error": (ctypes.c_char_p, []),
+        "nerf_param_count": (i, []),
+        "nerf_param_offset": (i, [i, ctypes.POINTER(i), ctypes.POINTER(i)]),
+        "nerf_packed_floats": (i, []),
+        "nerf_pack_params": (i, [p, p, p]),
+        "nerf_debug_pack_table": (i, [p]),
+        "nerf_embed": (i, [p, l, i, p, p]),
+        "nerf_sample_coarse": (i, [p, i, i, p, i, i, p, p, p]),
+        "nerf_act_floats": (sz, [i, i]),
+        "nerf_field_fwd": (i, [p, p, i, p, i, i, p, p, p]),
+        "nerf_raw2outputs": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p, p]),
+        "nerf_raw2outputs_bwd": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p]),
+        "nerf_sample_fine": (i, [p, p, i, i, i, p, p, p, p, p, p]),
+        "nerf_sample_pdf": (i, [p, p, i, i, i, p, p, p, p]),
+        "nerf_delta_floats": (sz, [i, i]),
+        "nerf_wgrad_partial_floats": (sz, [i, i]),
+        "nerf_field_bwd": (i, [p, p, p, i, i, p, p, p, i, p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
+           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_sample_coarse", "nerf_act_floats", "nerf_field_fwd",
+           "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
+           "nerf_wgrad_partial_floats", "nerf_field_bwd"]
+
+
+def lib():
+    """Load (once) and return the shared library.  Raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise NerfHipError(
+                f"{path} not found: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
+                "There is no PyTorch fallback for the render hot path.")
+        _LIB = ctypes.CDLL(path)
+        _declare(_LIB)
+        if _LIB.nerf_abi_version() != 1:
+            raise NerfHipError("libnerf_hip.so ABI version mismatch")
+    return _LIB
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise NerfHipError(f"{name} failed (code {rc}): {lib().nerf_last_error().decode()}")
+
+
+def _ptr(t, name="tensor", optional=False):
+    if t is None:
+        if optional:
+            return None
+        raise NerfHipError(f"{name} is required")
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise NerfHipError(f"{name} must be a contiguous fp32 tensor on the GPU "
+                           f"(got {type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)})")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+N_PARAMS = 595844
+
+
+def param_table():
+    """[(name, offset, shape)] of the flat parameter vector, from the library itself."""
+    L = lib()
+    names = []
+    for i in range(8):
+        names += [f"pts_linears.{i}.weight", f"pts_linears.{i}.bias"]
+    names += ["views_linears.0.weight", "views_linears.0.bias", "feature_linear.weight", "feature_linear.bias",
+              "alpha_linear.weight", "alpha_linear.bias", "rgb_linear.weight", "rgb_linear.bias"]
+    out = []
+    for idx, nm in enumerate(names):
+        r, c = ctypes.c_int(), ctypes.c_int()
+        off = L.nerf_param_offset(idx, ctypes.byref(r), ctypes.byref(c))
+        shape = (r.value, c.value) if nm.endswith("weight") else (r.value,)
+        out.append((nm, off, shape))
+    return out
+
+
+def pack_table():
+    """Host-side gather table of the fragment repack (numpy int32, -1 = zero padding)."""
+    import numpy as np
+    L = lib()
+    tab = np.empty(L.nerf_packed_floats(), dtype=np.int32)
+    _check(L.nerf_debug_pack_table(tab.ctypes.data_as(ctypes.c_void_p)), "nerf_debug_pack_table")
+    return tab
+
+
+def pack_params(flat, out=None):
+    L = lib()
+    if out is None:
+        out = torch.empty(L.nerf_packed_floats(), dtype=torch.float32, device=flat.device)
+    _check(L.nerf_pack_params(_ptr(flat, "params"), _ptr(out, "packed"), _stream()), "nerf_pack_params")
+    return out
+
+
+def embed(x, n_freqs):
+    x = x.contiguous()
+    out = torch.empty(x.shape[:-1] + (3 + 6 * n_freqs,), dtype=torch.float32, device=x.device)
+    n = x.numel() // 3
+    _check(lib().nerf_embed(_ptr(x, "x"), n, n_freqs, _ptr(out), _stream()), "nerf_embed")
+    return out
+
+
+def sample_coarse(rays, t_vals, lindisp, t_rand):
+    n, stride = rays.shape
+    S = t_vals.numel()
+    z = torch.empty((n, S), dtype=torch.float32, device=rays.device)
+    _check(lib().nerf_sample_coarse(_ptr(rays, "rays"), stride, n, _ptr(t_vals, "t_vals"), S, int(bool(lindisp)),
+                                    _ptr(t_rand, "t_rand", True), _ptr(z), _stream()), "nerf_sample_coarse")
+    return z
+
+
+def act_floats(n_rays, n_samples):
+    return lib().nerf_act_floats(n_rays, n_samples)
+
+
+def field_fwd(packed, rays, z_vals, save_act=False):
+    n, stride = rays.shape
+    S = z_vals.shape[1]
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
+    act = torch.empty(act_floats(n, S), dtype=torch.float32, device=rays.device) if save_act else None
+    _check(lib().nerf_field_fwd(_ptr(packed, "packed"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"), n, S,
+                                _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd")
+    return raw, act
+
+
+def raw2outputs(raw, z_vals, rays_d, dir_stride, noise, raw_noise_std, white_bkgd, want_weights=True, want_depth=True,
+                rays_d_offset=0):
+    """rays_d: tensor whose element [rays_d_offset] is ray 0's first direction component."""
+    n, S = z_vals.shape
+    dev = raw.device
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((n,), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    weights = torch.empty((n, S), dtype=torch.float32, device=dev) if want_weights else None
+    depth = torch.empty((n,), dtype=torch.float32, device=dev) if want_depth else None
+    dptr = _ptr(rays_d, "rays_d") + 4 * rays_d_offset
+    _check(lib().nerf_raw2outputs(_ptr(raw, "raw"), _ptr(z_vals, "z_vals"), dptr, dir_stride, n, S,
+                                  _ptr(noise, "noise", True), float(raw_noise_std), int(bool(white_bkgd)),
+                                  _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(weights, "w", True), _ptr(depth, "d", True),
+                                  _stream()), "nerf_raw2outputs")
+    return rgb, disp, acc, weights, depth
+
+
+def raw2outputs_bwd(raw, z_vals, rays_d, dir_stride, noise, raw_noise_std, white_bkgd, d_rgb, d_acc, d_disp,
+                    rays_d_offset=0):
+    n, S = z_vals.shape
+    d_raw = torch.empty((n, S, 4), dtype=torch.float32, device=raw.device)
+    dptr = _ptr(rays_d, "rays_d") + 4 * rays_d_offset
+    _check(lib().nerf_raw2outputs_bwd(_ptr(raw, "raw"), _ptr(z_vals, "z_vals"), dptr, dir_stride, n, S,
+                                      _ptr(noise, "noise", True), float(raw_noise_std), int(bool(white_bkgd)),
+                                      _ptr(d_rgb, "d_rgb"), _ptr(d_acc, "d_acc", True), _ptr(d_disp, "d_disp", True),
+                                      _ptr(d_raw), _stream()), "nerf_raw2outputs_bwd")
+    return d_raw
+
+
+def sample_fine(z_vals, weights, n_fine, u, u_lin, want_samples=False):
+    n, Sc = z_vals.shape
+    dev = z_vals.device
+    z_all = torch.empty((n, Sc + n_fine), dtype=torch.float32, device=dev)
+    z_std = torch.empty((n,), dtype=torch.float32, device=dev)
+    z_samples = torch.empty((n, n_fine), dtype=torch.float32, device=dev) if want_samples else None
+    _check(lib().nerf_sample_fine(_ptr(z_vals, "z_vals"), _ptr(weights, "weights"), n, Sc, n_fine,
+                                  _ptr(u, "u", True), _ptr(u_lin, "u_lin", True), _ptr(z_all),
+                                  _ptr(z_samples, "z_samples", True), _ptr(z_std), _stream()), "nerf_sample_fine")
+    return z_all, z_std, z_samples
+
+
+def sample_pdf(bins, weights, n_samples, u, u_lin):
+    n, nb = bins.shape
+    out = torch.empty((n, n_samples), dtype=torch.float32, device=bins.device)
+    _check(lib().nerf_sample_pdf(_ptr(bins, "bins"), _ptr(weights, "weights"), n, nb, n_samples,
+                                 _ptr(u, "u", True), _ptr(u_lin, "u_lin", True), _ptr(out), _stream()),
+           "nerf_sample_pdf")
+    return out
+
+
+def field_bwd(packed, act, d_raw, grad, accumulate):
+    n, S, _ = d_raw.shape
+    L = lib()
+    dev = d_raw.device
+    delta = torch.empty(L.nerf_delta_floats(n, S), dtype=torch.float32, device=dev)
+    partial = torch.empty(L.nerf_wgrad_partial_floats(n, S), dtype=torch.float32, device=dev)
+    _check(L.nerf_field_bwd(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
+                            _ptr(partial), _ptr(grad, "grad"), int(bool(accumulate)), _stream()), "nerf_field_bwd")
+    return grad

@@ -1,0 +1,456 @@
+"""Volumetric renderer host code: the reference's hot-path call surface
+(run_nerf.py:27-134, :262-418; run_nerf_helpers.py:153-239) on top of the HIP
+library.  Function names, argument order, defaults and returned structures are
+the reference's; the bodies enqueue fused kernels instead of ATen op chains.
+
+Random draws (stratified jitter, density noise, CDF samples) are made here with
+torch, in the reference's order and shapes, and handed to the
+kernels, so a seeded run consumes the generator exactly like the reference.
+"""
+import numpy as np
+import torch
+
+from . import hip_backend as hb
+from .field import NeRF
+
+_LINSPACE_CACHE = {}
+
+
+def _linspace01(n, device):
+    key = (n, str(device))
+    t = _LINSPACE_CACHE.get(key)
+    if t is None:
+        t = torch.linspace(0.0, 1.0, steps=n, dtype=torch.float32, device=device)
+        _LINSPACE_CACHE[key] = t
+    return t
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------- autograd glue
+class _FieldQuery(torch.autograd.Function):
+    """raw = field(rays, z) for explicit rays/depths; gradients w.r.t. the parameters only."""
+
+    @staticmethod
+    def forward(ctx, model, rays, z_vals, *params):
+        need = any(ctx.needs_input_grad[3:])
+        packed = model.packed_params()
+        raw, act = hb.field_fwd(packed, rays, z_vals, save_act=need)
+        ctx.model, ctx.packed, ctx.act = model, packed, act
+        ctx.set_materialize_grads(False)
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        model = ctx.model
+        if d_raw is None or ctx.act is None:
+            return (None, None, None) + (None,) * len(_param_slices(model))
+        grad = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=d_raw.device)
+        hb.field_bwd(ctx.packed, ctx.act, d_raw.contiguous(), grad, accumulate=False)
+        ctx.act = None
+        model.last_flat_grad = grad
+        return (None, None, None) + _grad_views(model, grad)
+
+
+def _param_slices(model):
+    from .field import _param_table
+    return _param_table()
+
+
+def _grad_views(model, flat_grad):
+    return tuple(flat_grad[off:off + int(np.prod(shape))].view(shape) for _, off, shape in _param_slices(model))
+
+
+class _RenderRays(torch.autograd.Function):
+    """The whole of render_rays (run_nerf.py:308-418) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, cfg, rays, rnd, model_c, model_f, *params):
+        n_c, n_f = cfg["N_samples"], cfg["N_importance"]
+        same_net = model_f is None or model_f is model_c
+        need = any(ctx.needs_input_grad[5:])
+        dev = rays.device
+        std = cfg["raw_noise_std"]
+        wb = cfg["white_bkgd"]
+        packed_c = model_c.packed_params()
+        z_c = hb.sample_coarse(rays, _linspace01(n_c, dev), cfg["lindisp"], rnd.get("t_rand"))
+        raw_c, act_c = hb.field_fwd(packed_c, rays, z_c, save_act=need)
+        rgb_c, disp_c, acc_c, w_c, _ = hb.raw2outputs(raw_c, z_c, rays, rays.shape[1], rnd.get("noise_c"), std, wb,
+                                                      want_weights=n_f > 0, want_depth=False, rays_d_offset=3)
+        ctx.cfg, ctx.model_c, ctx.model_f, ctx.same_net = cfg, model_c, model_f, same_net
+        ctx.n_params_c = len(_param_slices(model_c))
+        ctx.set_materialize_grads(False)
+        if n_f <= 0:
+            ctx.save_for_backward(rays, z_c, raw_c)
+            ctx.saved = dict(act_c=act_c, packed_c=packed_c, rnd=rnd)
+            ctx.mark_non_differentiable(raw_c)
+            return rgb_c, disp_c, acc_c, raw_c
+        u = rnd.get("u")
+        z_f, z_std, _ = hb.sample_fine(z_c, w_c, n_f, u, None if u is not None else _linspace01(n_f, dev))
+        mf = model_c if same_net else model_f
+        packed_f = mf.packed_params()
+        raw_f, act_f = hb.field_fwd(packed_f, rays, z_f, save_act=need)
+        rgb_f, disp_f, acc_f, _, _ = hb.raw2outputs(raw_f, z_f, rays, rays.shape[1], rnd.get("noise_f"), std, wb,
+                                                    want_weights=False, want_depth=False, rays_d_offset=3)
+        ctx.save_for_backward(rays, z_c, raw_c, z_f, raw_f)
+        ctx.saved = dict(act_c=act_c, packed_c=packed_c, rnd=rnd, act_f=act_f, packed_f=packed_f)
+        ctx.mark_non_differentiable(raw_f, z_std)
+        return rgb_f, disp_f, acc_f, raw_f, rgb_c, disp_c, acc_c, z_std
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        s, cfg = dict(ctx.saved), ctx.cfg
+        tens = ctx.saved_tensors
+        s.update(rays=tens[0], z_c=tens[1], raw_c=tens[2])
+        if len(tens) > 3:
+            s.update(z_f=tens[3], raw_f=tens[4])
+        rays, rnd = s["rays"], s["rnd"]
+        std, wb = cfg["raw_noise_std"], cfg["white_bkgd"]
+        n_lead = 5
+        none_c = (None,) * ctx.n_params_c
+        if s["act_c"] is None:
+            return (None,) * n_lead + none_c + (() if ctx.same_net else (None,) * ctx.n_params_c)
+        dev = rays.device
+        n = rays.shape[0]
+
+        def cgrads(d_rgb, d_disp, d_acc):
+            zero = lambda t, shape: t.contiguous() if t is not None else None
+            if d_rgb is None and d_disp is None and d_acc is None:
+                return None
+            if d_rgb is None:
+                d_rgb = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+            return d_rgb.contiguous(), zero(d_acc, n), zero(d_disp, n)
+
+        def field_grad(model, packed, act, raw, z, noise, g, grad, accumulate):
+            d_rgb, d_acc, d_disp = g
+            d_raw = hb.raw2outputs_bwd(raw, z, rays, rays.shape[1], noise, std, wb, d_rgb, d_acc, d_disp,
+                                       rays_d_offset=3)
+            hb.field_bwd(packed, act, d_raw, grad, accumulate)
+
+        if cfg["N_importance"] <= 0:
+            g = cgrads(gouts[0], gouts[1], gouts[2])
+            if g is None:
+                return (None,) * n_lead + none_c
+            grad_c = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
+            field_grad(ctx.model_c, s["packed_c"], s["act_c"], s["raw_c"], s["z_c"], rnd.get("noise_c"), g, grad_c, False)
+            ctx.model_c.last_flat_grad = grad_c
+            ctx.saved = None
+            return (None,) * n_lead + _grad_views(ctx.model_c, grad_c)
+
+        g_f = cgrads(gouts[0], gouts[1], gouts[2])
+        g_c = cgrads(gouts[4], gouts[5], gouts[6])
+        grad_c = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
+        wrote_c = False
+        if g_c is not None:
+            field_grad(ctx.model_c, s["packed_c"], s["act_c"], s["raw_c"], s["z_c"], rnd.get("noise_c"), g_c, grad_c, False)
+            wrote_c = True
+        grad_f = None
+        if ctx.same_net:
+            if g_f is not None:
+                field_grad(ctx.model_c, s["packed_f"], s["act_f"], s["raw_f"], s["z_f"], rnd.get("noise_f"), g_f, grad_c, wrote_c)
+                wrote_c = True
+        elif g_f is not None:
+            grad_f = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
+            field_grad(ctx.model_f, s["packed_f"], s["act_f"], s["raw_f"], s["z_f"], rnd.get("noise_f"), g_f, grad_f, False)
+            ctx.model_f.last_flat_grad = grad_f
+        ctx.saved = None
+        out_c = _grad_views(ctx.model_c, grad_c) if wrote_c else none_c
+        if wrote_c:
+            ctx.model_c.last_flat_grad = grad_c
+        if ctx.same_net:
+            return (None,) * n_lead + out_c
+        out_f = _grad_views(ctx.model_f, grad_f) if grad_f is not None else (None,) * ctx.n_params_c
+        return (None,) * n_lead + out_c + out_f
+
+
+class _Composite(torch.autograd.Function):
+    """raw2outputs with a gradient w.r.t. raw (for callers that use it standalone)."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays_d, noise, raw_noise_std, white_bkgd):
+        rgb, disp, acc, w, depth = hb.raw2outputs(raw, z_vals, rays_d, 3, noise, raw_noise_std, white_bkgd)
+        ctx.args = (raw, z_vals, rays_d, noise, raw_noise_std, white_bkgd)
+        ctx.mark_non_differentiable(w, depth)
+        ctx.set_materialize_grads(False)
+        return rgb, disp, acc, w, depth
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_disp, d_acc, d_w, d_depth):
+        raw, z_vals, rays_d, noise, std, wb = ctx.args
+        if d_rgb is None and d_disp is None and d_acc is None:
+            return (None,) * 6
+        if d_rgb is None:
+            d_rgb = torch.zeros((raw.shape[0], 3), dtype=torch.float32, device=raw.device)
+        c = lambda t: t.contiguous() if t is not None else None
+        d_raw = hb.raw2outputs_bwd(raw, z_vals, rays_d, 3, noise, std, wb, d_rgb.contiguous(), c(d_acc), c(d_disp))
+        return d_raw, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------- reference call surface
+def query_points(model, pts, viewdirs_per_point):
+    """Evaluate the field at explicit points: every point is its own ray record
+    (o = pt, d = 0, z = 0  =>  o + d*z == pt exactly)."""
+    pts = _f32c(pts)
+    vd = _f32c(viewdirs_per_point)
+    n = pts.shape[0]
+    rays = torch.zeros((n, 11), dtype=torch.float32, device=pts.device)
+    rays[:, 0:3] = pts
+    rays[:, 8:11] = vd
+    z = torch.zeros((n, 1), dtype=torch.float32, device=pts.device)
+    raw = _FieldQuery.apply(model, rays, z, *model.param_list())
+    return raw.reshape(n, 4)
+
+
+def batchify(fn, chunk):
+    """run_nerf.py:27-34."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """run_nerf.py:37-51.  inputs [N,S,3], viewdirs [N,3], fn a NeRF module.  The embedders are
+    accepted for signature parity; encoding happens inside the fused kernel (and the
+    netchunk loop disappears: the kernel tiles the points itself)."""
+    if not isinstance(fn, NeRF):
+        raise NotImplementedError("run_network: fn must be a nerf-pytorch_amd NeRF module")
+    if viewdirs is None:
+        raise NotImplementedError("run_network: use_viewdirs=False is not implemented on gfx950")
+    flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    dirs = viewdirs[:, None].expand(inputs.shape)
+    dirs_flat = torch.reshape(dirs, [-1, dirs.shape[-1]])
+    out = query_points(fn, flat, dirs_flat)
+    return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
+    """run_nerf.py:262-305: (rgb_map, disp_map, acc_map, weights, depth_map)."""
+    noise = None
+    std = float(raw_noise_std)
+    if raw_noise_std > 0.0:
+        noise = torch.randn(raw[..., 3].shape, device=raw.device)
+        if pytest:
+            np.random.seed(0)
+            noise = torch.Tensor(np.random.rand(*list(raw[..., 3].shape)) * raw_noise_std).to(raw.device)
+            std = 1.0
+        noise = noise.contiguous()
+    raw_c = raw.to(torch.float32).contiguous()
+    return _Composite.apply(raw_c, _f32c(z_vals), _f32c(rays_d), noise, std, bool(white_bkgd))
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    """run_nerf_helpers.py:196-239 (output is a constant: the reference detaches it, run_nerf.py:394)."""
+    bins, weights = _f32c(bins), _f32c(weights)
+    dev = bins.device
+    lead = list(bins.shape[:-1])
+    u = None
+    if not det:
+        u = torch.rand(lead + [N_samples], device=dev)
+    if pytest:
+        np.random.seed(0)
+        if det:
+            u = torch.Tensor(np.broadcast_to(np.linspace(0.0, 1.0, N_samples), lead + [N_samples]).copy()).to(dev)
+        else:
+            u = torch.Tensor(np.random.rand(*(lead + [N_samples]))).to(dev)
+    b2 = bins.reshape(-1, bins.shape[-1])
+    w2 = weights.reshape(-1, weights.shape[-1])
+    u2 = u.reshape(-1, N_samples).contiguous() if u is not None else None
+    out = hb.sample_pdf(b2, w2, N_samples, u2, None if u2 is not None else _linspace01(N_samples, dev))
+    return out.reshape(lead + [N_samples])
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
+                *, randoms=None):
+    """run_nerf.py:308-418.  Same arguments, same returned dict.
+
+    ``randoms`` (keyword-only, not in the reference) injects the random tensors
+    {t_rand [N,N_samples], noise_c [N,N_samples], u [N,N_importance], noise_f [N,N_samples+N_importance]}
+    instead of drawing them: the explicit form of the reference's ``pytest=`` hook."""
+    if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
+        raise NotImplementedError("render_rays: network_fn / network_fine must be nerf-pytorch_amd NeRF modules")
+    if ray_batch.shape[-1] <= 8:
+        raise NotImplementedError("render_rays: rays without view directions (use_viewdirs=False) are not implemented")
+    rays = ray_batch.to(torch.float32).contiguous().detach()
+    n = rays.shape[0]
+    dev = rays.device
+    n_f = int(N_importance)
+    rnd = {}
+    if randoms is not None:
+        keys = (["t_rand"] if perturb > 0. else []) + (["noise_c"] if raw_noise_std > 0. else [])
+        if n_f > 0:
+            keys += (["u"] if perturb > 0. else []) + (["noise_f"] if raw_noise_std > 0. else [])
+        rnd = {k: randoms[k].to(device=dev, dtype=torch.float32).contiguous() for k in keys}
+        perturb_draw = 0.
+    else:
+        perturb_draw = perturb
+    # draw order of the reference: t_rand (:371) -> noise coarse (:285) -> u (helpers:208) -> noise fine (:285)
+    if perturb_draw > 0.:
+        rnd["t_rand"] = torch.rand((n, N_samples), device=dev)
+        if pytest:
+            np.random.seed(0)
+            rnd["t_rand"] = torch.Tensor(np.random.rand(n, N_samples)).to(dev)
+    std = float(raw_noise_std)
+
+    def draw_noise(S):
+        nz = torch.randn((n, S), device=dev)
+        if pytest:
+            np.random.seed(0)
+            nz = torch.Tensor(np.random.rand(n, S) * raw_noise_std).to(dev)
+        return nz.contiguous()
+    if raw_noise_std > 0. and randoms is None:
+        rnd["noise_c"] = draw_noise(N_samples)
+    if n_f > 0:
+        if perturb_draw > 0.:
+            rnd["u"] = torch.rand((n, n_f), device=dev)
+            if pytest:
+                np.random.seed(0)
+                rnd["u"] = torch.Tensor(np.random.rand(n, n_f)).to(dev)
+        elif pytest:
+            pass        # det + pytest: np.linspace == torch.linspace to fp32 rounding; kernel uses torch.linspace
+        if raw_noise_std > 0. and randoms is None:
+            rnd["noise_f"] = draw_noise(N_samples + n_f)
+    if pytest and raw_noise_std > 0. and randoms is None:
+        std = 1.0       # pytest noise is pre-scaled in float64 like the reference (run_nerf.py:290)
+    cfg = dict(N_samples=int(N_samples), N_importance=n_f, lindisp=bool(lindisp), white_bkgd=bool(white_bkgd),
+               raw_noise_std=std)
+    params = network_fn.param_list()
+    same = network_fine is None or network_fine is network_fn
+    if n_f > 0 and not same:
+        params = params + network_fine.param_list()
+    outs = _RenderRays.apply(cfg, rays, rnd, network_fn, None if (same or n_f <= 0) else network_fine, *params)
+    if n_f <= 0:
+        rgb_map, disp_map, acc_map, raw = outs
+        ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+        if retraw:
+            ret['raw'] = raw
+        return ret
+    rgb_map, disp_map, acc_map, raw, rgb0, disp0, acc0, z_std = outs
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    if retraw:
+        ret['raw'] = raw
+    ret['rgb0'] = rgb0
+    ret['disp0'] = disp0
+    ret['acc0'] = acc0
+    ret['z_std'] = z_std
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """run_nerf.py:54-66."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+
+# ---- ray geometry: per-ray (not per-sample) work, stays PyTorch behind render()
+def get_rays(H, W, K, c2w):
+    """run_nerf_helpers.py:153-162."""
+    dev = c2w.device if isinstance(c2w, torch.Tensor) else None
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=dev), torch.linspace(0, H - 1, H, device=dev), indexing='ij')
+    i = i.t()
+    j = j.t()
+    dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def get_rays_np(H, W, K, c2w):
+    """run_nerf_helpers.py:165-172."""
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
+    dirs = np.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -np.ones_like(i)], -1)
+    rays_d = np.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+    rays_o = np.broadcast_to(c2w[:3, -1], np.shape(rays_d))
+    return rays_o, rays_d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """run_nerf_helpers.py:175-192."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2. * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """run_nerf.py:69-134: [rgb_map, disp_map, acc_map, extras]."""
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+    if not use_viewdirs:
+        raise NotImplementedError("render: use_viewdirs=False is not implemented on gfx950 (all BASELINE configs use it)")
+    viewdirs = rays_d
+    if c2w_staticcam is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
+    viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+    viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    sh = rays_d.shape
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    rays = torch.cat([rays_o, rays_d, near, far, viewdirs], -1)
+    all_ret = batchify_rays(rays, chunk, **kwargs)
+    for k in all_ret:
+        k_sh = list(sh[:-1]) + list(all_ret[k].shape[1:])
+        all_ret[k] = torch.reshape(all_ret[k], k_sh)
+    k_extract = ['rgb_map', 'disp_map', 'acc_map']
+    ret_list = [all_ret[k] for k in k_extract]
+    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+    return ret_list + [ret_dict]
+
+
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
+img2mse = lambda x, y: torch.mean((x - y) ** 2)
+mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device if isinstance(x, torch.Tensor) else None))
+
+
+def _write_png(path, rgb8):
+    """Minimal PNG writer (imageio is not a dependency of the hot path)."""
+    import struct
+    import zlib
+    h, w, c = rgb8.shape
+    rows = b"".join(b"\x00" + rgb8[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0))
+    png += chunk(b"IDAT", zlib.compress(rows, 6)) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(png)
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
+    """run_nerf.py:137-175: (rgbs[F,H,W,3], disps[F,H,W]) as numpy."""
+    import os
+    H, W, focal = hwf
+    if render_factor != 0:
+        H = H // render_factor
+        W = W // render_factor
+        focal = focal / render_factor
+    rgbs, disps = [], []
+    for i, c2w in enumerate(render_poses):
+        rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+        if savedir is not None:
+            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
+    return np.stack(rgbs, 0), np.stack(disps, 0)

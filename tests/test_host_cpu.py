@@ -1,0 +1,123 @@
+"""CPU: C-ABI surface, host-side objects (NeRF module / flat parameter vector / config parser / create_nerf)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import nerf_oracle as orc
+import nerf_pytorch_amd as npa
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    declared = set(re.findall(r"\b(nerf_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(npa.build.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/nerf_hip.h but not exported"
+    assert declared == set(npa.hip_backend.EXPORTS), declared ^ set(npa.hip_backend.EXPORTS)
+    L = npa.hip_backend.lib()
+    assert L.nerf_abi_version() == 1 and L.nerf_param_count() == 595844
+    assert L.nerf_packed_floats() % 4 == 0
+
+
+def test_argument_errors_are_codes_not_crashes():
+    L = npa.hip_backend.lib()
+    assert L.nerf_pack_params(None, None, None) == -1
+    assert b"null pointer" in L.nerf_last_error()
+    assert L.nerf_field_fwd(None, None, 11, None, 4, 4, None, None, None) == -1
+    assert L.nerf_act_floats(0, 64) == 0
+    n, S = 4096, 192
+    P = n * S
+    assert L.nerf_act_floats(n, S) == P * (9 * 256 + 128 + 64) + n * 32 + 9 * P * 8
+    assert L.nerf_delta_floats(n, S) == P * (9 * 256 + 128)
+    assert L.nerf_wgrad_partial_floats(n, S) % 595844 == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(npa.hip_backend, "_LIB", None)
+    monkeypatch.setattr(npa.build, "LIB_PATH", "/nonexistent/libnerf_hip.so")
+    with pytest.raises(npa.hip_backend.NerfHipError):
+        npa.hip_backend.lib()
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    x = torch.randn(4, 3)
+    with pytest.raises(npa.hip_backend.NerfHipError):
+        npa.hip_backend.embed(x, 10)
+
+
+def test_nerf_module_state_dict_and_flat_binding():
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    torch.manual_seed(3)
+    m = npa.NeRF(**kw)
+    want = [nm for nm, _ in orc.param_shapes()]
+    assert list(m.state_dict().keys()) == want
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(s) for _, s in orc.param_shapes()]
+    assert m._is_bound()
+    P = orc.make_params(5)
+    m.load_state_dict(P)
+    assert m._is_bound()
+    flat = m.flat_params()
+    for nm, off, shape in npa.hip_backend.param_table():
+        assert torch.equal(flat[off:off + int(np.prod(shape))].view(shape), P[nm])
+    # optimizer updates go through to the flat vector
+    opt = torch.optim.SGD(m.parameters(), lr=1.0)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert torch.allclose(flat[:10], P["pts_linears.0.weight"].reshape(-1)[:10] - 1.0)
+    # dtype / device moves re-bind
+    m2 = m.to(torch.device("cpu"))
+    assert m2._is_bound()
+    # same default init as the reference architecture under the same seed
+    torch.manual_seed(3)
+    ref_first = torch.nn.Linear(63, 256).weight
+    torch.manual_seed(3)
+    assert torch.equal(npa.NeRF(**kw).pts_linears[0].weight, ref_first)
+
+
+def test_unsupported_architectures_raise():
+    with pytest.raises(NotImplementedError):
+        npa.NeRF(D=8, W=128, input_ch=63, input_ch_views=27, use_viewdirs=True)
+    with pytest.raises(NotImplementedError):
+        npa.NeRF(D=8, W=256, input_ch=63, input_ch_views=0, use_viewdirs=False)
+
+
+def test_config_parser_reads_reference_style_files(tmp_path):
+    cfg = tmp_path / "lego.txt"
+    cfg.write_text("expname = blender_paper_lego\nbasedir = ./logs\ndatadir = ./data/nerf_synthetic/lego\n"
+                   "dataset_type = blender\n\nno_batching = True\n\nuse_viewdirs = True\nwhite_bkgd = True\n"
+                   "lrate_decay = 500\n\nN_samples = 64\nN_importance = 128\nN_rand = 1024\n\n"
+                   "precrop_iters = 500\nprecrop_frac = 0.5\n\nhalf_res = True\n")
+    a = npa.config_parser().parse_args(["--config", str(cfg), "--N_rand", "4096"])
+    assert (a.expname, a.N_rand, a.N_importance, a.use_viewdirs, a.white_bkgd, a.half_res, a.no_batching) == \
+           ("blender_paper_lego", 4096, 128, True, True, True, True)
+    assert (a.netdepth, a.netwidth, a.chunk, a.netchunk, a.multires, a.multires_views, a.perturb, a.lrate) == \
+           (8, 256, 32768, 65536, 10, 4, 1.0, 5e-4)
+    d = npa.config_parser().parse_args([])
+    assert d.N_rand == 4096 and d.dataset_type == "llff" and d.i_weights == 10000 and not d.lindisp
+
+
+def test_create_nerf_builds_the_reference_kwargs(tmp_path):
+    a = npa.config_parser().parse_args(["--expname", "t", "--basedir", str(tmp_path), "--use_viewdirs",
+                                       "--N_importance", "128", "--white_bkgd", "--dataset_type", "blender"])
+    (tmp_path / "t").mkdir()
+    tr, te, start, grad_vars, opt = npa.create_nerf(a, device=torch.device("cpu"))
+    assert start == 0 and len(grad_vars) == 48 and isinstance(opt, torch.optim.Adam)
+    assert set(tr) == {"network_query_fn", "perturb", "N_importance", "network_fine", "N_samples", "network_fn",
+                       "use_viewdirs", "white_bkgd", "raw_noise_std", "ndc", "lindisp"}
+    assert te["perturb"] is False and te["raw_noise_std"] == 0. and tr["ndc"] is False
+    assert isinstance(tr["network_fn"], npa.NeRF) and isinstance(tr["network_fine"], npa.NeRF)
+    # checkpoint round trip in the reference's format (run_nerf.py:792-800, reload :216-233)
+    torch.save({"global_step": 7, "network_fn_state_dict": tr["network_fn"].state_dict(),
+                "network_fine_state_dict": tr["network_fine"].state_dict(),
+                "optimizer_state_dict": opt.state_dict()}, tmp_path / "t" / "000007.tar")
+    tr2, _, start2, _, _ = npa.create_nerf(a, device=torch.device("cpu"))
+    assert start2 == 7
+    assert torch.equal(tr2["network_fn"].flat_params(), tr["network_fn"].flat_params())

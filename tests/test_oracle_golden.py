@@ -1,0 +1,84 @@
+"""CPU: the oracle reproduces every golden fixture produced by the real reference, and (when the
+reference tree is present, i.e. in the build container) is bit-identical to it function by function."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nerf_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = {
+    "lego_det": (dict(), None),
+    "lego_train": (dict(perturb=1.0), 123),
+    "fern_train": (dict(perturb=1.0, raw_noise_std=1.0, white_bkgd=False, n_fine=64, lindisp=True), 321),
+    "lego_coarse_only": (dict(perturb=1.0, n_fine=0), 11),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_reference_golden(name):
+    kw, seed = CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    rays = orc.synthetic_rays(256, seed=7)
+    target = torch.tensor(np.random.RandomState(99).rand(256, 3), dtype=torch.float32)
+    Pc, Pf = orc.scene_params()
+    assert abs(float(rays.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-9
+    pcs = sum(float(torch.cat([v.reshape(-1) for v in P.values()]).double().abs().sum()) for P in (Pc, Pf))
+    assert abs(pcs - float(gold["params_checksum"])) < 1e-6
+    Pc = {k: v.requires_grad_(True) for k, v in Pc.items()}
+    Pf = {k: v.requires_grad_(True) for k, v in Pf.items()}
+    args = dict(n_coarse=64, n_fine=128, perturb=0.0, white_bkgd=True, raw_noise_std=0.0, lindisp=False, retraw=True)
+    args.update(kw)
+    rnd = {}
+    if seed is not None:
+        torch.manual_seed(seed)
+        if args["perturb"] > 0:
+            rnd["t_rand"] = torch.rand(256, 64)
+        if args["raw_noise_std"] > 0:
+            rnd["noise_c"] = torch.randn(256, 64)
+        if args["n_fine"] > 0 and args["perturb"] > 0:
+            rnd["u"] = torch.rand(256, args["n_fine"])
+        if args["n_fine"] > 0 and args["raw_noise_std"] > 0:
+            rnd["noise_f"] = torch.randn(256, 64 + args["n_fine"])
+    out = orc.trace_rays(rays, Pc, Pf if args["n_fine"] > 0 else None, **args, **rnd)
+    loss = orc.mse(out["rgb_map"], target)
+    if "rgb0" in out:
+        loss = loss + orc.mse(out["rgb0"], target)
+    loss.backward()
+    assert loss.item() == float(gold["loss"])
+    for k in gold.files:
+        if k in out:
+            got = out[k].detach()
+            got = got[:, ::8] if k == "raw" else got
+            a, b = got.numpy(), gold[k]
+            assert np.array_equal(a, b, equal_nan=True), k
+    for tag, P in (("c", Pc), ("f", Pf)):
+        for nm, p in P.items():
+            key = f"{tag}/{nm}/val"
+            if key in gold.files:
+                assert np.array_equal(p.grad.reshape(-1)[gold[f"{tag}/{nm}/idx"]].numpy(), gold[key]), (tag, nm)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_oracle_is_bit_identical_to_the_reference():
+    import pin_against_reference
+    pin_against_reference.main(n_rays=48)
+
+
+def test_known_answers():
+    """Facts about the reference established in SURVEY §8c."""
+    x = torch.tensor([[0.5, -1.0, 2.0]])
+    e = orc.posenc(x, 10)
+    assert e.shape == (1, 63)
+    assert torch.equal(e[0, :3], x[0]) and torch.allclose(e[0, 3:6], torch.sin(x[0])) and torch.allclose(e[0, 6:9], torch.cos(x[0]))
+    assert torch.allclose(e[0, 57:60], torch.sin(x[0] * 512))
+    assert sum(int(np.prod(s)) for _, s in orc.param_shapes()) == 595844
+    z = torch.linspace(2, 6, 64)[None]
+    w = torch.rand(1, 64)
+    s = orc.inverse_cdf(.5 * (z[..., 1:] + z[..., :-1]), w[..., 1:-1], 128)
+    assert (s[:, 1:] >= s[:, :-1]).all() and s.min() >= z[0, 0] and s.max() <= z[0, -1]
+    raw = torch.full((1, 64, 4), -3.0)
+    rgb, disp, acc, _, _ = orc.composite(raw, z, torch.tensor([[0., 0., -1.]]), None, True)
+    assert torch.equal(rgb, torch.ones(1, 3)) and acc.item() == 0 and torch.isnan(disp).all()
