@@ -100,6 +100,13 @@ size_t nerf_wgrad_partial_floats(int n_rays, int n_samples);
 int nerf_field_bwd(const float* packed, const float* act, const float* d_raw, int n_rays, int n_samples,
                    float* delta, float* partial, float* grad, int accumulate, void* stream);
 
+/* the two halves of nerf_field_bwd, separately launchable (bench.py brackets each with HIP events):
+ * dgrad: d_raw -> per-layer deltas;  wgrad: (deltas, saved activations) -> parameter gradient. */
+int nerf_field_dgrad(const float* packed, const float* act, const float* d_raw, int n_rays, int n_samples,
+                     float* delta, void* stream);
+int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
+                     float* partial, float* grad, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_dgrad_kernel(FieldBwdA
 // ------------------------------------------------------------------ weight gradients
 constexpr int WG_TILE = 128;        // output tile 128 (n) x 128 (k) per 256-thread workgroup
 constexpr int WG_STAGE = 32;        // points per LDS stage
-constexpr int WG_MAX_JOBS = 13;
+constexpr int WG_MAX_JOBS = 14;       // 8 trunk layers (+1: layer 5 has two inputs) + feature + alpha + views (2 inputs) + rgb
 
 struct WgradJob {
     const float* A; const float* B;
@@ -305,8 +305,8 @@ size_t wgrad_partial_floats(long P) {
     return (size_t)n * N_PARAMS;
 }
 
-hipError_t launch_field_bwd(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
-                            float* delta, float* partial, float* grad, int accumulate, hipStream_t stream) {
+hipError_t launch_field_dgrad(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
+                              float* delta, hipStream_t stream) {
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     static bool attr_set = false;
@@ -318,15 +318,21 @@ hipError_t launch_field_bwd(const float* packed, const float* act, const float* 
     FieldBwdArgs ba{packed, act, d_raw, delta, n_rays, S};
     const unsigned blocks = (unsigned)((P + PTS_PER_WG - 1) / PTS_PER_WG);
     hipLaunchKernelGGL(field_dgrad_kernel, dim3(blocks), dim3(FIELD_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
 
+hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
+                              float* partial, float* grad, int accumulate, hipStream_t stream) {
+    const long P = (long)n_rays * S;
+    if (P <= 0) return hipSuccess;
+    hipError_t e;
     const ActLayout al = act_layout((size_t)P, (size_t)n_rays);
     const DeltaLayout dl = delta_layout((size_t)P);
     constexpr Canon cn = canon();
     WgradArgs wa{};
     int nj = 0, tiles = 0;
     auto add = [&](const float* A, int lda, int nA, const float* B, int ldb, int nB, int rowdiv, int c_off, int ldc, int bias_off) {
+        if (nj >= WG_MAX_JOBS) { ++nj; return; }
         WgradJob& j = wa.job[nj++];
         j.A = A; j.B = B; j.lda = lda; j.nA = nA; j.ldb = ldb; j.nB = nB; j.b_rowdiv = rowdiv;
         j.c_off = c_off; j.ldc = ldc; j.bias_off = bias_off;
@@ -352,6 +358,7 @@ hipError_t launch_field_bwd(const float* packed, const float* act, const float* 
     add(delta + dl.hv, WV, WV, act + al.feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
     add(delta + dl.hv, WV, WV, act + al.dir, 32, IN_DIR, S, cn.wv + W, W + IN_DIR, -1);
     add(d_raw, 4, 3, act + al.hv, WV, WV, 1, cn.wr, WV, cn.br);
+    if (nj != WG_MAX_JOBS) return hipErrorInvalidValue;
     wa.n_jobs = nj;
     wa.total_tiles = tiles;
     wa.P = P;
@@ -363,6 +370,13 @@ hipError_t launch_field_bwd(const float* packed, const float* act, const float* 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, stream,
                        (const float*)partial, wa.n_chunks, grad, accumulate);
     return hipGetLastError();
+}
+
+hipError_t launch_field_bwd(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
+                            float* delta, float* partial, float* grad, int accumulate, hipStream_t stream) {
+    hipError_t e = launch_field_dgrad(packed, act, d_raw, n_rays, S, delta, stream);
+    if (e != hipSuccess) return e;
+    return launch_field_wgrad(act, delta, d_raw, n_rays, S, partial, grad, accumulate, stream);
 }
 
 }  // namespace nerf

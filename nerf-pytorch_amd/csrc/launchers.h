@@ -44,6 +44,10 @@ hipError_t launch_field_fwd(const float* packed, const float* rays, int ray_stri
                             int n_rays, int S, float* raw, float* act, hipStream_t stream);
 hipError_t launch_field_bwd(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
                             float* delta, float* partial, float* grad, int accumulate, hipStream_t stream);
+hipError_t launch_field_dgrad(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
+                              float* delta, hipStream_t stream);
+hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
+                              float* partial, float* grad, int accumulate, hipStream_t stream);
 size_t wgrad_partial_floats(long P);
 void pack_table_host(int* out);
 

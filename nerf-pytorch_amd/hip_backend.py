@@ -42,6 +42,8 @@ def _declare(lib):
         "nerf_delta_floats": (sz, [i, i]),
         "nerf_wgrad_partial_floats": (sz, [i, i]),
         "nerf_field_bwd": (i, [p, p, p, i, i, p, p, p, i, p]),
+        "nerf_field_dgrad": (i, [p, p, p, i, i, p, p]),
+        "nerf_field_wgrad": (i, [p, p, p, i, i, p, p, i, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
@@ -53,7 +55,7 @@ def _declare(lib):
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
            "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_sample_coarse", "nerf_act_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
-           "nerf_wgrad_partial_floats", "nerf_field_bwd"]
+           "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad"]
 
 
 def lib():
@@ -90,6 +92,48 @@ def _ptr(t, name="tensor", optional=False):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+class KernelTimer:
+    """Optional HIP-event bracketing of the heavy launches (bench.py).  Events are recorded on torch's
+    current stream, which is the stream the kernels are enqueued on.  `work` = algorithmic FLOPs."""
+
+    def __init__(self):
+        self.records = []       # (name, start_event, end_event, flops)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, fl in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+        return out
+
+
+TIMER = None        # set to a KernelTimer() to enable
+
+
+class _timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if TIMER is not None:
+            self.e1.record()
+            TIMER.records.append((self.name, self.e0, self.e1, self.flops))
+
+
+FLOP_FWD_PER_POINT = 2 * 593408
+FLOP_DGRAD_PER_POINT = 2 * 557696
+FLOP_WGRAD_PER_POINT = 2 * 593408
 
 
 N_PARAMS = 595844
@@ -155,8 +199,9 @@ def field_fwd(packed, rays, z_vals, save_act=False):
     S = z_vals.shape[1]
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
     act = torch.empty(act_floats(n, S), dtype=torch.float32, device=rays.device) if save_act else None
-    _check(lib().nerf_field_fwd(_ptr(packed, "packed"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"), n, S,
-                                _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd")
+    with _timed("field_fwd_kernel<save>" if save_act else "field_fwd_kernel", FLOP_FWD_PER_POINT * n * S):
+        _check(lib().nerf_field_fwd(_ptr(packed, "packed"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"), n, S,
+                                    _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd")
     return raw, act
 
 
@@ -217,6 +262,10 @@ def field_bwd(packed, act, d_raw, grad, accumulate):
     dev = d_raw.device
     delta = torch.empty(L.nerf_delta_floats(n, S), dtype=torch.float32, device=dev)
     partial = torch.empty(L.nerf_wgrad_partial_floats(n, S), dtype=torch.float32, device=dev)
-    _check(L.nerf_field_bwd(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
-                            _ptr(partial), _ptr(grad, "grad"), int(bool(accumulate)), _stream()), "nerf_field_bwd")
+    with _timed("field_dgrad_kernel", FLOP_DGRAD_PER_POINT * n * S):
+        _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
+                                  _stream()), "nerf_field_dgrad")
+    with _timed("wgrad_kernel(+reduce)", FLOP_WGRAD_PER_POINT * n * S):
+        _check(L.nerf_field_wgrad(_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial),
+                                  _ptr(grad, "grad"), int(bool(accumulate)), _stream()), "nerf_field_wgrad")
     return grad

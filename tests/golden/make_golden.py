@@ -28,16 +28,51 @@ def checksum(t):
     return float(t.double().abs().sum())
 
 
-def grad_digest(named_grads):
-    """per-tensor L2 norm + GRAD_SAMPLES strided entries"""
+def grad_digest(named_grads, named_grads64):
+    """per tensor: max |g|, fp32-vs-fp64 noise of the reference itself, GRAD_SAMPLES strided entries"""
     out = {}
     for k, g in named_grads.items():
         flat = g.reshape(-1)
         idx = np.linspace(0, flat.numel() - 1, num=min(GRAD_SAMPLES, flat.numel())).astype(np.int64)
-        out[k + "/norm"] = np.float64(flat.double().norm())
+        out[k + "/max"] = np.float64(flat.abs().max())
+        out[k + "/noise"] = np.float64((flat.double() - named_grads64[k].reshape(-1)).abs().max())
         out[k + "/idx"] = idx
         out[k + "/val"] = flat[idx].numpy()
     return out
+
+
+def oracle_fp64(rays, Pc, Pf, target, kw, rnd):
+    """The same computation in float64 (oracle == reference bit for bit in fp32, see pin_against_reference):
+    its distance from the fp32 reference is the reference's own rounding noise on these inputs."""
+    P64c = {k: v.double().requires_grad_(True) for k, v in Pc.items()}
+    P64f = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
+    n_f = kw["N_importance"]
+    out = orc.trace_rays(rays.double(), P64c, P64f if n_f > 0 else None, 64, n_f, perturb=kw["perturb"],
+                         lindisp=kw["lindisp"], white_bkgd=kw["white_bkgd"], raw_noise_std=kw["raw_noise_std"],
+                         retraw=True, **{k: v.double() for k, v in rnd.items()})
+    loss = orc.mse(out["rgb_map"], target.double())
+    if "rgb0" in out:
+        loss = loss + orc.mse(out["rgb0"], target.double())
+    loss.backward()
+    return out, {k: v.grad for k, v in P64c.items() if v.grad is not None}, {k: v.grad for k, v in P64f.items() if v.grad is not None}
+
+
+def draw_randoms(seed, kw, n=N_RAYS):
+    """The reference's draw order (run_nerf.py:371, :285, helpers:208, :285) replayed on the CPU generator."""
+    rnd = {}
+    if seed is None:
+        return rnd
+    torch.manual_seed(seed)
+    n_f = kw["N_importance"]
+    if kw["perturb"] > 0:
+        rnd["t_rand"] = torch.rand(n, 64)
+    if kw["raw_noise_std"] > 0:
+        rnd["noise_c"] = torch.randn(n, 64)
+    if n_f > 0 and kw["perturb"] > 0:
+        rnd["u"] = torch.rand(n, n_f)
+    if n_f > 0 and kw["raw_noise_std"] > 0:
+        rnd["noise_f"] = torch.randn(n, 64 + n_f)
+    return rnd
 
 
 def run_case(name, run_nerf, helpers, rays, nets, Pc, Pf, target, **cfg):
@@ -59,17 +94,24 @@ def run_case(name, run_nerf, helpers, rays, nets, Pc, Pf, target, **cfg):
     if "rgb0" in out:
         loss = loss + helpers.img2mse(out["rgb0"], target)
     loss.backward()
+    out64, g64c, g64f = oracle_fp64(rays, Pc, Pf, target, kw, draw_randoms(seed, kw))
     rec = {"loss": np.float64(loss.item()), "rays_checksum": checksum(rays),
            "params_checksum": checksum(torch.cat([v.reshape(-1) for v in Pc.values()])) +
            checksum(torch.cat([v.reshape(-1) for v in Pf.values()]))}
     for k, v in out.items():
         v = v.detach()
+        d = (v.double() - out64[k].detach())
+        both_nan = torch.isnan(v) & torch.isnan(out64[k].detach())
+        rec["noise/" + k] = np.float64(d.abs().masked_fill(both_nan, 0.0).max())
         rec[k] = (v[:, ::8] if k == "raw" else v).numpy()
-    rec.update({"c/" + k: v for k, v in grad_digest({k: p.grad for k, p in net_c.named_parameters() if p.grad is not None}).items()})
-    rec.update({"f/" + k: v for k, v in grad_digest({k: p.grad for k, p in net_f.named_parameters() if p.grad is not None}).items()})
+    rec.update({"c/" + k: v for k, v in grad_digest({k: p.grad for k, p in net_c.named_parameters() if p.grad is not None}, g64c).items()})
+    rec.update({"f/" + k: v for k, v in grad_digest({k: p.grad for k, p in net_f.named_parameters() if p.grad is not None}, g64f).items()})
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **rec)
-    print(f"{name}: loss {loss.item():.6f}  -> {path} ({os.path.getsize(path)} B)")
+    noise = {k[6:]: float(rec[k]) for k in rec if k.startswith("noise/")}
+    gnoise = max(float(rec[k]) / max(float(rec[k[:-5] + "max"]), 1e-30) for k in rec if k.endswith("/noise"))
+    print(f"{name}: loss {loss.item():.6f} -> {os.path.basename(path)} ({os.path.getsize(path)} B); reference fp32-vs-fp64 noise {noise}; "
+          f"worst grad noise/max {gnoise:.2e}")
 
 
 def main():

@@ -1,15 +1,17 @@
 #!/bin/bash
-# One gpurun call: environment probe, GPU parity tests, quick timing.  Output lands in gpurun_out/.
+# One gpurun call: GPU parity tests, contract bench, rocprofv3 kernel stats.  Output lands in gpurun_out/.
 mkdir -p gpurun_out
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 {
-  echo "== env"; nproc; rocm-smi --showproductname 2>/dev/null | head -8; ls /root/reference 2>&1 | head -2
-  python - <<'PY'
-import torch, os
-print("torch", torch.__version__, "hip", torch.version.hip, "gpus", torch.cuda.device_count(), torch.cuda.get_device_name(0), "cpus", os.cpu_count())
-PY
   echo "== pytest -m gpu"
-  timeout 1500 python -m pytest tests -q -m gpu -x --tb=short -p no:cacheprovider 2>&1 | tail -60
-  echo "== quick bench"
-  timeout 600 python tools/quick_bench.py 4096 2>&1 | tail -40
+  timeout 1500 python -m pytest tests -q -m gpu --tb=short -p no:cacheprovider -n 4 -rP 2>&1 | grep -vE "^\s*$|amdgpu.ids|Captured|^-+$" | cut -c1-1500 | tail -150
+  echo "== bench"
+  timeout 900 python bench.py 2>&1 | tail -5
+  echo "== smoke"
+  timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3
+  echo "== rocprofv3"
+  cd /tmp && export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -5
+  cd $R; find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats*.csv"); do head -20 $f; done
 } > gpurun_out/gpu_check.log 2>&1
-tail -100 gpurun_out/gpu_check.log
+tail -230 gpurun_out/gpu_check.log
