@@ -1,0 +1,105 @@
+"""CPU, world_size 2, gloo: the data-parallel logic around the hot path (nerf-pytorch_amd/parallel.py).
+
+The HIP kernels need a GPU, so the per-rank gradients here come from the oracle; what is tested is the
+N > 1 control flow itself: ray sharding, ONE all-reduce over the flat gradient bucket the .grad tensors
+are views of, identical Adam steps on every rank, and frame dealing for render_only."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import nerf_oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_flat_grad(P, rays, target, n_samples=16):
+    """coarse-only oracle loss gradient, flattened in state_dict order"""
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    out = orc.trace_rays(rays, Pg, None, n_samples, 0, perturb=0., white_bkgd=True)
+    orc.mse(out["rgb_map"], target).backward()
+    return torch.cat([Pg[k].grad.reshape(-1) for k, _ in orc.param_shapes()])
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import nerf_pytorch_amd as npa
+    from nerf_pytorch_amd import parallel
+    torch.set_num_threads(2)
+    r, w, dev = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    torch.manual_seed(100 + rank)                      # ranks start from DIFFERENT weights ...
+    net = npa.NeRF(**kw)
+    parallel.broadcast_parameters([net])               # ... and are made identical by one broadcast
+    P0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    n = 32
+    rays_all = orc.synthetic_rays(n, seed=4)
+    target_all = torch.rand(n, 3, generator=torch.Generator().manual_seed(0))
+    batch = torch.stack([rays_all[:, 0:3], rays_all[:, 3:6]], 0)
+    sh_rays, sh_tgt = parallel.shard_rays(batch, target_all)
+    lo, hi = parallel.shard_slice(n, rank, world)
+    assert torch.equal(sh_rays[0], rays_all[lo:hi, 0:3]) and torch.equal(sh_tgt, target_all[lo:hi])
+    # per-rank gradient of the local shard, installed the way the HIP backward installs it:
+    # every .grad is a view into one flat bucket
+    flat = _oracle_flat_grad(P0, rays_all[lo:hi], target_all[lo:hi])
+    net.last_flat_grad = flat
+    for nm, off, shape in npa.hip_backend.param_table():
+        dict(net.named_parameters())[nm].grad = flat[off:off + int(np.prod(shape))].view(shape)
+    assert parallel._flat_grad_of(net) is flat
+    parallel.allreduce_gradients([net])
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    opt.step()
+    frames = parallel.frames_of_rank(7)
+    got = parallel.gather_frames([np.full((2, 2), i) for i in frames], frames, 7)
+    q.put((rank, flat.numpy().copy(), net.flat_params().detach().numpy().copy(), {k: v.numpy().copy() for k, v in P0.items()},
+           [int(f[0, 0]) for f in got]))        # numpy: pickled by value (torch tensors travel as fds of a dying process)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce_equals_full_batch():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, g0, w0, P0, fr0), (_, g1, w1, P1, fr1) = res
+    for k in P0:
+        assert np.array_equal(P0[k], P1[k]), "broadcast_parameters left the ranks with different weights"
+    assert np.array_equal(g0, g1) and np.array_equal(w0, w1), "ranks diverged after all-reduce + Adam"
+    P0 = {k: torch.tensor(v) for k, v in P0.items()}
+    g0 = torch.tensor(g0)
+    # averaged shard gradients == gradient of the full batch (the loss is a mean over rays)
+    n = 32
+    rays_all = orc.synthetic_rays(n, seed=4)
+    target_all = torch.rand(n, 3, generator=torch.Generator().manual_seed(0))
+    full = _oracle_flat_grad(P0, rays_all, target_all)
+    assert (g0 - full).abs().max() <= 1e-6 * max(1.0, float(full.abs().max())) + 1e-7
+    assert fr0 == list(range(7)) and fr1 == list(range(7))
+
+
+def test_shard_slice_requires_even_split():
+    from nerf_pytorch_amd import parallel
+    assert parallel.shard_slice(4096 * 8, 3, 8) == (3 * 4096, 4 * 4096)
+    with pytest.raises(ValueError):
+        parallel.shard_slice(10, 0, 4)
+    assert parallel.frames_of_rank(40, 3, 8) == [3, 11, 19, 27, 35]
