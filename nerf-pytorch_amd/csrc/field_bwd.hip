@@ -77,12 +77,6 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_dgrad_kernel(FieldBwdA
                 dhv[4 * nb + r] = ((msk[D].x >> (4 * nb + r)) & 1u) ? v : 0.0f;
             }
         }
-        if (valid) {
-            float* o = a.delta + dl.hv + p * WV + 4 * q;
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb)
-                *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{dhv[4 * nb], dhv[4 * nb + 1], dhv[4 * nb + 2], dhv[4 * nb + 3]};
-        }
     }
 
     f32x4 acc[16];
@@ -92,15 +86,28 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_dgrad_kernel(FieldBwdA
     // ---- views_linears.0^T (feature columns only): 128 -> 256, no activation on feature
 #pragma unroll
     for (int nb = 0; nb < 16; ++nb) acc[nb] = zero4;
-    mma_chunk<16, 16, 0, 32>(acc, dhv, ws.acquire(), lane);
+    // every delta is stored one chunk late: right after the next acquire() issued its DMA (see field_fwd.hip)
+    {
+        const float* first = ws.acquire();
+        if (valid) {
+            float* o = a.delta + dl.hv + p * WV + 4 * q;
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb)
+                *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{dhv[4 * nb], dhv[4 * nb + 1], dhv[4 * nb + 2], dhv[4 * nb + 3]};
+        }
+        mma_chunk<16, 16, 0, 32>(acc, dhv, first, lane);
+    }
     mma_chunk<16, 16, 16, 32>(acc, dhv, ws.acquire(), lane);
 #pragma unroll
     for (int i = 0; i < 64; ++i) d[i] = acc[i >> 2][i & 3];
-    if (valid) {
-        float* o = a.delta + dl.feat + p * W + 4 * q;
+    auto store_d = [&](size_t off) {
+        if (valid) {
+            float* o = a.delta + off + p * W + 4 * q;
 #pragma unroll
-        for (int nb = 0; nb < 16; ++nb) *reinterpret_cast<f32x4*>(o + 16 * nb) = acc[nb];
-    }
+            for (int nb = 0; nb < 16; ++nb)
+                *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{d[4 * nb], d[4 * nb + 1], d[4 * nb + 2], d[4 * nb + 3]};
+        }
+    };
 
     // ---- feature_linear^T + alpha_linear^T, ReLU mask of layer 7
     {
@@ -111,24 +118,26 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_dgrad_kernel(FieldBwdA
             acc[nb] = f32x4{g[3] * w[0], g[3] * w[1], g[3] * w[2], g[3] * w[3]};
         }
     }
-    mma_chunk<16, 16, 0, 64>(acc, d, ws.acquire(), lane);
+    {
+        const float* first = ws.acquire();
+        store_d(dl.feat);
+        mma_chunk<16, 16, 0, 64>(acc, d, first, lane);
+    }
     mma_chunk<16, 16, 16, 64>(acc, d, ws.acquire(), lane);
     mma_chunk<16, 16, 32, 64>(acc, d, ws.acquire(), lane);
     mma_chunk<16, 16, 48, 64>(acc, d, ws.acquire(), lane);
     apply_mask<64>(d, acc, msk[D - 1]);
-    if (valid) {
-        float* o = a.delta + dl.h[D - 1] + p * W + 4 * q;
-#pragma unroll
-        for (int nb = 0; nb < 16; ++nb)
-            *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{d[4 * nb], d[4 * nb + 1], d[4 * nb + 2], d[4 * nb + 3]};
-    }
 
     // ---- trunk: delta_{l-1} = (W_l^T delta_l) * relu'(h_{l-1}),  l = 7 .. 1
 #pragma unroll 1
     for (int l = D - 1; l >= 1; --l) {
 #pragma unroll
         for (int nb = 0; nb < 16; ++nb) acc[nb] = zero4;
-        mma_chunk<16, 16, 0, 64>(acc, d, ws.acquire(), lane);
+        {
+            const float* first = ws.acquire();
+            store_d((size_t)l * P * W);                                  // == dl.h[l]: delta of layer l (input of this step)
+            mma_chunk<16, 16, 0, 64>(acc, d, first, lane);
+        }
         mma_chunk<16, 16, 16, 64>(acc, d, ws.acquire(), lane);
         mma_chunk<16, 16, 32, 64>(acc, d, ws.acquire(), lane);
         mma_chunk<16, 16, 48, 64>(acc, d, ws.acquire(), lane);
@@ -136,13 +145,8 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_dgrad_kernel(FieldBwdA
 #pragma unroll
         for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];      // select without dynamic register indexing
         apply_mask<64>(d, acc, m);
-        if (valid) {
-            float* o = a.delta + (size_t)(l - 1) * P * W + p * W + 4 * q;       // == dl.h[l-1]
-#pragma unroll
-            for (int nb = 0; nb < 16; ++nb)
-                *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{d[4 * nb], d[4 * nb + 1], d[4 * nb + 2], d[4 * nb + 3]};
-        }
     }
+    store_d(0);                                                          // dl.h[0]
 }
 
 // ------------------------------------------------------------------ weight gradients
@@ -278,6 +282,99 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Full-width jobs (256 x 256 outputs, 16-byte aligned rows): one workgroup owns the WHOLE output of a job for its
+// point chunk, so delta and input rows are fetched from HBM exactly once (the 128x128 kernel above reads each twice).
+// 8 waves = 2 (n) x 4 (k), wave tile 128 x 64 = 32 accumulator blocks, 3 ds_read_b128 per 32 MFMAs.
+constexpr int WG256_LDS_FLOATS = 2 * 2 * WG_STAGE * 256;        // sA[2][32][256] | sB[2][32][256] = 128 KiB
+
+__global__ __launch_bounds__(512) void wgrad256_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm256[];
+    float (*sA)[WG_STAGE][256] = reinterpret_cast<float (*)[WG_STAGE][256]>(sm256);
+    float (*sB)[WG_STAGE][256] = reinterpret_cast<float (*)[WG_STAGE][256]>(sm256 + 2 * WG_STAGE * 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave >> 2, wave_k = wave & 3;
+    const int ji = blockIdx.x % a.n_jobs;
+    const int chunk = blockIdx.x / a.n_jobs;
+    const WgradJob& jb = a.job[ji];
+    const long p_begin = (long)chunk * a.chunk_pts;
+    const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
+    const int n_stages = (int)((p_end - p_begin + WG_STAGE - 1) / WG_STAGE);
+    const int srow = tid >> 6, scol = (tid & 63) * 4;
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int st) {
+        const long r0 = p_begin + (long)st * WG_STAGE + srow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long r = r0 + 8 * i;
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[i] = r < p_end ? *reinterpret_cast<const f32x4*>(jb.A + r * jb.lda + scol) : z;
+            rb[i] = r < p_end ? *reinterpret_cast<const f32x4*>(jb.B + r * jb.ldb + scol) : z;
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&sA[buf][srow + 8 * i][scol]) = ra[i];
+            *reinterpret_cast<f32x4*>(&sB[buf][srow + 8 * i][scol]) = rb[i];
+        }
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum0 = f32x4{0.f, 0.f, 0.f, 0.f}, bsum1 = bsum0;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int c = lane & 15, pp = lane >> 4;
+    for (int st = 0; st < n_stages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < n_stages) gload(st + 1);
+#pragma unroll
+        for (int ps = 0; ps < WG_STAGE / 4; ++ps) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&sA[buf][4 * ps + pp][wave_n * 128 + 4 * c]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&sA[buf][4 * ps + pp][wave_n * 128 + 64 + 4 * c]);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&sB[buf][4 * ps + pp][wave_k * 64 + 4 * c]);
+            bsum0 += a0;
+            bsum1 += a1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], bv[j], acc[4 + i][j], 0, 0, 0);
+                }
+        }
+        if (st + 1 < n_stages) swrite(buf ^ 1);
+        __syncthreads();
+    }
+    // acc[4h+i][j][r] = dW[wave_n*128 + 64h + 4*(4*pp + r) + i][wave_k*64 + 4*c + j]
+    float* out = a.partial + (size_t)chunk * N_PARAMS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = wave_n * 128 + 64 * h + 4 * (4 * pp + r) + i;
+                float* row = out + jb.c_off + (size_t)n * jb.ldc + wave_k * 64 + 4 * c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) row[j] = acc[4 * h + i][j][r];
+            }
+    if (jb.bias_off >= 0 && wave_k == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = h == 0 ? bsum0[i] : bsum1[i];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (pp == 0) out[jb.bias_off + wave_n * 128 + 64 * h + 4 * c + i] = v;
+            }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N_PARAMS) return;
@@ -359,16 +456,49 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     add(delta + dl.hv, WV, WV, act + al.dir, 32, IN_DIR, S, cn.wv + W, W + IN_DIR, -1);
     add(d_raw, 4, 3, act + al.hv, WV, WV, 1, cn.wr, WV, cn.br);
     if (nj != WG_MAX_JOBS) return hipErrorInvalidValue;
-    wa.n_jobs = nj;
-    wa.total_tiles = tiles;
-    wa.P = P;
-    wa.n_chunks = wgrad_chunks(P, &wa.chunk_pts);
-    wa.partial = partial;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(tiles * wa.n_chunks)), dim3(256), 0, stream, wa);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
+    WgradArgs big{}, small{};
+    int small_tiles = 0;
+    for (int j = 0; j < nj; ++j) {
+        const WgradJob& src = wa.job[j];
+#ifdef NERF_NO_WGRAD256
+        if (false) {
+#else
+        if (src.nA == 256 && src.nB == 256 && src.vecA && src.vecB && src.b_rowdiv == 1) {
+#endif
+            big.job[big.n_jobs++] = src;
+        } else {
+            WgradJob& dst = small.job[small.n_jobs++];
+            dst = src;
+            dst.tile_base = small_tiles;
+            small_tiles += ((src.nA + WG_TILE - 1) / WG_TILE) * src.tiles_k;
+        }
+    }
+    int chunk_pts = 0;
+    const int n_chunks = wgrad_chunks(P, &chunk_pts);
+    big.P = small.P = P;
+    big.chunk_pts = small.chunk_pts = chunk_pts;
+    big.n_chunks = small.n_chunks = n_chunks;
+    big.partial = small.partial = partial;
+    small.total_tiles = small_tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute((const void*)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG256_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (big.n_jobs > 0) {
+        hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG256_LDS_FLOATS * 4, stream, big);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (small.n_jobs > 0) {
+        hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(small_tiles * n_chunks)), dim3(256), 0, stream, small);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, stream,
-                       (const float*)partial, wa.n_chunks, grad, accumulate);
+                       (const float*)partial, n_chunks, grad, accumulate);
     return hipGetLastError();
 }
 

@@ -76,20 +76,26 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
     for (int nb = 0; nb < 16; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[4 * nb + r] = fmaxf(acc[nb][r], 0.0f);
-    if (SAVE && valid) {
-        float* ho = a.act + al.h[0] + (size_t)p * W + 4 * q;
+    // Saved activations are stored one chunk late: right AFTER the next acquire() has issued its DMA, so the
+    // stores have a whole chunk of MFMA work to drain before the following vmcnt(0) + barrier.
+    auto save_trunk = [&](int layer) {
+        if (SAVE && valid) {
+            float* ho = a.act + (size_t)layer * (size_t)P * W + (size_t)p * W + 4 * q;      // == al.h[layer]
 #pragma unroll
-        for (int nb = 0; nb < 16; ++nb)
-            *reinterpret_cast<f32x4*>(ho + 16 * nb) = f32x4{h[4 * nb], h[4 * nb + 1], h[4 * nb + 2], h[4 * nb + 3]};
-        save_mask<64>(a.act + al.mask, 0, (size_t)P, (size_t)p, q, h);
-    }
+            for (int nb = 0; nb < 16; ++nb)
+                *reinterpret_cast<f32x4*>(ho + 16 * nb) = f32x4{h[4 * nb], h[4 * nb + 1], h[4 * nb + 2], h[4 * nb + 3]};
+            save_mask<64>(a.act + al.mask, layer, (size_t)P, (size_t)p, q, h);
+        }
+    };
 
     // ---- layers 1..7 (layer 5 also contracts the xyz encoding: skip connection)
 #pragma unroll 1
     for (int l = 1; l < D; ++l) {
         load_bias<16>(acc, bias + l * W, q);
-        if (l == SKIP + 1) mma_chunk<16, 16, 0, 16>(acc, e, ws.acquire(), lane);
-        mma_chunk<16, 16, 0, 64>(acc, h, ws.acquire(), lane);
+        const float* first = ws.acquire();
+        save_trunk(l - 1);
+        if (l == SKIP + 1) { mma_chunk<16, 16, 0, 16>(acc, e, first, lane); first = ws.acquire(); }
+        mma_chunk<16, 16, 0, 64>(acc, h, first, lane);
         mma_chunk<16, 16, 16, 64>(acc, h, ws.acquire(), lane);
         mma_chunk<16, 16, 32, 64>(acc, h, ws.acquire(), lane);
         mma_chunk<16, 16, 48, 64>(acc, h, ws.acquire(), lane);
@@ -97,13 +103,6 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
         for (int nb = 0; nb < 16; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[4 * nb + r] = fmaxf(acc[nb][r], 0.0f);
-        if (SAVE && valid) {
-            float* ho = a.act + (size_t)l * (size_t)P * W + (size_t)p * W + 4 * q;   // == al.h[l]
-#pragma unroll
-            for (int nb = 0; nb < 16; ++nb)
-                *reinterpret_cast<f32x4*>(ho + 16 * nb) = f32x4{h[4 * nb], h[4 * nb + 1], h[4 * nb + 2], h[4 * nb + 3]};
-            save_mask<64>(a.act + al.mask, l, (size_t)P, (size_t)p, q, h);
-        }
     }
 
     // ---- density head: alpha_linear 256 -> 1 (VALU dot + quarter reduction)
@@ -121,7 +120,11 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
 
     // ---- feature_linear 256 -> 256 (no activation)
     load_bias<16>(acc, small_ptr(lds, SM_BFEAT), q);
-    mma_chunk<16, 16, 0, 64>(acc, h, ws.acquire(), lane);
+    {
+        const float* first = ws.acquire();
+        save_trunk(D - 1);
+        mma_chunk<16, 16, 0, 64>(acc, h, first, lane);
+    }
     mma_chunk<16, 16, 16, 64>(acc, h, ws.acquire(), lane);
     mma_chunk<16, 16, 32, 64>(acc, h, ws.acquire(), lane);
     mma_chunk<16, 16, 48, 64>(acc, h, ws.acquire(), lane);
@@ -129,11 +132,6 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
     for (int nb = 0; nb < 16; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[4 * nb + r] = acc[nb][r];
-    if (SAVE && valid) {
-        float* ho = a.act + al.feat + (size_t)p * W + 4 * q;
-#pragma unroll
-        for (int nb = 0; nb < 16; ++nb) *reinterpret_cast<f32x4*>(ho + 16 * nb) = acc[nb];
-    }
 
     // ---- view branch: [feature, enc(dir)] 283 -> 128, ReLU
     float v[7];
@@ -148,7 +146,16 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
     }
     f32x4 av[8];
     load_bias<8>(av, small_ptr(lds, SM_BVIEWS), q);
-    mma_chunk<8, 16, 0, 64>(av, h, ws.acquire(), lane);
+    {
+        const float* first = ws.acquire();
+        if (SAVE && valid) {
+            float* ho = a.act + al.feat + (size_t)p * W + 4 * q;
+#pragma unroll
+            for (int nb = 0; nb < 16; ++nb)
+                *reinterpret_cast<f32x4*>(ho + 16 * nb) = f32x4{h[4 * nb], h[4 * nb + 1], h[4 * nb + 2], h[4 * nb + 3]};
+        }
+        mma_chunk<8, 16, 0, 64>(av, h, first, lane);
+    }
     mma_chunk<8, 16, 16, 64>(av, h, ws.acquire(), lane);
     mma_chunk<8, 16, 32, 64>(av, h, ws.acquire(), lane);
     mma_chunk<8, 16, 48, 64>(av, h, ws.acquire(), lane);

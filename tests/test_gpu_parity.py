@@ -187,7 +187,7 @@ def test_sample_fine(npa, dev, det, Sc, Nf):
 def test_field_forward(npa, dev, nets, n_rays, S):
     nc, nf, Pc, Pf = nets
     rays = orc.synthetic_rays(n_rays, seed=S)
-    z = torch.sort(torch.rand(n_rays, S) * 4.0 + 2.0, -1)[0]
+    z = torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0]
     raw, act = npa.hip_backend.field_fwd(nf.packed_params(), rays.to(dev), z.to(dev), save_act=False)
     pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]
     P64 = {k: v.double() for k, v in Pf.items()}
@@ -206,7 +206,7 @@ def test_field_forward_hidden_activations(npa, dev, nets):
     n_rays, S = 19, 64
     P = n_rays * S
     rays = orc.synthetic_rays(n_rays, seed=3)
-    z = torch.sort(torch.rand(n_rays, S) * 4.0 + 2.0, -1)[0]
+    z = torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(3)) * 4.0 + 2.0, -1)[0]
     raw, act = npa.hip_backend.field_fwd(nc.packed_params(), rays.to(dev), z.to(dev), save_act=True)
     act = act.cpu()
     pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)
@@ -230,24 +230,46 @@ def test_field_forward_hidden_activations(npa, dev, nets):
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192), (70, 20)])
 def test_field_backward(npa, dev, nets, n_rays, S):
     nc, nf, Pc, Pf = nets
+    g = torch.Generator().manual_seed(7 * n_rays + S)
     rays = orc.synthetic_rays(n_rays, seed=S + 1)
-    z = torch.sort(torch.rand(n_rays, S) * 4.0 + 2.0, -1)[0]
-    d_raw = torch.randn(n_rays, S, 4)
+    z = torch.sort(torch.rand(n_rays, S, generator=g) * 4.0 + 2.0, -1)[0]
+    d_raw = torch.randn(n_rays, S, 4, generator=g)
+    P64 = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]
+    # ReLU kinks: a unit whose pre-activation is within fp32 rounding of 0 legitimately lands on either side
+    # (about 1 unit per million); such points get no upstream gradient so the comparison is well defined.
+    with torch.no_grad():
+        feats = torch.cat([orc.posenc(pts.reshape(-1, 3).double(), 10),
+                           orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3).double(), 4)], -1)
+        _, hidden, feat, hv = orc.field_mlp({k: v.detach() for k, v in P64.items()}, feats, return_hidden=True)
+        lin = torch.nn.functional.linear
+        pre_min = torch.full((feats.shape[0],), float("inf"), dtype=torch.float64)
+        h_in = feats[:, :63]
+        for i in range(8):
+            pre = lin(h_in, P64[f"pts_linears.{i}.weight"].detach(), P64[f"pts_linears.{i}.bias"].detach())
+            pre_min = torch.minimum(pre_min, pre.abs().min(-1)[0])
+            h_in = torch.relu(pre)
+            if i == 4:
+                h_in = torch.cat([feats[:, :63], h_in], -1)
+        pre = lin(torch.cat([feat, feats[:, 63:]], -1), P64["views_linears.0.weight"].detach(), P64["views_linears.0.bias"].detach())
+        pre_min = torch.minimum(pre_min, pre.abs().min(-1)[0])
+        risky = (pre_min < 2e-5).reshape(n_rays, S)          # fp32 pre-activation error is ~1e-6
+    d_raw[risky] = 0.0
     raw, act = npa.hip_backend.field_fwd(nf.packed_params(), rays.to(dev), z.to(dev), save_act=True)
     grad = torch.full((595844,), float("nan"), device=dev)
     npa.hip_backend.field_bwd(nf.packed_params(), act, d_raw.to(dev), grad, accumulate=False)
-    P64 = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
-    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]
     ref = orc.query_field(P64, pts.double(), rays[:, 8:11].double())
     (ref * d_raw.double()).sum().backward()
     grad = grad.cpu()
     assert not torch.isnan(grad).any(), "wgrad left parts of the gradient vector unwritten"
     worst = {}
     for nm, off, shape in npa.hip_backend.param_table():
-        g = grad[off:off + int(np.prod(shape))].view(shape)
+        gg = grad[off:off + int(np.prod(shape))].view(shape)
         r = P64[nm].grad
-        worst[nm] = maxdiff(g, r) / max(float(r.abs().max()), 1e-30)
-    print("field_bwd max|err|/max|grad| per tensor:", {k: f"{v:.1e}" for k, v in worst.items()})
+        worst[nm] = maxdiff(gg, r) / max(float(r.abs().max()), 1e-30)
+    print("kink-adjacent points excluded:", int(risky.sum()), "of", risky.numel(),
+          "| field_bwd max|err|/max|grad| per tensor:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert risky.float().mean() < 0.15
     assert max(worst.values()) <= 1e-4, worst
     # accumulate=True adds
     npa.hip_backend.field_bwd(nf.packed_params(), act, d_raw.to(dev), grad_dev := grad.to(dev), accumulate=True)
