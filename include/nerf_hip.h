@@ -107,6 +107,20 @@ int nerf_field_dgrad(const float* packed, const float* act, const float* d_raw, 
 int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                      float* partial, float* grad, int accumulate, void* stream);
 
+/* ---- split-bf16 ("bf16x3") datapath of the same functions: every product W*x is evaluated as
+ * W_hi*x_hi + W_hi*x_lo + W_lo*x_hi on bf16 MFMA with fp32 accumulation (~1e-5 relative error per product,
+ * judged by the PSNR-delta criterion instead of the fp32 tolerances).  Parameters are repacked into (hi, lo)
+ * bf16 fragment streams of nerf_packed3_floats() 32-bit words; the activation save buffer has the same size
+ * and row layout as the fp32 path (only the ReLU bitmask words are lane-order specific to this datapath,
+ * so forward and backward of one evaluation must use the same datapath). */
+int nerf_packed3_floats(void);
+int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream);
+int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                          int n_samples, float* raw, float* act, void* stream);
+/* test hook (host only): out_host[e] for every 16-bit element e of the weight streams (2 * stream words):
+ * 2 * canonical_index + is_low_part, or -1 for zero padding. */
+int nerf_debug_pack3_table(int* out_host);
+
 #ifdef __cplusplus
 }
 #endif

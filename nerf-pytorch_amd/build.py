@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnerf_hip.so")
 STAMP_PATH = os.path.join(PKG_DIR, "libnerf_hip.stamp")
-SOURCES = ["api.hip", "pack.hip", "ray_ops.hip", "field_fwd.hip", "field_bwd.hip"]
+SOURCES = ["api.hip", "pack.hip", "ray_ops.hip", "field_fwd.hip", "field_bwd.hip", "field_fwd_bf16.hip"]
 HEADERS = ["nerf_common.h", "field_device.h", "launchers.h", os.path.join("..", "..", "include", "nerf_hip.h")]
 # -ffp-contract=off: the per-ray arithmetic is written in the reference's operation
 # order (separate multiply / add) so z_vals, dists and sample points round identically.

@@ -42,9 +42,10 @@ __device__ inline void dma_1k(const float* gsrc_lane, unsigned lds_dst_uniform) 
         : "v"(gsrc_lane), "s"(lds_dst_uniform)
         : "memory");
 }
+template <int NWAVES>
 __device__ inline void dma_chunk(const float* gsrc, float* lbuf, int nfloats, int wave, int lane) {
     const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(lbuf));
-    for (int i = wave * 256; i < nfloats; i += FIELD_WAVES * 256)
+    for (int i = wave * 256; i < nfloats; i += NWAVES * 256)
         dma_1k(gsrc + i + lane * 4, base + (unsigned)i * 4u);
 }
 
@@ -52,40 +53,53 @@ __device__ inline void dma_chunk(const float* gsrc, float* lbuf, int nfloats, in
 // two weight buffers, so the main loop issues no compiler-tracked global loads.
 constexpr int SMALL_FLOATS = PACKED_FLOATS - SM_BIAS;
 constexpr int FIELD_LDS_FLOATS = 2 * CHUNK_FLOATS + SMALL_FLOATS;
-__device__ inline void stage_small(const float* packed, float* lds) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(packed + SM_BIAS);
+__device__ inline void stage_small_from(const float* small_src, float* lds, int nthreads) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(small_src);
     f32x4* dst = reinterpret_cast<f32x4*>(lds + 2 * CHUNK_FLOATS);
-    for (int i = threadIdx.x; i < SMALL_FLOATS / 4; i += FIELD_WAVES * 64) dst[i] = src[i];
+    for (int i = threadIdx.x; i < SMALL_FLOATS / 4; i += nthreads) dst[i] = src[i];
 }
+__device__ inline void stage_small(const float* packed, float* lds) { stage_small_from(packed + SM_BIAS, lds, FIELD_WAVES * 64); }
 // LDS address of packed[SM_x] after stage_small()
 __device__ inline const float* small_ptr(const float* lds, int sm_offset) {
     return lds + 2 * CHUNK_FLOATS + (sm_offset - SM_BIAS);
 }
 
+// chunk sizes (32-bit words) of the four weight streams, in consumption order
+//   MODE 0: fp32 forward   1: fp32 backward   2: bf16x3 forward   3: bf16x3 backward
+template <int MODE>
+__device__ constexpr int stream_chunk_words(int c) {
+    if (MODE == 0) return fwd_chunk_floats(c);
+    if (MODE == 1) return bwd_chunk_floats(c);
+    if (MODE == 2) return c < 36 ? CHUNK_FLOATS : (c == 36 ? KS3_DIR * KSTEP3_W4 : 0);   // 34 full + views 2 x 8 k-steps + 2 k-steps
+    return c < 34 ? CHUNK_FLOATS : 0;                                                  // views^T 2 | feat^T 4 | L7..L1 28
+}
+
 // Double-buffered weight stream.  acquire() = "chunk c has landed for every wave,
 // nobody still reads the other buffer" -> start DMA of chunk c+1 -> hand out chunk c.
-template <bool FWD>
-struct WeightStream {
+template <int MODE, int NWAVES>
+struct WeightStreamT {
     const float* next_src;
     float* lds;
     int wave, lane, c;
     __device__ inline void start(const float* src, float* lds_, int wave_, int lane_) {
         lds = lds_; wave = wave_; lane = lane_; c = 0;
-        const int nf = FWD ? fwd_chunk_floats(0) : bwd_chunk_floats(0);
-        dma_chunk(src, lds, nf, wave, lane);
+        const int nf = stream_chunk_words<MODE>(0);
+        dma_chunk<NWAVES>(src, lds, nf, wave, lane);
         next_src = src + nf;
     }
     __device__ inline const float* acquire() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float* cur = lds + (c & 1) * CHUNK_FLOATS;
-        const int nf = FWD ? fwd_chunk_floats(c + 1) : bwd_chunk_floats(c + 1);
-        if (nf > 0) dma_chunk(next_src, lds + ((c + 1) & 1) * CHUNK_FLOATS, nf, wave, lane);
+        const int nf = stream_chunk_words<MODE>(c + 1);
+        if (nf > 0) dma_chunk<NWAVES>(next_src, lds + ((c + 1) & 1) * CHUNK_FLOATS, nf, wave, lane);
         next_src += nf;
         ++c;
         return cur;
     }
 };
+template <bool FWD>
+using WeightStream = WeightStreamT<FWD ? 0 : 1, FIELD_WAVES>;
 
 // acc[nb] (16x16 block nb of the transposed output) += A(lds) * b over KS k-steps.
 // b[BOFF + s] is this lane's B operand of k-step s (static indices -> registers).

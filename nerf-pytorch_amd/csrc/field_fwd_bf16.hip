@@ -1,0 +1,311 @@
+// Split-bf16 ("bf16x3") variant of the fused field evaluation (same boundary, same outputs as field_fwd.hip):
+//   W*x ~= W_hi*x_hi + W_hi*x_lo + W_lo*x_hi   on v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+// ~1e-5 relative error per product (fp32: 6e-8, plain bf16: 4e-3) at 16/3 = 5.3x the fp32-MFMA rate.
+// One wave = 32 points, activations stay in VGPRs as fp32 and are split into (hi, lo) bf16 fragments
+// just in time for each k-step (the conversion VALU work hides under the 24 MFMAs of the previous k-step);
+// weights stream L2 -> LDS as pre-split (hi, lo) fragments.  256-thread workgroups, 1 wave / SIMD (~350 VGPRs).
+#include "field_device.h"
+#include "launchers.h"
+
+namespace nerf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct FieldFwd3Args {
+    const float* packed3;   // PACKED3_WORDS
+    const float* rays;
+    const float* z_vals;
+    float* raw;
+    float* act;             // nullable
+    int ray_stride, n_rays, S;
+};
+
+__device__ inline unsigned pack_bf16x2(float a, float b) {       // RNE, low half = a
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+// 8 fp32 values -> bf16 (hi, lo) B fragments
+__device__ inline void split8(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        hi[i] = h;
+        lo[i] = pack_bf16x2(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+}
+__device__ inline f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// one k-step for NB output blocks: acc[nb] += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi
+// kbase = LDS address of this k-step's fragments (u32x4 units), lane-linear: ((nb*2 + hl)*64 + lane)
+template <int NB>
+__device__ inline void mma3_kstep(f32x16 (&acc)[NB], const u32x4 bhi, const u32x4 blo, const u32x4* kbase) {
+#pragma unroll
+    for (int g = 0; g < NB; g += 4) {
+        u32x4 ahi[4], alo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ahi[i] = kbase[((g + i) * 2) * 64]; alo[i] = kbase[((g + i) * 2 + 1) * 64]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g + i] = mfma_bf16(ahi[i], bhi, acc[g + i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g + i] = mfma_bf16(ahi[i], blo, acc[g + i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g + i] = mfma_bf16(alo[i], bhi, acc[g + i]);
+    }
+}
+
+// KS k-steps whose B operands are v[VOFF + 8*s .. +7] (fp32, already activated)
+template <int NB, int KS, int VOFF, int NV>
+__device__ inline void mma3_chunk(f32x16 (&acc)[NB], const float (&v)[NV], const float* lbuf, int lane) {
+    const u32x4* a = reinterpret_cast<const u32x4*>(lbuf) + lane;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        u32x4 bhi, blo;
+        split8(&v[VOFF + 8 * s], bhi, blo);
+        mma3_kstep<NB>(acc, bhi, blo, a + s * (NB * 2 * 64));
+    }
+}
+
+template <int NB>
+__device__ inline void load_bias3(f32x16 (&acc)[NB], const float* bias, int half) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * nb + 8 * g + 4 * half);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nb][4 * g + r] = b[r];
+        }
+}
+
+// lane value i (0..16*NB-1) = feature 32*(i>>4) + d32row(i&15, half): 4 consecutive features per float4
+template <int NV>
+__device__ inline void store_rows3(float* row, const float (&v)[NV], int half) {
+#pragma unroll
+    for (int ob = 0; ob < NV / 16; ++ob)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(row + 32 * ob + 8 * g + 4 * half) =
+                f32x4{v[16 * ob + 4 * g], v[16 * ob + 4 * g + 1], v[16 * ob + 4 * g + 2], v[16 * ob + 4 * g + 3]};
+}
+// ReLU sign bits of the lane's NV values -> act.mask[layer][p][half] (4 words; NV <= 128)
+template <int NV>
+__device__ inline void save_mask3(float* mask_base, int layer, size_t P, size_t p, int half, const float (&v)[NV]) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) w[i >> 5] |= (v[i] > 0.0f ? 1u : 0u) << (i & 31);
+    u32x4* m = reinterpret_cast<u32x4*>(mask_base) + ((size_t)layer * P + p) * 2 + half;
+    *m = u32x4{w[0], w[1], w[2], w[3]};
+}
+
+__device__ inline float half_sum(float v) { return v + __shfl_xor(v, 32); }
+
+template <bool SAVE>
+__global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const long P = (long)a.n_rays * a.S;
+    const long p_raw = ((long)blockIdx.x * FIELD3_WAVES + wave) * PTS_PER_WAVE3 + (lane & 31);
+    const bool valid = p_raw < P;
+    const long p = valid ? p_raw : P - 1;
+    const int ray = (int)(p / a.S);
+
+    WeightStreamT<2, FIELD3_WAVES> ws;
+    ws.start(a.packed3, lds, wave, lane);
+    stage_small_from(a.packed3 + P3_SMALL, lds, FIELD3_WAVES * 64);
+
+    const float* rp = a.rays + (long)ray * a.ray_stride;
+    const float z = a.z_vals[p];
+    const float x0 = rp[0] + rp[3] * z;
+    const float x1 = rp[1] + rp[4] * z;
+    const float x2 = rp[2] + rp[5] * z;
+    const float vd0 = rp[8], vd1 = rp[9], vd2 = rp[10];
+
+    // ---- xyz encoding: 32 values per lane (slot map enc3slot)
+    float e[32];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int i = half * 16 + m;                 // (freq, axis) pair
+        if (m < 14 || half == 0) {
+            const int dim = i % 3, fr = i / 3;
+            const float xv = dim == 0 ? x0 : (dim == 1 ? x1 : x2);
+            float sn, cs;
+            sincosf(xv * pow2f(fr), &sn, &cs);
+            e[2 * m] = sn;
+            e[2 * m + 1] = cs;
+        } else if (m == 14) { e[28] = x0; e[29] = x1; }
+        else { e[30] = x2; e[31] = 0.0f; }
+    }
+    ActLayout al{};
+    if (SAVE) {
+        al = act_layout((size_t)P, (size_t)a.n_rays);
+        if (valid) {
+            float* eo = a.act + al.enc + (size_t)p * 64;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) {
+                const int col = enc3slot(v, half);
+                if (col >= 0) eo[col] = e[v];
+            }
+        }
+    }
+
+    const float* bias = small_ptr(lds, SM_BIAS);
+    f32x16 acc[8];
+    float h[128];
+    auto take = [&](bool relu) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[16 * nb + r] = relu ? fmaxf(acc[nb][r], 0.0f) : acc[nb][r];
+    };
+    auto save_trunk = [&](int layer) {
+        if (SAVE && valid) {
+            store_rows3<128>(a.act + (size_t)layer * (size_t)P * W + (size_t)p * W, h, half);
+            save_mask3<128>(a.act + al.mask, layer, (size_t)P, (size_t)p, half, h);
+        }
+    };
+
+    // ---- layer 0
+    load_bias3<8>(acc, bias, half);
+    mma3_chunk<8, 4, 0, 32>(acc, e, ws.acquire(), lane);
+    take(true);
+
+    // ---- layers 1..7
+#pragma unroll 1
+    for (int l = 1; l < D; ++l) {
+        load_bias3<8>(acc, bias + l * W, half);
+        const float* cur = ws.acquire();
+        save_trunk(l - 1);
+        if (l == SKIP + 1) { mma3_chunk<8, 4, 0, 32>(acc, e, cur, lane); cur = ws.acquire(); }
+        mma3_chunk<8, 4, 0, 128>(acc, h, cur, lane);
+        mma3_chunk<8, 4, 32, 128>(acc, h, ws.acquire(), lane);
+        mma3_chunk<8, 4, 64, 128>(acc, h, ws.acquire(), lane);
+        mma3_chunk<8, 4, 96, 128>(acc, h, ws.acquire(), lane);
+        take(true);
+    }
+
+    // ---- density head (VALU dot + half reduction)
+    float sigma = 0.0f;
+    {
+        const float* wa = small_ptr(lds, SM_WALPHA);
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wa + 32 * ob + 8 * g + 4 * half);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sigma = fmaf(h[16 * ob + 4 * g + r], w[r], sigma);
+            }
+        sigma = half_sum(sigma) + small_ptr(lds, SM_BALPHA)[0];
+    }
+
+    // ---- feature_linear (no activation)
+    load_bias3<8>(acc, small_ptr(lds, SM_BFEAT), half);
+    {
+        const float* cur = ws.acquire();
+        save_trunk(D - 1);
+        mma3_chunk<8, 4, 0, 128>(acc, h, cur, lane);
+    }
+    mma3_chunk<8, 4, 32, 128>(acc, h, ws.acquire(), lane);
+    mma3_chunk<8, 4, 64, 128>(acc, h, ws.acquire(), lane);
+    mma3_chunk<8, 4, 96, 128>(acc, h, ws.acquire(), lane);
+    take(false);
+
+    // ---- view branch: [feature, enc(dir)] -> 128, ReLU
+    float dv[16];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int i = half * 8 + m;
+        if (half == 0 || m < 4) {
+            const int dim = i % 3, fr = i / 3;
+            const float xv = dim == 0 ? vd0 : (dim == 1 ? vd1 : vd2);
+            float sn, cs;
+            sincosf(xv * pow2f(fr), &sn, &cs);
+            dv[2 * m] = sn;
+            dv[2 * m + 1] = cs;
+        } else if (m == 4) { dv[8] = vd0; dv[9] = vd1; }
+        else if (m == 5) { dv[10] = vd2; dv[11] = 0.0f; }
+        else { dv[2 * m] = 0.0f; dv[2 * m + 1] = 0.0f; }
+    }
+    if (SAVE && valid && (p - (long)ray * a.S) == 0) {
+        float* dout = a.act + al.dir + (size_t)ray * 32;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int col = dir3slot(v, half);
+            if (col >= 0) dout[col] = dv[v];
+        }
+    }
+    f32x16 av[4];
+    load_bias3<4>(av, small_ptr(lds, SM_BVIEWS), half);
+    {
+        const float* cur = ws.acquire();
+        if (SAVE && valid) store_rows3<128>(a.act + al.feat + (size_t)p * W, h, half);
+        mma3_chunk<4, 8, 0, 128>(av, h, cur, lane);
+    }
+    mma3_chunk<4, 8, 64, 128>(av, h, ws.acquire(), lane);
+    mma3_chunk<4, 2, 0, 16>(av, dv, ws.acquire(), lane);
+    float hv[64];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[16 * nb + r] = fmaxf(av[nb][r], 0.0f);
+    if (SAVE && valid) {
+        store_rows3<64>(a.act + al.hv + (size_t)p * WV, hv, half);
+        save_mask3<64>(a.act + al.mask, D, (size_t)P, (size_t)p, half, hv);
+    }
+
+    // ---- rgb_linear 128 -> 3
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    {
+        const float* wr = small_ptr(lds, SM_WRGB);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = 32 * ob + 8 * g + 4 * half;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + col);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + WV + col);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 2 * WV + col);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = hv[16 * ob + 4 * g + r];
+                    c0 = fmaf(x, w0[r], c0);
+                    c1 = fmaf(x, w1[r], c1);
+                    c2 = fmaf(x, w2[r], c2);
+                }
+            }
+        c0 = half_sum(c0) + small_ptr(lds, SM_BRGB)[0];
+        c1 = half_sum(c1) + small_ptr(lds, SM_BRGB)[1];
+        c2 = half_sum(c2) + small_ptr(lds, SM_BRGB)[2];
+    }
+    if (valid && half == 0) *reinterpret_cast<f32x4*>(a.raw + (size_t)p * 4) = f32x4{c0, c1, c2, sigma};
+}
+
+hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
+                             int n_rays, int S, float* raw, float* act, hipStream_t stream) {
+    FieldFwd3Args a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S};
+    const long P = (long)n_rays * S;
+    if (P <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)field_fwd3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        hipError_t e2 = hipFuncSetAttribute((const void*)field_fwd3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        if (e1 != hipSuccess) return e1;
+        if (e2 != hipSuccess) return e2;
+        attr_set = true;
+    }
+    if (act)
+        hipLaunchKernelGGL(field_fwd3_kernel<true>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
+    else
+        hipLaunchKernelGGL(field_fwd3_kernel<false>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace nerf

@@ -50,5 +50,9 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
                               float* partial, float* grad, int accumulate, hipStream_t stream);
 size_t wgrad_partial_floats(long P);
 void pack_table_host(int* out);
+void pack3_table_host(int* out);
+hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream);
+hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
+                             int n_rays, int S, float* raw, float* act, hipStream_t stream);
 
 }  // namespace nerf

@@ -150,3 +150,55 @@ constexpr int FIELD_WAVES = 8;                      // 512-thread workgroups, 2 
 constexpr int PTS_PER_WG = PTS_PER_WAVE * FIELD_WAVES;
 
 }  // namespace nerf
+
+// =====================================================================================
+// Split-bf16 ("bf16x3") datapath: W*x ~= W_hi*x_hi + W_hi*x_lo + W_lo*x_hi on v_mfma_f32_32x32x16_bf16
+// with fp32 accumulation (hi = bf16(v), lo = bf16(v - hi): 16-17 significant bits per operand, ~1e-5
+// relative error per product instead of bf16's 4e-3).  One wave owns 32 points; the D layout of a
+// 32-feature block (lane (p = l&31, half = l>>5) holds features 32*ob + (r&3) + 8*(r>>2) + 4*half,
+// r = 0..15) is again the B operand of the next layer after a permutation of the contraction index.
+// =====================================================================================
+namespace nerf {
+
+// feature held in accumulator register r of lane half `half` inside a 32-feature block
+__host__ __device__ constexpr int d32row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// hidden vector, 16 k-steps of 16 slots: k-step s, lane half, element j (0..7) -> feature
+__host__ __device__ constexpr int h3slot(int s, int half, int j) { return 32 * (s >> 1) + d32row(8 * (s & 1) + j, half); }
+// xyz encoding, 4 k-steps: lane half 0 owns (freq,axis) pairs 0..15, half 1 pairs 16..29 + identity + pad;
+// lane value v = 8*s + j; pairs are (sin, cos) adjacent
+__host__ __device__ constexpr int enc3slot(int v, int half) {
+    if (half == 0) { const int i = v >> 1, fn = v & 1; return 3 + (i / 3) * 6 + fn * 3 + (i % 3); }
+    if (v < 28) { const int i = 16 + (v >> 1), fn = v & 1; return 3 + (i / 3) * 6 + fn * 3 + (i % 3); }
+    return v < 31 ? v - 28 : -1;
+}
+// dir encoding, 2 k-steps: half 0 owns pairs 0..7, half 1 pairs 8..11 + identity + pad; lane value v = 8*s + j
+__host__ __device__ constexpr int dir3slot(int v, int half) {
+    if (half == 0) { const int i = v >> 1, fn = v & 1; return 3 + (i / 3) * 6 + fn * 3 + (i % 3); }
+    if (v < 8) { const int i = 8 + (v >> 1), fn = v & 1; return 3 + (i / 3) * 6 + fn * 3 + (i % 3); }
+    return v < 11 ? v - 8 : -1;
+}
+constexpr int KS3_H = 16, KS3_ENC = 4, KS3_DIR = 2, KS3_HV = 8;
+// one k-step of an NB-block layer = NB * 2 (hi, lo) * 64 lanes * 16 B; sizes below in 32-bit words
+constexpr int KSTEP3_W8 = 8 * 2 * 64 * 4;      // 4096 words = 16 KiB (256 outputs)
+constexpr int KSTEP3_W4 = 4 * 2 * 64 * 4;      // 2048 words (128 outputs)
+// element (nb, hl, lane, j) of a k-step lives at 16-bit index (((nb*2 + hl)*64 + lane)*8 + j)
+constexpr int P3F_L0 = 0;
+constexpr int P3F_L1 = P3F_L0 + KS3_ENC * KSTEP3_W8;                    // layers 1..4
+constexpr int P3F_L5 = P3F_L1 + 4 * KS3_H * KSTEP3_W8;
+constexpr int P3F_L6 = P3F_L5 + (KS3_ENC + KS3_H) * KSTEP3_W8;          // layers 6, 7
+constexpr int P3F_FEAT = P3F_L6 + 2 * KS3_H * KSTEP3_W8;
+constexpr int P3F_VIEWS = P3F_FEAT + KS3_H * KSTEP3_W8;
+constexpr int P3F_END = P3F_VIEWS + (KS3_H + KS3_DIR) * KSTEP3_W4;
+constexpr int P3B_VIEWS = P3F_END;                                      // transposed streams, all 8 blocks
+constexpr int P3B_FEAT = P3B_VIEWS + KS3_HV * KSTEP3_W8;
+constexpr int P3B_L7 = P3B_FEAT + KS3_H * KSTEP3_W8;                    // then L6 .. L1
+constexpr int P3B_END = P3B_L7 + 7 * KS3_H * KSTEP3_W8;
+constexpr int P3_SMALL = P3B_END;                                       // fp32 small parameters, same order as SM_*
+constexpr int PACKED3_WORDS = P3_SMALL + (PACKED_FLOATS - SM_BIAS);
+static_assert(P3F_VIEWS % 4096 == 0 && P3B_VIEWS % 4 == 0, "chunk alignment");
+
+constexpr int PTS_PER_WAVE3 = 32;
+constexpr int FIELD3_WAVES = 4;                                         // 256-thread workgroups, 1 wave / SIMD
+constexpr int PTS_PER_WG3 = PTS_PER_WAVE3 * FIELD3_WAVES;
+
+}  // namespace nerf

@@ -72,6 +72,91 @@ __global__ void pack_params_kernel(const float* __restrict__ canon_params, float
     packed[idx] = src < 0 ? 0.0f : canon_params[src];
 }
 
+// ---- split-bf16 repack: every weight becomes (hi, lo) bf16; layout in nerf_common.h (bf16x3 section)
+// returns the canonical source index of 16-bit element e16 of the weight streams (-1: zero padding);
+// *is_lo tells whether the element is the low part
+__host__ __device__ inline int pack3_source(int e16, int* is_lo) {
+    constexpr Canon c = canon();
+    const int word = e16 >> 1;
+    int base, kind;          // kind: 0..7 trunk layer fwd, 8 feature fwd, 9 views fwd, 10 views^T, 11 feat^T, 12+l: layer l ^T
+    if (word < P3F_L1) { base = P3F_L0; kind = 0; }
+    else if (word < P3F_L5) { kind = 1 + (word - P3F_L1) / (KS3_H * KSTEP3_W8); base = P3F_L1 + (kind - 1) * KS3_H * KSTEP3_W8; }
+    else if (word < P3F_L6) { base = P3F_L5; kind = 5; }
+    else if (word < P3F_FEAT) { kind = 6 + (word - P3F_L6) / (KS3_H * KSTEP3_W8); base = P3F_L6 + (kind - 6) * KS3_H * KSTEP3_W8; }
+    else if (word < P3F_VIEWS) { base = P3F_FEAT; kind = 8; }
+    else if (word < P3F_END) { base = P3F_VIEWS; kind = 9; }
+    else if (word < P3B_FEAT) { base = P3B_VIEWS; kind = 10; }
+    else if (word < P3B_L7) { base = P3B_FEAT; kind = 11; }
+    else { const int t = (word - P3B_L7) / (KS3_H * KSTEP3_W8); kind = 12 + (7 - t); base = P3B_L7 + t * KS3_H * KSTEP3_W8; }
+    const int nblk = kind == 9 ? 4 : 8;
+    const int per_kstep16 = nblk * 2 * 64 * 8;
+    const int r = e16 - 2 * base;
+    const int s = r / per_kstep16, rem = r % per_kstep16;
+    const int nb = rem / 1024, hl = (rem / 512) & 1, lane = (rem >> 3) & 63, j = rem & 7;
+    const int row = 32 * nb + (lane & 31), half = lane >> 5;
+    *is_lo = hl;
+    if (kind <= 7) {
+        const int ld = fan_in(kind);
+        if (kind == 0) { const int e = enc3slot(8 * s + j, half); return e < 0 ? -1 : c.w[0] + row * ld + e; }
+        if (kind == SKIP + 1) {
+            if (s < KS3_ENC) { const int e = enc3slot(8 * s + j, half); return e < 0 ? -1 : c.w[kind] + row * ld + e; }
+            return c.w[kind] + row * ld + IN_XYZ + h3slot(s - KS3_ENC, half, j);
+        }
+        return c.w[kind] + row * ld + h3slot(s, half, j);
+    }
+    if (kind == 8) return c.wf + row * W + h3slot(s, half, j);
+    if (kind == 9) {
+        if (s < KS3_H) return c.wv + row * (W + IN_DIR) + h3slot(s, half, j);
+        const int d = dir3slot(8 * (s - KS3_H) + j, half);
+        return d < 0 ? -1 : c.wv + row * (W + IN_DIR) + W + d;
+    }
+    // transposed: output row = input feature k of the layer, contraction slot = output feature n
+    const int n = h3slot(s, half, j);
+    if (kind == 10) return c.wv + n * (W + IN_DIR) + row;
+    if (kind == 11) return c.wf + n * W + row;
+    const int l = kind - 12;
+    if (l == SKIP + 1) return c.w[l] + n * (W + IN_XYZ) + IN_XYZ + row;
+    return c.w[l] + n * W + row;
+}
+
+__device__ inline unsigned short bf16_rne(float x) {
+    return __builtin_bit_cast(unsigned short, (__bf16)x);
+}
+
+__global__ void pack3_params_kernel(const float* __restrict__ canon_params, unsigned short* __restrict__ packed16) {
+    const int e16 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e16 >= 2 * P3B_END) return;
+    int is_lo;
+    const int src = pack3_source(e16, &is_lo);
+    unsigned short v = 0;
+    if (src >= 0) {
+        const float x = canon_params[src];
+        const unsigned short hi = bf16_rne(x);
+        v = is_lo ? bf16_rne(x - __uint_as_float((unsigned)hi << 16)) : hi;
+    }
+    packed16[e16] = v;
+}
+
+__global__ void pack3_small_kernel(const float* __restrict__ canon_params, float* __restrict__ packed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= PACKED_FLOATS - SM_BIAS) return;
+    const int src = pack_source(SM_BIAS + i);
+    packed[P3_SMALL + i] = src < 0 ? 0.0f : canon_params[src];
+}
+
+void pack3_table_host(int* out) {
+    for (int e = 0; e < 2 * P3B_END; ++e) { int lo; const int s = pack3_source(e, &lo); out[e] = s < 0 ? -1 : 2 * s + lo; }
+}
+
+hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream) {
+    const int threads = 256;
+    hipLaunchKernelGGL(pack3_params_kernel, dim3((2 * P3B_END + threads - 1) / threads), dim3(threads), 0, stream,
+                       canon_params, reinterpret_cast<unsigned short*>(packed));
+    hipLaunchKernelGGL(pack3_small_kernel, dim3((PACKED_FLOATS - SM_BIAS + threads - 1) / threads), dim3(threads), 0, stream,
+                       canon_params, packed);
+    return hipGetLastError();
+}
+
 // host copy of the gather table (CPU tests emulate the MFMA data flow with it)
 void pack_table_host(int* out) {
     for (int i = 0; i < PACKED_FLOATS; ++i) out[i] = pack_source(i);

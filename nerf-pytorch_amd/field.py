@@ -115,15 +115,17 @@ class NeRF(nn.Module):
             self._bind_flat()
         return self._flat
 
-    def packed_params(self):
-        """Fragment repack of the current parameters (cached on the parameters' versions)."""
+    def packed_params(self, precision="fp32"):
+        """Fragment repack of the current parameters for the given datapath (cached on the parameters' versions)."""
         flat = self.flat_params()
         key = tuple(p._version for p in self.parameters()) + (flat.data_ptr(),)
         if self._packed is None or key != self._packed_key:
-            # fresh tensor each time: a pending backward keeps a reference to the old one
-            self._packed = hb.pack_params(flat)
+            self._packed = {}
             self._packed_key = key
-        return self._packed
+        if precision not in self._packed:
+            # fresh tensor each time: a pending backward keeps a reference to the old one
+            self._packed[precision] = hb.pack_params(flat, precision=precision)
+        return self._packed[precision]
 
     def param_list(self):
         return [p for _, _, _, p in self._ordered_params()]

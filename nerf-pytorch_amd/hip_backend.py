@@ -44,6 +44,10 @@ def _declare(lib):
         "nerf_field_bwd": (i, [p, p, p, i, i, p, p, p, i, p]),
         "nerf_field_dgrad": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad": (i, [p, p, p, i, i, p, p, i, p]),
+        "nerf_packed3_floats": (i, []),
+        "nerf_pack_params_bf16x3": (i, [p, p, p]),
+        "nerf_field_fwd_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
+        "nerf_debug_pack3_table": (i, [p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
@@ -55,7 +59,8 @@ def _declare(lib):
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
            "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_sample_coarse", "nerf_act_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
-           "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad"]
+           "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
+           "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table"]
 
 
 def lib():
@@ -165,8 +170,31 @@ def pack_table():
     return tab
 
 
-def pack_params(flat, out=None):
+PRECISIONS = ("fp32", "bf16x3")
+
+
+def pack_table3():
+    """Host-side gather table of the split-bf16 repack: per 16-bit element 2*canonical_index + is_lo, -1 = padding."""
+    import numpy as np
     L = lib()
+    n16 = 2 * (L.nerf_packed3_floats() - (L.nerf_packed_floats() - _small_offset()))
+    tab = np.empty(n16, dtype=np.int32)
+    _check(L.nerf_debug_pack3_table(tab.ctypes.data_as(ctypes.c_void_p)), "nerf_debug_pack3_table")
+    return tab
+
+
+def _small_offset():
+    # SM_BIAS of csrc/nerf_common.h = first word after the fp32 forward + backward weight streams
+    return 593408 + 557056
+
+
+def pack_params(flat, out=None, precision="fp32"):
+    L = lib()
+    if precision == "bf16x3":
+        if out is None:
+            out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
+        _check(L.nerf_pack_params_bf16x3(_ptr(flat, "params"), _ptr(out, "packed"), _stream()), "nerf_pack_params_bf16x3")
+        return out
     if out is None:
         out = torch.empty(L.nerf_packed_floats(), dtype=torch.float32, device=flat.device)
     _check(L.nerf_pack_params(_ptr(flat, "params"), _ptr(out, "packed"), _stream()), "nerf_pack_params")
@@ -194,11 +222,16 @@ def act_floats(n_rays, n_samples):
     return lib().nerf_act_floats(n_rays, n_samples)
 
 
-def field_fwd(packed, rays, z_vals, save_act=False):
+def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     n, stride = rays.shape
     S = z_vals.shape[1]
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
     act = torch.empty(act_floats(n, S), dtype=torch.float32, device=rays.device) if save_act else None
+    if precision == "bf16x3":
+        with _timed("field_fwd3_kernel<save>" if save_act else "field_fwd3_kernel", FLOP_FWD_PER_POINT * n * S):
+            _check(lib().nerf_field_fwd_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                               n, S, _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd_bf16x3")
+        return raw, act
     with _timed("field_fwd_kernel<save>" if save_act else "field_fwd_kernel", FLOP_FWD_PER_POINT * n * S):
         _check(lib().nerf_field_fwd(_ptr(packed, "packed"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"), n, S,
                                     _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd")

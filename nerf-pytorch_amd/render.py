@@ -14,6 +14,20 @@ from . import hip_backend as hb
 from .field import NeRF
 
 _LINSPACE_CACHE = {}
+_PRECISION = __import__("os").environ.get("NERF_PRECISION", "fp32")
+
+
+def set_precision(mode):
+    """Select the field datapath: "fp32" (exact fp32 MFMA, the parity anchor) or "bf16x3" (split-bf16 MFMA,
+    fp32 accumulate, ~1e-5 relative error; judged by the PSNR-delta criterion)."""
+    global _PRECISION
+    if mode not in hb.PRECISIONS:
+        raise ValueError(f"precision must be one of {hb.PRECISIONS}")
+    _PRECISION = mode
+
+
+def get_precision():
+    return _PRECISION
 
 
 def _linspace01(n, device):
@@ -34,10 +48,12 @@ class _FieldQuery(torch.autograd.Function):
     """raw = field(rays, z) for explicit rays/depths; gradients w.r.t. the parameters only."""
 
     @staticmethod
-    def forward(ctx, model, rays, z_vals, *params):
-        need = any(ctx.needs_input_grad[3:])
-        packed = model.packed_params()
-        raw, act = hb.field_fwd(packed, rays, z_vals, save_act=need)
+    def forward(ctx, model, rays, z_vals, need, *params):
+        prec = _PRECISION
+        if need and prec != "fp32":
+            raise NotImplementedError(f"precision {prec!r}: backward not implemented yet; use set_precision('fp32') to train")
+        packed = model.packed_params(prec)
+        raw, act = hb.field_fwd(packed, rays, z_vals, save_act=need, precision=prec)
         ctx.model, ctx.packed, ctx.act = model, packed, act
         ctx.set_materialize_grads(False)
         return raw
@@ -46,12 +62,12 @@ class _FieldQuery(torch.autograd.Function):
     def backward(ctx, d_raw):
         model = ctx.model
         if d_raw is None or ctx.act is None:
-            return (None, None, None) + (None,) * len(_param_slices(model))
+            return (None, None, None, None) + (None,) * len(_param_slices(model))
         grad = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=d_raw.device)
         hb.field_bwd(ctx.packed, ctx.act, d_raw.contiguous(), grad, accumulate=False)
         ctx.act = None
         model.last_flat_grad = grad
-        return (None, None, None) + _grad_views(model, grad)
+        return (None, None, None, None) + _grad_views(model, grad)
 
 
 def _param_slices(model):
@@ -70,13 +86,16 @@ class _RenderRays(torch.autograd.Function):
     def forward(ctx, cfg, rays, rnd, model_c, model_f, *params):
         n_c, n_f = cfg["N_samples"], cfg["N_importance"]
         same_net = model_f is None or model_f is model_c
-        need = any(ctx.needs_input_grad[5:])
+        need = cfg["need_grad"]
         dev = rays.device
         std = cfg["raw_noise_std"]
         wb = cfg["white_bkgd"]
-        packed_c = model_c.packed_params()
+        prec = cfg.get("precision", "fp32")
+        if need and prec != "fp32":
+            raise NotImplementedError(f"precision {prec!r}: backward not implemented yet; use set_precision('fp32') to train")
+        packed_c = model_c.packed_params(prec)
         z_c = hb.sample_coarse(rays, _linspace01(n_c, dev), cfg["lindisp"], rnd.get("t_rand"))
-        raw_c, act_c = hb.field_fwd(packed_c, rays, z_c, save_act=need)
+        raw_c, act_c = hb.field_fwd(packed_c, rays, z_c, save_act=need, precision=prec)
         rgb_c, disp_c, acc_c, w_c, _ = hb.raw2outputs(raw_c, z_c, rays, rays.shape[1], rnd.get("noise_c"), std, wb,
                                                       want_weights=n_f > 0, want_depth=False, rays_d_offset=3)
         ctx.cfg, ctx.model_c, ctx.model_f, ctx.same_net = cfg, model_c, model_f, same_net
@@ -90,8 +109,8 @@ class _RenderRays(torch.autograd.Function):
         u = rnd.get("u")
         z_f, z_std, _ = hb.sample_fine(z_c, w_c, n_f, u, None if u is not None else _linspace01(n_f, dev))
         mf = model_c if same_net else model_f
-        packed_f = mf.packed_params()
-        raw_f, act_f = hb.field_fwd(packed_f, rays, z_f, save_act=need)
+        packed_f = mf.packed_params(prec)
+        raw_f, act_f = hb.field_fwd(packed_f, rays, z_f, save_act=need, precision=prec)
         rgb_f, disp_f, acc_f, _, _ = hb.raw2outputs(raw_f, z_f, rays, rays.shape[1], rnd.get("noise_f"), std, wb,
                                                     want_weights=False, want_depth=False, rays_d_offset=3)
         ctx.save_for_backward(rays, z_c, raw_c, z_f, raw_f)
@@ -199,7 +218,9 @@ def query_points(model, pts, viewdirs_per_point):
     rays[:, 0:3] = pts
     rays[:, 8:11] = vd
     z = torch.zeros((n, 1), dtype=torch.float32, device=pts.device)
-    raw = _FieldQuery.apply(model, rays, z, *model.param_list())
+    plist = model.param_list()
+    need = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
+    raw = _FieldQuery.apply(model, rays, z, need, *plist)
     return raw.reshape(n, 4)
 
 
@@ -318,11 +339,13 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     if pytest and raw_noise_std > 0. and randoms is None:
         std = 1.0       # pytest noise is pre-scaled in float64 like the reference (run_nerf.py:290)
     cfg = dict(N_samples=int(N_samples), N_importance=n_f, lindisp=bool(lindisp), white_bkgd=bool(white_bkgd),
-               raw_noise_std=std)
+               raw_noise_std=std, precision=_PRECISION)
     params = network_fn.param_list()
     same = network_fine is None or network_fine is network_fn
     if n_f > 0 and not same:
         params = params + network_fine.param_list()
+    # activations are saved only when a backward can follow (Function.forward itself always runs in no-grad mode)
+    cfg["need_grad"] = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     outs = _RenderRays.apply(cfg, rays, rnd, network_fn, None if (same or n_f <= 0) else network_fine, *params)
     if n_f <= 0:
         rgb_map, disp_map, acc_map, raw = outs

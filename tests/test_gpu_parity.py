@@ -383,6 +383,57 @@ def test_golden_coarse_only(npa, dev, nets):
     _check_golden(npa, dev, nets, "lego_coarse_only", dict(perturb=1.0, N_importance=0, network_fine=None), 11)
 
 
+# ---------------------------------------------------------------- split-bf16 datapath (precision "bf16x3")
+@pytest.mark.parametrize("n_rays,S", [(64, 64), (37, 192), (5, 3)])
+def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
+    """W*x = W_hi*x_hi + W_hi*x_lo + W_lo*x_hi on bf16 MFMA: ~1e-5 relative per product (fp32: 6e-8, bf16: 4e-3)."""
+    nc, nf, Pc, Pf = nets
+    rays = orc.synthetic_rays(n_rays, seed=S)
+    z = torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0]
+    raw, _ = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=False, precision="bf16x3")
+    raw32, _ = npa.hip_backend.field_fwd(nf.packed_params("fp32"), rays.to(dev), z.to(dev), save_act=False)
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]
+    ref64 = orc.query_field({k: v.double() for k, v in Pf.items()}, pts.double(), rays[:, 8:11].double())
+    scale = max(1.0, float(ref64.abs().max()))
+    e3, e32 = maxdiff(raw, ref64), maxdiff(raw32, ref64)
+    print(f"bf16x3 max|raw-ref64| = {e3:.2e} (fp32 kernel: {e32:.2e}) at |raw|max = {scale:.1f}")
+    assert e3 <= 3e-4 * scale, (e3, scale)
+    raw_s, act = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
+    assert torch.equal(raw, raw_s)
+    P = n_rays * S
+    feats = torch.cat([orc.posenc(pts.reshape(-1, 3), 10), orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3), 4)], -1)
+    _, hidden, feat, hv = orc.field_mlp(Pf, feats, return_hidden=True)
+    act = act.cpu()
+    for l in range(8):
+        got = act[l * P * 256:(l + 1) * P * 256].view(P, 256)
+        assert maxdiff(got, hidden[l]) <= 3e-4 * max(1.0, float(hidden[l].abs().max())), l
+    assert maxdiff(act[8 * P * 256:9 * P * 256].view(P, 256), feat) <= 3e-4 * max(1.0, float(feat.abs().max()))
+    assert maxdiff(act[9 * P * 256:9 * P * 256 + P * 128].view(P, 128), hv) <= 3e-4 * max(1.0, float(hv.abs().max()))
+    o = 9 * P * 256 + P * 128
+    assert maxdiff(act[o:o + P * 64].view(P, 64)[:, :63], feats[:, :63]) <= 5e-6
+
+
+def test_bf16x3_render_psnr_delta(npa, dev, nets):
+    """north_star bar for a reduced-precision datapath: PSNR delta vs the reference < 0.01 dB (here: measured ~1e-4)."""
+    nc, nf, Pc, Pf = nets
+    rays = orc.synthetic_rays(512, seed=31)
+    target = torch.rand(512, 3, generator=torch.Generator().manual_seed(5))
+    npa.set_precision("bf16x3")
+    try:
+        with torch.no_grad():
+            out = npa.render_rays(rays.to(dev), nc, None, 64, N_importance=128, network_fine=nf, white_bkgd=True, retraw=True)
+    finally:
+        npa.set_precision("fp32")
+    ref = orc.trace_rays(rays, Pc, Pf, 64, 128, white_bkgd=True)
+    d0 = maxdiff(out["rgb0"], ref["rgb0"])
+    mse_h = float(((out["rgb_map"].cpu() - target) ** 2).mean())
+    mse_r = float(((ref["rgb_map"] - target) ** 2).mean())
+    dpsnr = abs(10 * np.log10(mse_h / mse_r))
+    print(f"bf16x3: max|rgb0 - ref| = {d0:.2e}, max|rgb - ref| = {maxdiff(out['rgb_map'], ref['rgb_map']):.2e}, PSNR delta = {dpsnr:.2e} dB")
+    assert d0 <= 2e-4
+    assert dpsnr < 0.01
+
+
 def test_adversarial_scene_psnr_delta(npa, dev):
     """Unrelated coarse/fine networks with full-strength 2^9-frequency columns: per-ray agreement is not
     defined (the reference's own fp32-vs-fp64 runs disagree at 1e-2 here), the image-level criterion is."""

@@ -38,6 +38,10 @@ packed = nf.packed_params()
 z = torch.sort(torch.rand(N, 192, device=dev) * 4 + 2, -1)[0]
 res["field_fwd_192_s"] = timeit(lambda: npa.hip_backend.field_fwd(packed, rays, z, False))
 res["field_fwd_192_save_s"] = timeit(lambda: npa.hip_backend.field_fwd(packed, rays, z, True))
+packed3 = nf.packed_params("bf16x3")
+res["field_fwd3_192_s"] = timeit(lambda: npa.hip_backend.field_fwd(packed3, rays, z, False, precision="bf16x3"))
+res["field_fwd3_192_save_s"] = timeit(lambda: npa.hip_backend.field_fwd(packed3, rays, z, True, precision="bf16x3"))
+npa.set_precision("bf16x3"); res["hip_infer_bf16x3_s"] = timeit(infer); npa.set_precision("fp32")
 raw, act = npa.hip_backend.field_fwd(packed, rays, z, True)
 d_raw = torch.randn(N, 192, 4, device=dev); grad = torch.empty(595844, device=dev)
 res["field_bwd_192_s"] = timeit(lambda: npa.hip_backend.field_bwd(packed, act, d_raw, grad, False))
@@ -55,12 +59,14 @@ def eager_train():
 def eager_infer():
     with torch.no_grad():
         orc.trace_rays(rays, Pcg, Pfg, 64, 128, perturb=0.0, white_bkgd=True)
-res["eager_infer_s"] = timeit(eager_infer, 1, 3); res["eager_train_s"] = timeit(eager_train, 1, 3)
+if "--eager" in sys.argv:
+    res["eager_infer_s"] = timeit(eager_infer, 1, 3); res["eager_train_s"] = timeit(eager_train, 1, 3)
 for k in list(res):
     res[k.replace("_s", "_rays_per_s")] = N / res[k]
 flop_fwd = 303.82e6 * N; flop_train = 893.19e6 * N
 res["hip_infer_TFLOPs"] = flop_fwd / res["hip_infer_s"] / 1e12
 res["hip_train_TFLOPs"] = flop_train / res["hip_train_s"] / 1e12
 res["field_fwd_192_TFLOPs"] = 1186816 * N * 192 / res["field_fwd_192_s"] / 1e12
+res["field_fwd3_192_TFLOPs_equiv"] = 1186816 * N * 192 / res["field_fwd3_192_s"] / 1e12
 res["field_bwd_192_TFLOPs"] = 2 * (557696 + 593408) * N * 192 / res["field_bwd_192_s"] / 1e12
 print(json.dumps(res, indent=1))
