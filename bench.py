@@ -28,6 +28,7 @@ N_SAMPLES, N_IMPORTANCE = 64, 128
 FLOP_FWD_PER_RAY = 2 * 593408 * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)               # 303.82 MFLOP
 FLOP_TRAIN_PER_RAY = 2 * (593408 + 557696 + 593408) * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)  # 893.19 MFLOP
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = vector rate; exact-fp32 datapath
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA; the bf16x3 datapath issues 3 MFMA FLOPs per algorithmic FLOP
 
 
 def cpu_baseline(n_rays=512):
@@ -69,12 +70,15 @@ def main():
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--rays", type=int, default=N_RAND, help="rays per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=os.environ.get("NERF_BENCH_PRECISION", "fp32"),
+                    help="field datapath: exact fp32 MFMA or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)")
     args = ap.parse_args()
 
     import nerf_oracle as orc
     import nerf_pytorch_amd as npa
     from nerf_pytorch_amd import parallel
 
+    npa.set_precision(args.precision)
     rank, world, dev = parallel.init_distributed()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the render hot path has no CPU fallback)"
@@ -155,16 +159,23 @@ def main():
         roofline = None
         if dom is not None:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            if args.precision == "fp32":
+                peak, issued = PEAK_FP32_MFMA_TFLOPS, 1.0
+            else:       # every algorithmic FLOP is issued three times on the bf16 pipe
+                peak, issued = PEAK_BF16_MFMA_TFLOPS, 3.0
+            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": ach * issued, "peak": peak,
+                        "unit": "TFLOP/s", "frac": ach * issued / peak, "traffic": None,
+                        "algorithmic_tflops": ach, "mfma_flops_per_algorithmic_flop": issued,
                         "avg_launch_ms": dom["ms"] / dom["launches"],
-                        "whole_step_frac": value * flop_per_ray / world / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+                        "whole_step_frac": value * flop_per_ray * issued / world / 1e12 / peak}
         line = {
             "metric": "rays/sec (coarse+fine, 64+128 samples), training step" if args.mode == "train"
                       else "rays/sec (coarse+fine, 64+128 samples), inference",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-bf16 MFMA products, f32 accumulate/activations/gradients)",
+            "data": "synthetic",
             "config": {"workload": f"lego-like 400x400, N_rand={n} rays/GPU x (64 coarse + 128 fine) samples, "
                                    "two 8x256 networks, perturb=1, white_bkgd; step = render + MSE + backward"
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + " + Adam"

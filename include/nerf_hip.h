@@ -117,6 +117,12 @@ int nerf_packed3_floats(void);
 int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream);
 int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                           int n_samples, float* raw, float* act, void* stream);
+/* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  The narrow weight-gradient
+ * jobs (63- / 27- / 3- / 1-wide) stay on the exact fp32 kernel. */
+int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
+                            float* delta, void* stream);
+int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
+                            float* partial, float* grad, int accumulate, void* stream);
 /* test hook (host only): out_host[e] for every 16-bit element e of the weight streams (2 * stream words):
  * 2 * canonical_index + is_low_part, or -1 for zero padding. */
 int nerf_debug_pack3_table(int* out_host);

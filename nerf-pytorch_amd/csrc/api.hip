@@ -165,7 +165,25 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
                      float* partial, float* grad, int accumulate, void* stream) {
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate,
+    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 0,
+                                                   (hipStream_t)stream));
+}
+
+int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
+                            float* delta, void* stream) {
+    REQUIRE(packed3 && act && d_raw && delta, "null pointer");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
+            "packed/act/d_raw/delta must be 16-byte aligned");
+    return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, (hipStream_t)stream));
+}
+
+int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
+                            float* partial, float* grad, int accumulate, void* stream) {
+    REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 1,
                                                    (hipStream_t)stream));
 }
 

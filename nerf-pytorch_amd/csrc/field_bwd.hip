@@ -13,7 +13,7 @@
 //                        split over point chunks; per-chunk partial gradients are
 //                        written in canonical layout and summed by
 //   wgrad_reduce_kernel (deterministic, no atomics).
-#include "field_device.h"
+#include "field_device_bf16.h"
 
 #include "launchers.h"
 
@@ -375,6 +375,106 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(WgradArgs a) {
     }
 }
 
+// Split-bf16 variant of wgrad256_kernel: dW = delta^T X with every product evaluated as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16 (contraction over points).  The MFMA wants 8 consecutive POINTS of one feature per lane,
+// the operands are stored point-major, so staging transposes through registers: thread (operand, feature f) loads
+// its feature for the 32 points of a stage (each wave-instruction = 64 consecutive features of one point = 256 B),
+// splits them into (hi, lo) bf16 and writes four 16-byte groups into a feature-major LDS image padded to 144 B per
+// feature (conflict-free ds_write_b128 and ds_read_b128).  Bias gradients fall out of the staging threads exactly
+// (fp32 sums of the values they loaded).  HBM-bound: 64 KiB of operands per 48 MFMAs per wave.
+constexpr int WG3_FEAT_BYTES = 144;                              // 32 pts x 2 B x (hi, lo) + 16 B pad
+constexpr int WG3_OPERAND_BYTES = 256 * WG3_FEAT_BYTES;          // 36,864
+constexpr int WG3_LDS_BYTES = 2 * 2 * WG3_OPERAND_BYTES;         // 2 buffers x (A, B) = 147,456
+
+__global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave >> 2, wave_k = wave & 3;
+    const int ji = blockIdx.x % a.n_jobs;
+    const int chunk = blockIdx.x / a.n_jobs;
+    const WgradJob& jb = a.job[ji];
+    const long p_begin = (long)chunk * a.chunk_pts;
+    const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
+    const int n_stages = (int)((p_end - p_begin + WG_STAGE - 1) / WG_STAGE);
+    // staging role: operand 0 = delta (A), 1 = input (B); one feature column per thread
+    const int sop = tid >> 8, sf = tid & 255;
+    const float* sbase = (sop == 0 ? jb.A : jb.B) + sf;
+    const int sld = sop == 0 ? jb.lda : jb.ldb;
+    float rv[WG_STAGE];
+    float colsum = 0.0f;
+    auto gload = [&](int st) {
+        const long r0 = p_begin + (long)st * WG_STAGE;
+#pragma unroll
+        for (int q = 0; q < WG_STAGE; ++q) {
+            const long r = r0 + q;
+            rv[q] = r < p_end ? sbase[r * sld] : 0.0f;
+        }
+    };
+    auto swrite = [&](int buf) {
+        unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + sf * WG3_FEAT_BYTES;
+#pragma unroll
+        for (int gq = 0; gq < WG_STAGE / 8; ++gq) {
+            u32x4 hi, lo;
+            split8(&rv[8 * gq], hi, lo);
+            *reinterpret_cast<u32x4*>(dst + 16 * gq) = hi;
+            *reinterpret_cast<u32x4*>(dst + 64 + 16 * gq) = lo;
+        }
+#pragma unroll
+        for (int q = 0; q < WG_STAGE; ++q) colsum += rv[q];
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int row = lane & 31, hf = lane >> 5;
+    for (int st = 0; st < n_stages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < n_stages) gload(st + 1);
+        const unsigned char* sa = sm3 + (buf * 2) * WG3_OPERAND_BYTES + (wave_n * 128 + row) * WG3_FEAT_BYTES + 16 * hf;
+        const unsigned char* sb = sm3 + (buf * 2 + 1) * WG3_OPERAND_BYTES + (wave_k * 64 + row) * WG3_FEAT_BYTES + 16 * hf;
+#pragma unroll
+        for (int t = 0; t < WG_STAGE / 16; ++t) {
+            u32x4 bhi[2], blo[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bhi[j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * WG3_FEAT_BYTES + 32 * t);
+                blo[j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * WG3_FEAT_BYTES + 64 + 32 * t);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 ahi = *reinterpret_cast<const u32x4*>(sa + i * 32 * WG3_FEAT_BYTES + 32 * t);
+                const u32x4 alo = *reinterpret_cast<const u32x4*>(sa + i * 32 * WG3_FEAT_BYTES + 64 + 32 * t);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(ahi, bhi[j], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(ahi, blo[j], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(alo, bhi[j], acc[i][j]);
+            }
+        }
+        if (st + 1 < n_stages) swrite(buf ^ 1);
+        __syncthreads();
+    }
+    // acc[i][j][r] at lane (col = lane&31, hf) = dW[wave_n*128 + 32*i + d32row(r, hf)][wave_k*64 + 32*j + col]
+    float* out = a.partial + (size_t)chunk * N_PARAMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = wave_n * 128 + 32 * i + d32row(r, hf);
+            float* orow = out + jb.c_off + (size_t)n * jb.ldc + wave_k * 64 + row;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) orow[32 * j] = acc[i][j][r];
+        }
+    if (jb.bias_off >= 0 && sop == 0) out[jb.bias_off + sf] = colsum;
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N_PARAMS) return;
@@ -419,7 +519,7 @@ hipError_t launch_field_dgrad(const float* packed, const float* act, const float
 }
 
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
-                              float* partial, float* grad, int accumulate, hipStream_t stream) {
+                              float* partial, float* grad, int accumulate, int bf16x3, hipStream_t stream) {
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     hipError_t e;
@@ -487,7 +587,17 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (big.n_jobs > 0) {
+    static bool attr3_set = false;
+    if (bf16x3 && !attr3_set) {
+        e = hipFuncSetAttribute((const void*)wgrad3_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr3_set = true;
+    }
+    if (big.n_jobs > 0 && bf16x3) {
+        hipLaunchKernelGGL(wgrad3_256_kernel, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG3_LDS_BYTES, stream, big);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    } else if (big.n_jobs > 0) {
         hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG256_LDS_FLOATS * 4, stream, big);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -506,7 +616,7 @@ hipError_t launch_field_bwd(const float* packed, const float* act, const float* 
                             float* delta, float* partial, float* grad, int accumulate, hipStream_t stream) {
     hipError_t e = launch_field_dgrad(packed, act, d_raw, n_rays, S, delta, stream);
     if (e != hipSuccess) return e;
-    return launch_field_wgrad(act, delta, d_raw, n_rays, S, partial, grad, accumulate, stream);
+    return launch_field_wgrad(act, delta, d_raw, n_rays, S, partial, grad, accumulate, 0, stream);
 }
 
 }  // namespace nerf

@@ -1,0 +1,154 @@
+// Split-bf16 ("bf16x3") backward of the field evaluation: dgrad chain (this file, same register-resident
+// structure as field_fwd_bf16.hip with the transposed (hi, lo) weight stream) and the weight-gradient GEMM
+// wgrad3_kernel: dW = delta^T * X with both operands split on the fly into (hi, lo) bf16 while they are staged
+// into LDS (3 bf16 MFMAs per product, fp32 accumulate), contraction over points.
+#include "field_device_bf16.h"
+#include "launchers.h"
+
+namespace nerf {
+
+struct FieldBwd3Args {
+    const float* packed3;
+    const float* act;       // saved by field_fwd3_kernel<true> (bitmasks in the bf16x3 lane order)
+    const float* d_raw;     // [P][4]
+    float* delta;           // delta_layout(P)
+    int n_rays, S;
+};
+
+template <int NV>
+__device__ inline void apply_mask3(float (&d)[NV], const f32x16* acc, u32x4 m) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned bit = (m[i >> 5] >> (i & 31)) & 1u;
+        d[i] = bit ? acc[i >> 4][i & 15] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBwd3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const size_t P = (size_t)a.n_rays * a.S;
+    const size_t p_raw = ((size_t)blockIdx.x * FIELD3_WAVES + wave) * PTS_PER_WAVE3 + (lane & 31);
+    const bool valid = p_raw < P;
+    const size_t p = valid ? p_raw : P - 1;
+
+    WeightStreamT<3, FIELD3_WAVES> ws;
+    ws.start(a.packed3 + P3B_VIEWS, lds, wave, lane);
+    stage_small_from(a.packed3 + P3_SMALL, lds, FIELD3_WAVES * 64);
+
+    const ActLayout al = act_layout(P, (size_t)a.n_rays);
+    const DeltaLayout dl = delta_layout(P);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);       // (d_rgb3, d_sigma)
+    u32x4 msk[D + 1];
+    {
+        const u32x4* mp = reinterpret_cast<const u32x4*>(a.act + al.mask) + p * 2 + half;
+#pragma unroll
+        for (int l = 0; l <= D; ++l) msk[l] = mp[(size_t)l * P * 2];
+    }
+
+    // ---- rgb_linear^T (VALU) + ReLU mask of the view branch: lane value i = feature 32*(i>>4) + d32row(i&15, half)
+    float dhv[64];
+    {
+        const float* wr = small_ptr(lds, SM_WRGB);
+        __syncthreads();                 // stage_small visible
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = 32 * ob + 8 * q4 + 4 * half;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + col);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + WV + col);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 2 * WV + col);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ob + 4 * q4 + r;
+                    const float v = g[0] * w0[r] + g[1] * w1[r] + g[2] * w2[r];
+                    dhv[i] = ((msk[D][i >> 5] >> (i & 31)) & 1u) ? v : 0.0f;
+                }
+            }
+    }
+
+    f32x16 acc[8];
+    float d[128];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+    };
+    auto store_d = [&](size_t off) {
+        if (valid) store_rows3<128>(a.delta + off + p * W, d, half);
+    };
+
+    // ---- views_linears.0^T (feature columns): 128 -> 256
+    zero_acc();
+    {
+        const float* cur = ws.acquire();
+        if (valid) store_rows3<64>(a.delta + dl.hv + p * WV, dhv, half);
+        mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
+    }
+    mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.acquire(), lane);
+#pragma unroll
+    for (int i = 0; i < 128; ++i) d[i] = acc[i >> 4][i & 15];
+
+    // ---- feature_linear^T + alpha_linear^T, ReLU mask of layer 7
+    {
+        const float* wa = small_ptr(lds, SM_WALPHA);
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wa + 32 * ob + 8 * q4 + 4 * half);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ob][4 * q4 + r] = g[3] * w[r];
+            }
+    }
+    {
+        const float* cur = ws.acquire();
+        store_d(dl.feat);
+        mma3_chunk<8, 4, 0, 128>(acc, d, cur, lane);
+    }
+    mma3_chunk<8, 4, 32, 128>(acc, d, ws.acquire(), lane);
+    mma3_chunk<8, 4, 64, 128>(acc, d, ws.acquire(), lane);
+    mma3_chunk<8, 4, 96, 128>(acc, d, ws.acquire(), lane);
+    apply_mask3<128>(d, acc, msk[D - 1]);
+
+    // ---- trunk: delta_{l-1} = (W_l^T delta_l) * relu'(h_{l-1}),  l = 7 .. 1
+#pragma unroll 1
+    for (int l = D - 1; l >= 1; --l) {
+        zero_acc();
+        {
+            const float* cur = ws.acquire();
+            store_d((size_t)l * P * W);                                  // dl.h[l]
+            mma3_chunk<8, 4, 0, 128>(acc, d, cur, lane);
+        }
+        mma3_chunk<8, 4, 32, 128>(acc, d, ws.acquire(), lane);
+        mma3_chunk<8, 4, 64, 128>(acc, d, ws.acquire(), lane);
+        mma3_chunk<8, 4, 96, 128>(acc, d, ws.acquire(), lane);
+        u32x4 m = msk[0];
+#pragma unroll
+        for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];
+        apply_mask3<128>(d, acc, m);
+    }
+    store_d(0);                                                          // dl.h[0]
+}
+
+hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
+                               float* delta, hipStream_t stream) {
+    const long P = (long)n_rays * S;
+    if (P <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    FieldBwd3Args ba{packed3, act, d_raw, delta, n_rays, S};
+    const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
+    hipLaunchKernelGGL(field_dgrad3_kernel, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
+    return hipGetLastError();
+}
+
+}  // namespace nerf

@@ -4,14 +4,10 @@
 // One wave = 32 points, activations stay in VGPRs as fp32 and are split into (hi, lo) bf16 fragments
 // just in time for each k-step (the conversion VALU work hides under the 24 MFMAs of the previous k-step);
 // weights stream L2 -> LDS as pre-split (hi, lo) fragments.  256-thread workgroups, 1 wave / SIMD (~350 VGPRs).
-#include "field_device.h"
+#include "field_device_bf16.h"
 #include "launchers.h"
 
 namespace nerf {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct FieldFwd3Args {
     const float* packed3;   // PACKED3_WORDS
@@ -21,88 +17,6 @@ struct FieldFwd3Args {
     float* act;             // nullable
     int ray_stride, n_rays, S;
 };
-
-__device__ inline unsigned pack_bf16x2(float a, float b) {       // RNE, low half = a
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    const bf16x2 v = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, v);
-}
-// 8 fp32 values -> bf16 (hi, lo) B fragments
-__device__ inline void split8(const float* v, u32x4& hi, u32x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned h = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-        hi[i] = h;
-        lo[i] = pack_bf16x2(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
-    }
-}
-__device__ inline f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// one k-step for NB output blocks: acc[nb] += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi
-// kbase = LDS address of this k-step's fragments (u32x4 units), lane-linear: ((nb*2 + hl)*64 + lane)
-template <int NB>
-__device__ inline void mma3_kstep(f32x16 (&acc)[NB], const u32x4 bhi, const u32x4 blo, const u32x4* kbase) {
-#pragma unroll
-    for (int g = 0; g < NB; g += 4) {
-        u32x4 ahi[4], alo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { ahi[i] = kbase[((g + i) * 2) * 64]; alo[i] = kbase[((g + i) * 2 + 1) * 64]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[g + i] = mfma_bf16(ahi[i], bhi, acc[g + i]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[g + i] = mfma_bf16(ahi[i], blo, acc[g + i]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[g + i] = mfma_bf16(alo[i], bhi, acc[g + i]);
-    }
-}
-
-// KS k-steps whose B operands are v[VOFF + 8*s .. +7] (fp32, already activated)
-template <int NB, int KS, int VOFF, int NV>
-__device__ inline void mma3_chunk(f32x16 (&acc)[NB], const float (&v)[NV], const float* lbuf, int lane) {
-    const u32x4* a = reinterpret_cast<const u32x4*>(lbuf) + lane;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        u32x4 bhi, blo;
-        split8(&v[VOFF + 8 * s], bhi, blo);
-        mma3_kstep<NB>(acc, bhi, blo, a + s * (NB * 2 * 64));
-    }
-}
-
-template <int NB>
-__device__ inline void load_bias3(f32x16 (&acc)[NB], const float* bias, int half) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * nb + 8 * g + 4 * half);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[nb][4 * g + r] = b[r];
-        }
-}
-
-// lane value i (0..16*NB-1) = feature 32*(i>>4) + d32row(i&15, half): 4 consecutive features per float4
-template <int NV>
-__device__ inline void store_rows3(float* row, const float (&v)[NV], int half) {
-#pragma unroll
-    for (int ob = 0; ob < NV / 16; ++ob)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(row + 32 * ob + 8 * g + 4 * half) =
-                f32x4{v[16 * ob + 4 * g], v[16 * ob + 4 * g + 1], v[16 * ob + 4 * g + 2], v[16 * ob + 4 * g + 3]};
-}
-// ReLU sign bits of the lane's NV values -> act.mask[layer][p][half] (4 words; NV <= 128)
-template <int NV>
-__device__ inline void save_mask3(float* mask_base, int layer, size_t P, size_t p, int half, const float (&v)[NV]) {
-    unsigned w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int i = 0; i < NV; ++i) w[i >> 5] |= (v[i] > 0.0f ? 1u : 0u) << (i & 31);
-    u32x4* m = reinterpret_cast<u32x4*>(mask_base) + ((size_t)layer * P + p) * 2 + half;
-    *m = u32x4{w[0], w[1], w[2], w[3]};
-}
-
-__device__ inline float half_sum(float v) { return v + __shfl_xor(v, 32); }
 
 template <bool SAVE>
 __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3Args a) {

@@ -48,6 +48,8 @@ def _declare(lib):
         "nerf_pack_params_bf16x3": (i, [p, p, p]),
         "nerf_field_fwd_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_debug_pack3_table": (i, [p]),
+        "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, p]),
+        "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
@@ -60,7 +62,8 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_sample_coarse", "nerf_act_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
-           "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table"]
+           "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
+           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3"]
 
 
 def lib():
@@ -289,12 +292,20 @@ def sample_pdf(bins, weights, n_samples, u, u_lin):
     return out
 
 
-def field_bwd(packed, act, d_raw, grad, accumulate):
+def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32"):
     n, S, _ = d_raw.shape
     L = lib()
     dev = d_raw.device
     delta = torch.empty(L.nerf_delta_floats(n, S), dtype=torch.float32, device=dev)
     partial = torch.empty(L.nerf_wgrad_partial_floats(n, S), dtype=torch.float32, device=dev)
+    if precision == "bf16x3":
+        with _timed("field_dgrad3_kernel", FLOP_DGRAD_PER_POINT * n * S):
+            _check(L.nerf_field_dgrad_bf16x3(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
+                                             _ptr(delta), _stream()), "nerf_field_dgrad_bf16x3")
+        with _timed("wgrad3_kernel(+small fp32 jobs +reduce)", FLOP_WGRAD_PER_POINT * n * S):
+            _check(L.nerf_field_wgrad_bf16x3(_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial),
+                                             _ptr(grad, "grad"), int(bool(accumulate)), _stream()), "nerf_field_wgrad_bf16x3")
+        return grad
     with _timed("field_dgrad_kernel", FLOP_DGRAD_PER_POINT * n * S):
         _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
                                   _stream()), "nerf_field_dgrad")

@@ -50,11 +50,9 @@ class _FieldQuery(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, z_vals, need, *params):
         prec = _PRECISION
-        if need and prec != "fp32":
-            raise NotImplementedError(f"precision {prec!r}: backward not implemented yet; use set_precision('fp32') to train")
         packed = model.packed_params(prec)
         raw, act = hb.field_fwd(packed, rays, z_vals, save_act=need, precision=prec)
-        ctx.model, ctx.packed, ctx.act = model, packed, act
+        ctx.model, ctx.packed, ctx.act, ctx.prec = model, packed, act, prec
         ctx.set_materialize_grads(False)
         return raw
 
@@ -64,7 +62,7 @@ class _FieldQuery(torch.autograd.Function):
         if d_raw is None or ctx.act is None:
             return (None, None, None, None) + (None,) * len(_param_slices(model))
         grad = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=d_raw.device)
-        hb.field_bwd(ctx.packed, ctx.act, d_raw.contiguous(), grad, accumulate=False)
+        hb.field_bwd(ctx.packed, ctx.act, d_raw.contiguous(), grad, accumulate=False, precision=ctx.prec)
         ctx.act = None
         model.last_flat_grad = grad
         return (None, None, None, None) + _grad_views(model, grad)
@@ -91,8 +89,6 @@ class _RenderRays(torch.autograd.Function):
         std = cfg["raw_noise_std"]
         wb = cfg["white_bkgd"]
         prec = cfg.get("precision", "fp32")
-        if need and prec != "fp32":
-            raise NotImplementedError(f"precision {prec!r}: backward not implemented yet; use set_precision('fp32') to train")
         packed_c = model_c.packed_params(prec)
         z_c = hb.sample_coarse(rays, _linspace01(n_c, dev), cfg["lindisp"], rnd.get("t_rand"))
         raw_c, act_c = hb.field_fwd(packed_c, rays, z_c, save_act=need, precision=prec)
@@ -146,7 +142,7 @@ class _RenderRays(torch.autograd.Function):
             d_rgb, d_acc, d_disp = g
             d_raw = hb.raw2outputs_bwd(raw, z, rays, rays.shape[1], noise, std, wb, d_rgb, d_acc, d_disp,
                                        rays_d_offset=3)
-            hb.field_bwd(packed, act, d_raw, grad, accumulate)
+            hb.field_bwd(packed, act, d_raw, grad, accumulate, precision=cfg.get("precision", "fp32"))
 
         if cfg["N_importance"] <= 0:
             g = cgrads(gouts[0], gouts[1], gouts[2])
