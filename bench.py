@@ -62,6 +62,43 @@ def cpu_baseline(n_rays=512):
                       f"{os.cpu_count()} host CPUs)"}
 
 
+PEAK_HBM_GBS = 8000.0               # HBM3E spec (≈6.3 TB/s achievable, MI355X_MICROARCH.md)
+
+
+def kernel_table(kern, precision):
+    """per timed kernel: average launch time, algorithmic TFLOP/s and GB/s, and its fraction of both roofs"""
+    issued = 1.0 if precision == "fp32" else 3.0        # bf16x3 issues every algorithmic FLOP three times on the bf16 pipe
+    peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    out = {}
+    for k, v in kern.items():
+        sec = v["ms"] * 1e-3
+        fp32_kernel = precision == "fp32" or k.startswith(("wgrad_kernel", "wgrad_reduce"))
+        k_issued, k_peak = (1.0, PEAK_FP32_MFMA_TFLOPS) if fp32_kernel else (issued, peak)
+        tfl = v["flops"] / sec / 1e12
+        gbs = v["bytes"] / sec / 1e9
+        out[k] = {"launches": v["launches"], "avg_ms": v["ms"] / v["launches"], "total_ms": v["ms"],
+                  "algorithmic_tflops": tfl, "mfma_frac": tfl * k_issued / k_peak, "mfma_peak_tflops": k_peak,
+                  "mfma_flops_per_algorithmic_flop": k_issued,
+                  "algorithmic_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBS}
+    return out
+
+
+def roofline_of(table):
+    """roofline object of the dominant kernel (largest share of the timed region), bound = the roof it sits closer to"""
+    if not table:
+        return None
+    name, k = max(table.items(), key=lambda kv: kv[1]["total_ms"])
+    if k["hbm_frac"] > k["mfma_frac"]:
+        return {"bound": "hbm", "kernel": name, "achieved": k["algorithmic_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": k["hbm_frac"], "traffic": None, "avg_launch_ms": k["avg_ms"],
+                "also": {"mfma_frac": k["mfma_frac"], "algorithmic_tflops": k["algorithmic_tflops"]}}
+    return {"bound": "mfma", "kernel": name, "achieved": k["algorithmic_tflops"] * k["mfma_flops_per_algorithmic_flop"],
+            "peak": k["mfma_peak_tflops"], "unit": "TFLOP/s", "frac": k["mfma_frac"], "traffic": None,
+            "algorithmic_tflops": k["algorithmic_tflops"],
+            "mfma_flops_per_algorithmic_flop": k["mfma_flops_per_algorithmic_flop"], "avg_launch_ms": k["avg_ms"],
+            "also": {"hbm_frac": k["hbm_frac"], "algorithmic_GBps": k["algorithmic_GBps"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,8 +107,11 @@ def main():
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--rays", type=int, default=N_RAND, help="rays per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=os.environ.get("NERF_BENCH_PRECISION", "fp32"),
-                    help="field datapath: exact fp32 MFMA or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=os.environ.get("NERF_BENCH_PRECISION", "bf16x3"),
+                    help="headline field datapath: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate; PSNR delta vs the "
+                         "reference 2e-5 dB, tests/test_gpu_parity.py) or exact fp32 MFMA (the parity anchor). The other "
+                         "datapath is measured too (fewer steps) and reported in the same JSON line.")
+    ap.add_argument("--single-datapath", action="store_true", help="skip the secondary datapath measurement")
     args = ap.parse_args()
 
     import nerf_oracle as orc
@@ -120,24 +160,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    timer = npa.hip_backend.KernelTimer()
-    npa.hip_backend.TIMER = timer
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    npa.hip_backend.TIMER = None
-    kern = timer.summary()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(precision, steps, warmup):
+        npa.set_precision(precision)
+        for i in range(warmup):
+            step(i)
+        timer = npa.hip_backend.KernelTimer()
+        npa.hip_backend.TIMER = timer
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        barrier()
+        el = time.perf_counter() - t0
+        npa.hip_backend.TIMER = None
+        kern = timer.summary()
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, kern
 
-    # secondary number: inference rays/s on the same batch shape (not the headline)
+    elapsed, kern = measure(args.precision, args.steps, args.warmup)
+
+    # secondary numbers (not the headline): inference on the same batch shape, and the other datapath
     other = None
     if args.mode == "train":
         for i in range(2):
@@ -148,26 +193,28 @@ def main():
             infer_step(i)
         barrier()
         other = n * world * max(5, args.steps // 2) / (time.perf_counter() - t1)
+    second = None
+    if not args.single_datapath:
+        p2 = "fp32" if args.precision == "bf16x3" else "bf16x3"
+        k2 = max(4, args.steps // 4)
+        el2, kern2 = measure(p2, k2, 2)
+        tab2 = kernel_table(kern2, p2)
+        second = {"dtype": "f32" if p2 == "fp32" else "bf16x3", "value": n * world * k2 / el2, "unit": "rays/s",
+                  "steps": k2, "ms_per_step": 1e3 * el2 / k2, "roofline": roofline_of(tab2),
+                  "kernels": {k: {"avg_ms": v["avg_ms"], "mfma_frac": v["mfma_frac"], "hbm_frac": v["hbm_frac"]}
+                              for k, v in tab2.items()}}
+        npa.set_precision(args.precision)
 
     if rank == 0:
         total_rays = n * world * args.steps
         value = total_rays / elapsed
         flop_per_ray = FLOP_TRAIN_PER_RAY if args.mode == "train" else FLOP_FWD_PER_RAY
-        dom_name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"]) if kern else (None, None)
-        kernels = {k: {"launches": v["launches"], "avg_ms": v["ms"] / v["launches"],
-                       "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in kern.items()}
-        roofline = None
-        if dom is not None:
-            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            if args.precision == "fp32":
-                peak, issued = PEAK_FP32_MFMA_TFLOPS, 1.0
-            else:       # every algorithmic FLOP is issued three times on the bf16 pipe
-                peak, issued = PEAK_BF16_MFMA_TFLOPS, 3.0
-            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": ach * issued, "peak": peak,
-                        "unit": "TFLOP/s", "frac": ach * issued / peak, "traffic": None,
-                        "algorithmic_tflops": ach, "mfma_flops_per_algorithmic_flop": issued,
-                        "avg_launch_ms": dom["ms"] / dom["launches"],
-                        "whole_step_frac": value * flop_per_ray * issued / world / 1e12 / peak}
+        kernels = kernel_table(kern, args.precision)
+        roofline = roofline_of(kernels)
+        if roofline is not None:
+            issued = 1.0 if args.precision == "fp32" else 3.0
+            peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            roofline["whole_step_mfma_frac"] = value * flop_per_ray * issued / world / 1e12 / peak
         line = {
             "metric": "rays/sec (coarse+fine, 64+128 samples), training step" if args.mode == "train"
                       else "rays/sec (coarse+fine, 64+128 samples), inference",
@@ -186,6 +233,8 @@ def main():
         }
         if other is not None:
             line["inference_rays_per_s"] = other
+        if second is not None:
+            line["other_datapath"] = second
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

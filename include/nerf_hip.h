@@ -123,6 +123,11 @@ int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float*
                             float* delta, void* stream);
 int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                             float* partial, float* grad, int accumulate, void* stream);
+/* nerf_field_wgrad / nerf_field_wgrad_bf16x3 split into their three launches so that a profiler can bracket each:
+ * phases bit 0 = the eight full-width (256x256) jobs, bit 1 = the six narrow jobs, bit 2 = reduction of the per-chunk
+ * partial gradients into grad.  Calling it with phases 1, 2, 4 in that order equals one call with 7. */
+int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
+                           float* partial, float* grad, int accumulate, int bf16x3, int phases, void* stream);
 /* test hook (host only): out_host[e] for every 16-bit element e of the weight streams (2 * stream words):
  * 2 * canonical_index + is_low_part, or -1 for zero padding. */
 int nerf_debug_pack3_table(int* out_host);

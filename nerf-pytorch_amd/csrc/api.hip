@@ -165,8 +165,16 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
                      float* partial, float* grad, int accumulate, void* stream) {
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 0,
+    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 0, 7,
                                                    (hipStream_t)stream));
+}
+
+int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
+                           float* partial, float* grad, int accumulate, int bf16x3, int phases, void* stream) {
+    REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7, "bad size");
+    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate,
+                                                   bf16x3 ? 1 : 0, phases, (hipStream_t)stream));
 }
 
 int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
@@ -183,7 +191,7 @@ int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d
                             float* partial, float* grad, int accumulate, void* stream) {
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 1,
+    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 1, 7,
                                                    (hipStream_t)stream));
 }
 

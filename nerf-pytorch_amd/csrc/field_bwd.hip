@@ -236,19 +236,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     swrite(0);
     __syncthreads();
     const int c = lane & 15, pp = lane >> 4;
+    // narrow jobs (63 / 27 / 3 / 1 valid columns): a wave whose whole 64-wide n- or k-range is zero padding only helps
+    // with staging and leaves the MFMA pipe to the other workgroup resident on this CU
+    const bool wave_has_work = (wave_n * 64 < nA) && (wave_k * 64 < nB);
     for (int st = 0; st < n_stages; ++st) {
         const int buf = st & 1;
         if (st + 1 < n_stages) gload(st + 1);
+        if (wave_has_work) {
 #pragma unroll
-        for (int ps = 0; ps < WG_STAGE / 4; ++ps) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(&sA[buf][4 * ps + pp][wave_n * 64 + 4 * c]);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(&sB[buf][4 * ps + pp][wave_k * 64 + 4 * c]);
-            bsum += av;
+            for (int ps = 0; ps < WG_STAGE / 4; ++ps) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(&sA[buf][4 * ps + pp][wave_n * 64 + 4 * c]);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(&sB[buf][4 * ps + pp][wave_k * 64 + 4 * c]);
+                bsum += av;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
         }
         if (st + 1 < n_stages) swrite(buf ^ 1);
         __syncthreads();
@@ -396,20 +401,41 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
     const long p_begin = (long)chunk * a.chunk_pts;
     const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
     const int n_stages = (int)((p_end - p_begin + WG_STAGE - 1) / WG_STAGE);
-    // staging role: operand 0 = delta (A), 1 = input (B); one feature column per thread
-    const int sop = tid >> 8, sf = tid & 255;
-    const float* sbase = (sop == 0 ? jb.A : jb.B) + sf;
+    // staging role: operand 0 = delta (A), 1 = input (B); one feature column per thread.  Narrow jobs (63 / 27 / 3 / 1
+    // valid columns) run through the same tile: threads beyond the operand's width stage zeros and issue no loads, so
+    // padding costs no HBM bytes (the kernel is HBM-bound, idle MFMA blocks are free).
+    const int sop = __builtin_amdgcn_readfirstlane(tid >> 8);      // waves 0-3 stage A, waves 4-7 stage B (wave-uniform)
+    const int sf = tid & 255;
+    const int swidth = sop == 0 ? jb.nA : jb.nB;
+    const bool sactive = sf < swidth;
     const int sld = sop == 0 ? jb.lda : jb.ldb;
+    // scalar base of this workgroup's chunk + 32-bit per-lane offsets: one v_add per load instead of 64-bit address math
+    const char* cbase = reinterpret_cast<const char*>((sop == 0 ? jb.A : jb.B) + p_begin * (long)sld);
+    const unsigned soff = 4u * (unsigned)min(sf, swidth - 1);          // byte offset of the (clamped, always valid) column
+    const unsigned sldb = 4u * (unsigned)sld;                          // row pitch in bytes; a chunk spans < 4 GiB
+    const int nrows = (int)(p_end - p_begin);
     float rv[WG_STAGE];
     float colsum = 0.0f;
-    auto gload = [&](int st) {
-        const long r0 = p_begin + (long)st * WG_STAGE;
+    // 32 independent, unconditional loads per stage (zeros are selected afterwards): no control flow between the
+    // loads, they all stay in flight together; only the last stage of the last chunk needs row clamping
+    auto gload_into = [&](float (&dst)[WG_STAGE], int st) {
+        const int q0 = st * WG_STAGE;
+        float v[WG_STAGE];
+        if (q0 + WG_STAGE <= nrows) {
+            unsigned off = soff + (unsigned)q0 * sldb;
 #pragma unroll
-        for (int q = 0; q < WG_STAGE; ++q) {
-            const long r = r0 + q;
-            rv[q] = r < p_end ? sbase[r * sld] : 0.0f;
+            for (int q = 0; q < WG_STAGE; ++q) { v[q] = *reinterpret_cast<const float*>(cbase + off); off += sldb; }
+#pragma unroll
+            for (int q = 0; q < WG_STAGE; ++q) dst[q] = sactive ? v[q] : 0.0f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < WG_STAGE; ++q)
+                v[q] = *reinterpret_cast<const float*>(cbase + (soff + (unsigned)min(q0 + q, nrows - 1) * sldb));
+#pragma unroll
+            for (int q = 0; q < WG_STAGE; ++q) dst[q] = (sactive && q0 + q < nrows) ? v[q] : 0.0f;
         }
     };
+    auto gload = [&](int st) { gload_into(rv, st); };
     auto swrite = [&](int buf) {
         unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + sf * WG3_FEAT_BYTES;
 #pragma unroll
@@ -419,8 +445,10 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
             *reinterpret_cast<u32x4*>(dst + 16 * gq) = hi;
             *reinterpret_cast<u32x4*>(dst + 64 + 16 * gq) = lo;
         }
+        if (sop == 0) {
 #pragma unroll
-        for (int q = 0; q < WG_STAGE; ++q) colsum += rv[q];
+            for (int q = 0; q < WG_STAGE; ++q) colsum += rv[q];
+        }
     };
     f32x16 acc[4][2];
 #pragma unroll
@@ -429,15 +457,14 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    gload(0);
-    swrite(0);
-    __syncthreads();
     const int row = lane & 31, hf = lane >> 5;
-    for (int st = 0; st < n_stages; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < n_stages) gload(st + 1);
+    const int ni = min(4, (jb.nA - wave_n * 128 + 31) / 32);     // 32-row output blocks of this wave that hold real rows
+    const int nj = min(2, (jb.nB - wave_k * 64 + 31) / 32);
+    const bool wave_has_work = ni > 0 && nj > 0;
+    auto compute = [&](int buf) {
         const unsigned char* sa = sm3 + (buf * 2) * WG3_OPERAND_BYTES + (wave_n * 128 + row) * WG3_FEAT_BYTES + 16 * hf;
         const unsigned char* sb = sm3 + (buf * 2 + 1) * WG3_OPERAND_BYTES + (wave_k * 64 + row) * WG3_FEAT_BYTES + 16 * hf;
+        if (wave_has_work)
 #pragma unroll
         for (int t = 0; t < WG_STAGE / 16; ++t) {
             u32x4 bhi[2], blo[2];
@@ -448,6 +475,7 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (i >= ni) break;
                 const u32x4 ahi = *reinterpret_cast<const u32x4*>(sa + i * 32 * WG3_FEAT_BYTES + 32 * t);
                 const u32x4 alo = *reinterpret_cast<const u32x4*>(sa + i * 32 * WG3_FEAT_BYTES + 64 + 32 * t);
 #pragma unroll
@@ -458,7 +486,40 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(alo, bhi[j], acc[i][j]);
             }
         }
-        if (st + 1 < n_stages) swrite(buf ^ 1);
+    };
+    // Two stages of operands in flight in registers (rv, rw): the loads issued in iteration st are consumed in
+    // iteration st+1's write-back, i.e. they have a full compute phase plus a barrier to land (the kernel is
+    // load-latency bound with a single stage in flight).
+    float rw[WG_STAGE];
+    auto gload2 = [&](int st) { gload_into(rw, st); };
+    auto swrite2 = [&](int buf) {
+        unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + sf * WG3_FEAT_BYTES;
+#pragma unroll
+        for (int gq = 0; gq < WG_STAGE / 8; ++gq) {
+            u32x4 hi, lo;
+            split8(&rw[8 * gq], hi, lo);
+            *reinterpret_cast<u32x4*>(dst + 16 * gq) = hi;
+            *reinterpret_cast<u32x4*>(dst + 64 + 16 * gq) = lo;
+        }
+        if (sop == 0) {
+#pragma unroll
+            for (int q = 0; q < WG_STAGE; ++q) colsum += rw[q];
+        }
+    };
+    gload(0);
+    swrite(0);
+    if (n_stages > 1) gload(1);
+    __syncthreads();
+    // invariant at the top of iteration st (even): LDS buf 0 holds stage st, rv holds stage st+1
+    for (int st = 0; st < n_stages; st += 2) {
+        if (st + 2 < n_stages) gload2(st + 2);          // -> rw
+        compute(0);
+        if (st + 1 < n_stages) swrite(1);               // rv (stage st+1) -> buf 1
+        __syncthreads();
+        if (st + 1 >= n_stages) break;
+        if (st + 3 < n_stages) gload(st + 3);           // -> rv
+        compute(1);
+        if (st + 2 < n_stages) swrite2(0);              // rw (stage st+2) -> buf 0
         __syncthreads();
     }
     // acc[i][j][r] at lane (col = lane&31, hf) = dW[wave_n*128 + 32*i + d32row(r, hf)][wave_k*64 + 32*j + col]
@@ -468,11 +529,16 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = wave_n * 128 + 32 * i + d32row(r, hf);
-            float* orow = out + jb.c_off + (size_t)n * jb.ldc + wave_k * 64 + row;
+            if (n < jb.nA) {
+                float* orow = out + jb.c_off + (size_t)n * jb.ldc;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) orow[32 * j] = acc[i][j][r];
+                for (int j = 0; j < 2; ++j) {
+                    const int k = wave_k * 64 + 32 * j + row;
+                    if (k < jb.nB) orow[k] = acc[i][j][r];
+                }
+            }
         }
-    if (jb.bias_off >= 0 && sop == 0) out[jb.bias_off + sf] = colsum;
+    if (jb.bias_off >= 0 && sop == 0 && sactive) out[jb.bias_off + sf] = colsum;
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate) {
@@ -518,14 +584,29 @@ hipError_t launch_field_dgrad(const float* packed, const float* act, const float
     return hipGetLastError();
 }
 
+// per-ray view-direction encoding [N][32] -> per point [P][32] (float4 per thread)
+__global__ void expand_dir_kernel(const f32x4* __restrict__ dir_ray, f32x4* __restrict__ dir_pt, long P, int S) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * 8) return;
+    const long p = i >> 3;
+    dir_pt[i] = dir_ray[(p / S) * 8 + (i & 7)];
+}
+
+// phases: bit 0 = full-width jobs, bit 1 = narrow jobs, bit 2 = chunk reduction (7 = everything)
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
-                              float* partial, float* grad, int accumulate, int bf16x3, hipStream_t stream) {
+                              float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream) {
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     hipError_t e;
     const ActLayout al = act_layout((size_t)P, (size_t)n_rays);
     const DeltaLayout dl = delta_layout((size_t)P);
     constexpr Canon cn = canon();
+    if (phases & 1) {       // act is written by the forward; the expanded copy is scratch inside the same buffer
+        hipLaunchKernelGGL(expand_dir_kernel, dim3((unsigned)((P * 8 + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const f32x4*>(act + al.dir), reinterpret_cast<f32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     WgradArgs wa{};
     int nj = 0, tiles = 0;
     auto add = [&](const float* A, int lda, int nA, const float* B, int ldb, int nB, int rowdiv, int c_off, int ldc, int bias_off) {
@@ -553,7 +634,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     add(delta + dl.feat, W, W, act + al.h[D - 1], W, W, 1, cn.wf, W, cn.bf);
     add(d_raw + 3, 4, 1, act + al.h[D - 1], W, W, 1, cn.wa, W, cn.ba);
     add(delta + dl.hv, WV, WV, act + al.feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
-    add(delta + dl.hv, WV, WV, act + al.dir, 32, IN_DIR, S, cn.wv + W, W + IN_DIR, -1);
+    add(delta + dl.hv, WV, WV, act + al.dir_pt, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
     add(d_raw, 4, 3, act + al.hv, WV, WV, 1, cn.wr, WV, cn.br);
     if (nj != WG_MAX_JOBS) return hipErrorInvalidValue;
     // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
@@ -561,11 +642,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     int small_tiles = 0;
     for (int j = 0; j < nj; ++j) {
         const WgradJob& src = wa.job[j];
-#ifdef NERF_NO_WGRAD256
-        if (false) {
-#else
-        if (src.nA == 256 && src.nB == 256 && src.vecA && src.vecB && src.b_rowdiv == 1) {
-#endif
+        if (bf16x3 || (src.nA == 256 && src.nB == 256 && src.vecA && src.vecB && src.b_rowdiv == 1)) {
             big.job[big.n_jobs++] = src;
         } else {
             WgradJob& dst = small.job[small.n_jobs++];
@@ -593,22 +670,23 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         if (e != hipSuccess) return e;
         attr3_set = true;
     }
-    if (big.n_jobs > 0 && bf16x3) {
+    if (big.n_jobs > 0 && bf16x3 && (phases & 1)) {
         hipLaunchKernelGGL(wgrad3_256_kernel, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG3_LDS_BYTES, stream, big);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-    } else if (big.n_jobs > 0) {
+    } else if (big.n_jobs > 0 && (phases & 1)) {
         hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG256_LDS_FLOATS * 4, stream, big);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (small.n_jobs > 0) {
+    if (small.n_jobs > 0 && (phases & 2)) {
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(small_tiles * n_chunks)), dim3(256), 0, stream, small);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, stream,
-                       (const float*)partial, n_chunks, grad, accumulate);
+    if (phases & 4)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, stream,
+                           (const float*)partial, n_chunks, grad, accumulate);
     return hipGetLastError();
 }
 
@@ -616,7 +694,7 @@ hipError_t launch_field_bwd(const float* packed, const float* act, const float* 
                             float* delta, float* partial, float* grad, int accumulate, hipStream_t stream) {
     hipError_t e = launch_field_dgrad(packed, act, d_raw, n_rays, S, delta, stream);
     if (e != hipSuccess) return e;
-    return launch_field_wgrad(act, delta, d_raw, n_rays, S, partial, grad, accumulate, 0, stream);
+    return launch_field_wgrad(act, delta, d_raw, n_rays, S, partial, grad, accumulate, 0, 7, stream);
 }
 
 }  // namespace nerf

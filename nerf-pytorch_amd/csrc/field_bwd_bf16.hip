@@ -2,6 +2,7 @@
 // structure as field_fwd_bf16.hip with the transposed (hi, lo) weight stream) and the weight-gradient GEMM
 // wgrad3_kernel: dW = delta^T * X with both operands split on the fly into (hi, lo) bf16 while they are staged
 // into LDS (3 bf16 MFMAs per product, fp32 accumulate), contraction over points.
+#include <type_traits>
 #include "field_device_bf16.h"
 #include "launchers.h"
 
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     const size_t p = valid ? p_raw : P - 1;
 
     WeightStreamT<3, FIELD3_WAVES> ws;
-    ws.start(a.packed3 + P3B_VIEWS, lds, wave, lane);
+    ws.start(a.packed3 + P3B_VIEWS, lds, wave, lane, valid);
     stage_small_from(a.packed3 + P3_SMALL, lds, FIELD3_WAVES * 64);
 
     const ActLayout al = act_layout(P, (size_t)a.n_rays);
@@ -78,18 +79,22 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
     };
-    auto store_d = [&](size_t off) {
-        if (valid) store_rows3<128>(a.delta + off + p * W, d, half);
+    // every delta is written while the NEXT contraction runs, a quarter (8 stores) after each chunk acquire;
+    // the following acquire<8> keeps those stores in flight (counted vmcnt, see WeightStreamT::acquire)
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+    auto store_q = [&](auto part, size_t off) {
+        if (valid) store_rows3_part<decltype(part)::value>(a.delta + off + p * W, d, half);
     };
 
     // ---- views_linears.0^T (feature columns): 128 -> 256
     zero_acc();
     {
         const float* cur = ws.acquire();
-        if (valid) store_rows3<64>(a.delta + dl.hv + p * WV, dhv, half);
+        if (valid) store_rows3<64>(a.delta + dl.hv + p * WV, dhv, half);         // 16 stores
         mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
     }
-    mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.acquire(), lane);
+    mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<16>(), lane);
 #pragma unroll
     for (int i = 0; i < 128; ++i) d[i] = acc[i >> 4][i & 15];
 
@@ -107,32 +112,43 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     }
     {
         const float* cur = ws.acquire();
-        store_d(dl.feat);
+        store_q(Q0{}, dl.feat);
         mma3_chunk<8, 4, 0, 128>(acc, d, cur, lane);
+        cur = ws.template acquire<8>();
+        store_q(Q1{}, dl.feat);
+        mma3_chunk<8, 4, 32, 128>(acc, d, cur, lane);
+        cur = ws.template acquire<8>();
+        store_q(Q2{}, dl.feat);
+        mma3_chunk<8, 4, 64, 128>(acc, d, cur, lane);
+        cur = ws.template acquire<8>();
+        store_q(Q3{}, dl.feat);
+        mma3_chunk<8, 4, 96, 128>(acc, d, cur, lane);
     }
-    mma3_chunk<8, 4, 32, 128>(acc, d, ws.acquire(), lane);
-    mma3_chunk<8, 4, 64, 128>(acc, d, ws.acquire(), lane);
-    mma3_chunk<8, 4, 96, 128>(acc, d, ws.acquire(), lane);
     apply_mask3<128>(d, acc, msk[D - 1]);
 
     // ---- trunk: delta_{l-1} = (W_l^T delta_l) * relu'(h_{l-1}),  l = 7 .. 1
 #pragma unroll 1
     for (int l = D - 1; l >= 1; --l) {
         zero_acc();
-        {
-            const float* cur = ws.acquire();
-            store_d((size_t)l * P * W);                                  // dl.h[l]
-            mma3_chunk<8, 4, 0, 128>(acc, d, cur, lane);
-        }
-        mma3_chunk<8, 4, 32, 128>(acc, d, ws.acquire(), lane);
-        mma3_chunk<8, 4, 64, 128>(acc, d, ws.acquire(), lane);
-        mma3_chunk<8, 4, 96, 128>(acc, d, ws.acquire(), lane);
+        const size_t off = (size_t)l * P * W;                              // dl.h[l]: delta of layer l = input of this step
+        const float* cur = ws.acquire();
+        store_q(Q0{}, off);
+        mma3_chunk<8, 4, 0, 128>(acc, d, cur, lane);
+        cur = ws.template acquire<8>();
+        store_q(Q1{}, off);
+        mma3_chunk<8, 4, 32, 128>(acc, d, cur, lane);
+        cur = ws.template acquire<8>();
+        store_q(Q2{}, off);
+        mma3_chunk<8, 4, 64, 128>(acc, d, cur, lane);
+        cur = ws.template acquire<8>();
+        store_q(Q3{}, off);
+        mma3_chunk<8, 4, 96, 128>(acc, d, cur, lane);
         u32x4 m = msk[0];
 #pragma unroll
         for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];
         apply_mask3<128>(d, acc, m);
     }
-    store_d(0);                                                          // dl.h[0]
+    if (valid) store_rows3<128>(a.delta + p * W, d, half);                // dl.h[0]
 }
 
 hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,

@@ -81,14 +81,22 @@ struct WeightStreamT {
     const float* next_src;
     float* lds;
     int wave, lane, c;
-    __device__ inline void start(const float* src, float* lds_, int wave_, int lane_) {
+    bool counted;       // wave-uniform: every lane of this wave issues the stores acquire<N> accounts for
+    __device__ inline void start(const float* src, float* lds_, int wave_, int lane_, bool all_lanes_store = false) {
         lds = lds_; wave = wave_; lane = lane_; c = 0;
+        counted = __builtin_amdgcn_readfirstlane((int)__all(all_lanes_store)) != 0;
         const int nf = stream_chunk_words<MODE>(0);
         dma_chunk<NWAVES>(src, lds, nf, wave, lane);
         next_src = src + nf;
     }
+    // NPEND = number of vector-memory instructions (activation stores) this wave issued AFTER the DMA of the
+    // chunk being acquired: vmcnt retires in order, so waiting for "at most NPEND outstanding" guarantees the DMA
+    // has landed while those stores keep draining under the next chunk's MFMAs.  Must never exceed the real count.
+    template <int NPEND = 0>
     __device__ inline const float* acquire() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // a wave with no (or predicated-off) stores has fewer entries in flight than NPEND: it must drain fully
+        if (NPEND > 0 && counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPEND) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float* cur = lds + (c & 1) * CHUNK_FLOATS;
         const int nf = stream_chunk_words<MODE>(c + 1);

@@ -78,6 +78,16 @@ __device__ inline void store_rows3(float* row, const float (&v)[NV], int half) {
             *reinterpret_cast<f32x4*>(row + 32 * ob + 8 * g + 4 * half) =
                 f32x4{v[16 * ob + 4 * g], v[16 * ob + 4 * g + 1], v[16 * ob + 4 * g + 2], v[16 * ob + 4 * g + 3]};
 }
+// quarter PART (0..3) of store_rows3<128>: blocks 2*PART, 2*PART+1  (8 store instructions)
+template <int PART>
+__device__ inline void store_rows3_part(float* row, const float (&v)[128], int half) {
+#pragma unroll
+    for (int ob = 2 * PART; ob < 2 * PART + 2; ++ob)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(row + 32 * ob + 8 * g + 4 * half) =
+                f32x4{v[16 * ob + 4 * g], v[16 * ob + 4 * g + 1], v[16 * ob + 4 * g + 2], v[16 * ob + 4 * g + 3]};
+}
 // ReLU sign bits of the lane's NV values -> act.mask[layer][p][half] (4 words; NV <= 128)
 template <int NV>
 __device__ inline void save_mask3(float* mask_base, int layer, size_t P, size_t p, int half, const float (&v)[NV]) {

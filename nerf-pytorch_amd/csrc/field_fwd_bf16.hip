@@ -4,6 +4,7 @@
 // One wave = 32 points, activations stay in VGPRs as fp32 and are split into (hi, lo) bf16 fragments
 // just in time for each k-step (the conversion VALU work hides under the 24 MFMAs of the previous k-step);
 // weights stream L2 -> LDS as pre-split (hi, lo) fragments.  256-thread workgroups, 1 wave / SIMD (~350 VGPRs).
+#include <type_traits>
 #include "field_device_bf16.h"
 #include "launchers.h"
 
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
     const int ray = (int)(p / a.S);
 
     WeightStreamT<2, FIELD3_WAVES> ws;
-    ws.start(a.packed3, lds, wave, lane);
+    ws.start(a.packed3, lds, wave, lane, SAVE && valid);
     stage_small_from(a.packed3 + P3_SMALL, lds, FIELD3_WAVES * 64);
 
     const float* rp = a.rays + (long)ray * a.ray_stride;
@@ -78,12 +79,17 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[16 * nb + r] = relu ? fmaxf(acc[nb][r], 0.0f) : acc[nb][r];
     };
-    auto save_trunk = [&](int layer) {
+    // Saved rows of layer L are written while layer L+1 computes, a quarter (8 stores) after each of its 4 chunk
+    // acquires; the following acquire waits with a counted vmcnt so these stores stay in flight (acquire<N>).
+    constexpr int NQ = SAVE ? 8 : 0;            // stores per quarter
+    auto save_quarter = [&](auto part, size_t base_off, bool with_mask, int layer) {
         if (SAVE && valid) {
-            store_rows3<128>(a.act + (size_t)layer * (size_t)P * W + (size_t)p * W, h, half);
-            save_mask3<128>(a.act + al.mask, layer, (size_t)P, (size_t)p, half, h);
+            store_rows3_part<decltype(part)::value>(a.act + base_off + (size_t)p * W, h, half);
+            if (with_mask) save_mask3<128>(a.act + al.mask, layer, (size_t)P, (size_t)p, half, h);
         }
     };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
 
     // ---- layer 0
     load_bias3<8>(acc, bias, half);
@@ -94,13 +100,20 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
 #pragma unroll 1
     for (int l = 1; l < D; ++l) {
         load_bias3<8>(acc, bias + l * W, half);
+        const size_t prev_off = (size_t)(l - 1) * (size_t)P * W;          // al.h[l-1]
         const float* cur = ws.acquire();
-        save_trunk(l - 1);
         if (l == SKIP + 1) { mma3_chunk<8, 4, 0, 32>(acc, e, cur, lane); cur = ws.acquire(); }
+        save_quarter(Q0{}, prev_off, true, l - 1);                         // 8 rows + 1 mask store
         mma3_chunk<8, 4, 0, 128>(acc, h, cur, lane);
-        mma3_chunk<8, 4, 32, 128>(acc, h, ws.acquire(), lane);
-        mma3_chunk<8, 4, 64, 128>(acc, h, ws.acquire(), lane);
-        mma3_chunk<8, 4, 96, 128>(acc, h, ws.acquire(), lane);
+        cur = ws.template acquire<SAVE ? 9 : 0>();
+        save_quarter(Q1{}, prev_off, false, 0);
+        mma3_chunk<8, 4, 32, 128>(acc, h, cur, lane);
+        cur = ws.template acquire<NQ>();
+        save_quarter(Q2{}, prev_off, false, 0);
+        mma3_chunk<8, 4, 64, 128>(acc, h, cur, lane);
+        cur = ws.template acquire<NQ>();
+        save_quarter(Q3{}, prev_off, false, 0);
+        mma3_chunk<8, 4, 96, 128>(acc, h, cur, lane);
         take(true);
     }
 
@@ -119,16 +132,23 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
         sigma = half_sum(sigma) + small_ptr(lds, SM_BALPHA)[0];
     }
 
-    // ---- feature_linear (no activation)
+    // ---- feature_linear (no activation); layer 7's rows are written meanwhile
     load_bias3<8>(acc, small_ptr(lds, SM_BFEAT), half);
     {
+        const size_t prev_off = (size_t)(D - 1) * (size_t)P * W;
         const float* cur = ws.acquire();
-        save_trunk(D - 1);
+        save_quarter(Q0{}, prev_off, true, D - 1);
         mma3_chunk<8, 4, 0, 128>(acc, h, cur, lane);
+        cur = ws.template acquire<SAVE ? 9 : 0>();
+        save_quarter(Q1{}, prev_off, false, 0);
+        mma3_chunk<8, 4, 32, 128>(acc, h, cur, lane);
+        cur = ws.template acquire<NQ>();
+        save_quarter(Q2{}, prev_off, false, 0);
+        mma3_chunk<8, 4, 64, 128>(acc, h, cur, lane);
+        cur = ws.template acquire<NQ>();
+        save_quarter(Q3{}, prev_off, false, 0);
+        mma3_chunk<8, 4, 96, 128>(acc, h, cur, lane);
     }
-    mma3_chunk<8, 4, 32, 128>(acc, h, ws.acquire(), lane);
-    mma3_chunk<8, 4, 64, 128>(acc, h, ws.acquire(), lane);
-    mma3_chunk<8, 4, 96, 128>(acc, h, ws.acquire(), lane);
     take(false);
 
     // ---- view branch: [feature, enc(dir)] -> 128, ReLU
@@ -158,12 +178,16 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
     f32x16 av[4];
     load_bias3<4>(av, small_ptr(lds, SM_BVIEWS), half);
     {
-        const float* cur = ws.acquire();
-        if (SAVE && valid) store_rows3<128>(a.act + al.feat + (size_t)p * W, h, half);
+        const float* cur = ws.template acquire<NQ>();                      // quarter 3 of layer 7 is still draining
+        save_quarter(Q0{}, al.feat, false, 0);
+        save_quarter(Q1{}, al.feat, false, 0);
         mma3_chunk<4, 8, 0, 128>(av, h, cur, lane);
+        cur = ws.template acquire<2 * NQ>();
+        save_quarter(Q2{}, al.feat, false, 0);
+        save_quarter(Q3{}, al.feat, false, 0);
+        mma3_chunk<4, 8, 64, 128>(av, h, cur, lane);
+        mma3_chunk<4, 2, 0, 16>(av, dv, ws.template acquire<2 * NQ>(), lane);
     }
-    mma3_chunk<4, 8, 64, 128>(av, h, ws.acquire(), lane);
-    mma3_chunk<4, 2, 0, 16>(av, dv, ws.acquire(), lane);
     float hv[64];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)

@@ -116,7 +116,9 @@ struct ActLayout {
     size_t feat;        // [P][256]
     size_t hv;          // [P][128] post-ReLU view-branch activations
     size_t enc;         // [P][64]  xyz encoding, canonical column order (col 63 = 0)
-    size_t dir;         // [N][32]  dir encoding, canonical column order (cols 27..31 unused)
+    size_t dir;         // [N][32]  dir encoding per ray (written by the forward), canonical column order
+    size_t dir_pt;      // [P][32]  the same, expanded per point right before the weight-gradient GEMM so that
+                        //          every operand is point-indexed (cols 27..31 unused)
     size_t mask;        // [9][P][4] uint64 ReLU sign bits in D-layout (bit 4*nb+r of lane quarter q); 9th = view branch
     size_t total;       // floats
 };
@@ -128,6 +130,7 @@ __host__ __device__ inline ActLayout act_layout(size_t P, size_t N) {
     a.hv = o;   o += P * WV;
     a.enc = o;  o += P * 64;
     a.dir = o;  o += N * 32;
+    a.dir_pt = o; o += P * 32;
     o = (o + 3) & ~(size_t)3;
     a.mask = o; o += (size_t)(D + 1) * P * 8;
     a.total = o;

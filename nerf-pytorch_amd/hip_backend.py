@@ -50,6 +50,7 @@ def _declare(lib):
         "nerf_debug_pack3_table": (i, [p]),
         "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p]),
+        "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
@@ -63,7 +64,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
-           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3"]
+           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase"]
 
 
 def lib():
@@ -107,16 +108,17 @@ class KernelTimer:
     current stream, which is the stream the kernels are enqueued on.  `work` = algorithmic FLOPs."""
 
     def __init__(self):
-        self.records = []       # (name, start_event, end_event, flops)
+        self.records = []       # (name, start_event, end_event, algorithmic flops, algorithmic HBM bytes)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, e0, e1, fl in self.records:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for name, e0, e1, fl, by in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
+            d["bytes"] += by
         return out
 
 
@@ -124,8 +126,8 @@ TIMER = None        # set to a KernelTimer() to enable
 
 
 class _timed:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
 
     def __enter__(self):
         if TIMER is not None:
@@ -136,12 +138,18 @@ class _timed:
     def __exit__(self, *exc):
         if TIMER is not None:
             self.e1.record()
-            TIMER.records.append((self.name, self.e0, self.e1, self.flops))
+            TIMER.records.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
 
 
 FLOP_FWD_PER_POINT = 2 * 593408
 FLOP_DGRAD_PER_POINT = 2 * 557696
 FLOP_WGRAD_PER_POINT = 2 * 593408
+FLOP_WGRAD_BIG_PER_POINT = 2 * 8 * 256 * 256            # the eight full-width jobs
+# algorithmic HBM bytes per point (SURVEY §8d / DESIGN.md §2): what a launch must move once
+BYTES_ACT_PER_POINT = 4 * (9 * 256 + 128 + 64 + 32) + 8 * 9  # saved activations + encodings + bitmasks (forward, training)
+BYTES_DELTA_PER_POINT = 4 * (9 * 256 + 128)             # deltas written by dgrad
+BYTES_WGRAD_BIG_PER_POINT = 4 * 8 * (256 + 256)         # each full-width job reads its delta and its input once
+BYTES_WGRAD_SMALL_PER_POINT = 4 * (2 * (256 + 64) + (4 + 256) + (128 + 256) + (128 + 32) + (4 + 128))
 
 
 N_PARAMS = 595844
@@ -230,12 +238,13 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     S = z_vals.shape[1]
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
     act = torch.empty(act_floats(n, S), dtype=torch.float32, device=rays.device) if save_act else None
+    nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision == "bf16x3":
-        with _timed("field_fwd3_kernel<save>" if save_act else "field_fwd3_kernel", FLOP_FWD_PER_POINT * n * S):
+        with _timed("field_fwd3_kernel<save>" if save_act else "field_fwd3_kernel", FLOP_FWD_PER_POINT * n * S, nbytes):
             _check(lib().nerf_field_fwd_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                                n, S, _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd_bf16x3")
         return raw, act
-    with _timed("field_fwd_kernel<save>" if save_act else "field_fwd_kernel", FLOP_FWD_PER_POINT * n * S):
+    with _timed("field_fwd_kernel<save>" if save_act else "field_fwd_kernel", FLOP_FWD_PER_POINT * n * S, nbytes):
         _check(lib().nerf_field_fwd(_ptr(packed, "packed"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"), n, S,
                                     _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd")
     return raw, act
@@ -298,18 +307,28 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32"):
     dev = d_raw.device
     delta = torch.empty(L.nerf_delta_floats(n, S), dtype=torch.float32, device=dev)
     partial = torch.empty(L.nerf_wgrad_partial_floats(n, S), dtype=torch.float32, device=dev)
-    if precision == "bf16x3":
-        with _timed("field_dgrad3_kernel", FLOP_DGRAD_PER_POINT * n * S):
+    b3 = precision == "bf16x3"
+    P = n * S
+    with _timed("field_dgrad3_kernel" if b3 else "field_dgrad_kernel", FLOP_DGRAD_PER_POINT * P, BYTES_DELTA_PER_POINT * P):
+        if b3:
             _check(L.nerf_field_dgrad_bf16x3(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
                                              _ptr(delta), _stream()), "nerf_field_dgrad_bf16x3")
-        with _timed("wgrad3_kernel(+small fp32 jobs +reduce)", FLOP_WGRAD_PER_POINT * n * S):
-            _check(L.nerf_field_wgrad_bf16x3(_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial),
-                                             _ptr(grad, "grad"), int(bool(accumulate)), _stream()), "nerf_field_wgrad_bf16x3")
+        else:
+            _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
+                                      _stream()), "nerf_field_dgrad")
+    args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),
+            int(bool(accumulate)), int(b3))
+    if TIMER is None:
+        _check(L.nerf_field_wgrad_phase(*args, 7, _stream()), "nerf_field_wgrad_phase")
         return grad
-    with _timed("field_dgrad_kernel", FLOP_DGRAD_PER_POINT * n * S):
-        _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
-                                  _stream()), "nerf_field_dgrad")
-    with _timed("wgrad_kernel(+reduce)", FLOP_WGRAD_PER_POINT * n * S):
-        _check(L.nerf_field_wgrad(_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial),
-                                  _ptr(grad, "grad"), int(bool(accumulate)), _stream()), "nerf_field_wgrad")
+    if b3:      # all 14 jobs (full-width and narrow) run through the masked bf16x3 tile kernel
+        with _timed("wgrad3_256_kernel", FLOP_WGRAD_PER_POINT * P, (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT) * P):
+            _check(L.nerf_field_wgrad_phase(*args, 3, _stream()), "nerf_field_wgrad_phase")
+    else:
+        with _timed("wgrad256_kernel", FLOP_WGRAD_BIG_PER_POINT * P, BYTES_WGRAD_BIG_PER_POINT * P):
+            _check(L.nerf_field_wgrad_phase(*args, 1, _stream()), "nerf_field_wgrad_phase")
+        with _timed("wgrad_kernel(narrow jobs)", (FLOP_WGRAD_PER_POINT - FLOP_WGRAD_BIG_PER_POINT) * P, BYTES_WGRAD_SMALL_PER_POINT * P):
+            _check(L.nerf_field_wgrad_phase(*args, 2, _stream()), "nerf_field_wgrad_phase")
+    with _timed("wgrad_reduce_kernel", 0.0, 4.0 * N_PARAMS * (partial.numel() // N_PARAMS + 1)):
+        _check(L.nerf_field_wgrad_phase(*args, 4, _stream()), "nerf_field_wgrad_phase")
     return grad

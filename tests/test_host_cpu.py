@@ -34,7 +34,7 @@ def test_argument_errors_are_codes_not_crashes():
     assert L.nerf_act_floats(0, 64) == 0
     n, S = 4096, 192
     P = n * S
-    assert L.nerf_act_floats(n, S) == P * (9 * 256 + 128 + 64) + n * 32 + 9 * P * 8
+    assert L.nerf_act_floats(n, S) == P * (9 * 256 + 128 + 64 + 32) + n * 32 + 9 * P * 8
     assert L.nerf_delta_floats(n, S) == P * (9 * 256 + 128)
     assert L.nerf_wgrad_partial_floats(n, S) % 595844 == 0
 

@@ -54,7 +54,7 @@ for (n_rays, S) in [(48, 64), (11, 192), (70, 20)]:
     got = dl[8 * P * 256:9 * P * 256].view(P, 256).double(); res["feat"] = float((got - ft.grad).abs().max() / ft.grad.abs().max())
     got = dl[9 * P * 256:9 * P * 256 + P * 128].view(P, 128).double(); res["hv"] = float((got - av.grad).abs().max() / av.grad.abs().max())
     # masks
-    al_mask_off = 8*P*256 + P*256 + P*128 + P*64 + n_rays*32; al_mask_off = (al_mask_off + 3) & ~3
+    al_mask_off = 8*P*256 + P*256 + P*128 + P*64 + n_rays*32 + P*32; al_mask_off = (al_mask_off + 3) & ~3
     m = act.cpu()[al_mask_off:al_mask_off + 9*P*8].view(torch.int32).view(9, P, 4, 2)
     mres = {}
     for i in range(8):

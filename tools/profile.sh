@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --single-datapath"
 {
 echo "== kernel stats"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_stats -o bench -- $CMD 2>&1 | grep -E '^\{|rror' | cut -c1-600
@@ -25,7 +25,7 @@ for f in sorted(glob.glob("gpurun_out/prof_pmc_*/**/*counter_collection.csv", re
         agg[k][0] += 1; agg[k][1] += float(row["Counter_Value"])
     print("##", f)
     for (kn, cn), (n, v) in sorted(agg.items()):
-        if any(s in kn for s in ("field_", "wgrad", "composite", "sample_", "pack_")):
+        if any(s in kn for s in ("field_", "wgrad", "expand")):
             print(f"{kn:62s} {cn:28s} dispatches={n:4d} mean={v/n:.6g}")
 PY
 } > $R/gpurun_out/profile.log 2>&1
