@@ -83,6 +83,29 @@ def kernel_table(kern, precision):
     return out
 
 
+def pmc_traffic(kernel_name, precision):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary of this same command
+    (separate --pmc passes; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_bf16x3_pmc_summary.csv" if precision == "bf16x3" else "r01_pmc_summary.csv")
+    key = kernel_name.split("<")[0].split("(")[0]
+    fetch = write = None
+    try:
+        for line in open(path):
+            if line.startswith("#") or "," not in line:
+                continue
+            kn, cn, _, val = line.rstrip().rsplit(",", 3)
+            if kn.replace("nerf::", "").split("<")[0] == key or (key in kn and ("<true>" in kn) == ("<save>" in kernel_name)):
+                if cn == "FETCH_SIZE":
+                    fetch = float(val)
+                elif cn == "WRITE_SIZE":
+                    write = float(val)
+    except OSError:
+        return None, None
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.relpath(path, ROOT)
+
+
 def roofline_of(table):
     """roofline object of the dominant kernel (largest share of the timed region), bound = the roof it sits closer to"""
     if not table:
@@ -212,6 +235,12 @@ def main():
         kernels = kernel_table(kern, args.precision)
         roofline = roofline_of(kernels)
         if roofline is not None:
+            tr, src = pmc_traffic(roofline["kernel"], args.precision)
+            if tr is not None:
+                k = kernels[roofline["kernel"]]
+                roofline["traffic"] = tr
+                roofline["traffic_note"] = (f"bytes per launch (mean over coarse+fine launches) from {src}: 2*FETCH_SIZE + WRITE_SIZE; "
+                                            f"algorithmic bytes per launch here: {k['algorithmic_GBps'] * 1e9 * k['avg_ms'] * 1e-3:.4g}")
             issued = 1.0 if args.precision == "fp32" else 3.0
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
             roofline["whole_step_mfma_frac"] = value * flop_per_ray * issued / world / 1e12 / peak
