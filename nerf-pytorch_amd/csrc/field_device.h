@@ -42,11 +42,36 @@ __device__ inline void dma_1k(const float* gsrc_lane, unsigned lds_dst_uniform) 
         : "v"(gsrc_lane), "s"(lds_dst_uniform)
         : "memory");
 }
+// four consecutive 1 KiB pieces under ONE M0 set-up: the immediate offset advances the global and the LDS address alike
+__device__ inline void dma_4k(const float* gsrc_lane, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc_lane), "s"(lds_dst_uniform)
+        : "memory");
+}
+// every wave copies one contiguous span of the chunk (nfloats / NWAVES, a multiple of 256 floats) in 4 KiB and 1 KiB steps
 template <int NWAVES>
 __device__ inline void dma_chunk(const float* gsrc, float* lbuf, int nfloats, int wave, int lane) {
     const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(lbuf));
-    for (int i = wave * 256; i < nfloats; i += NWAVES * 256)
-        dma_1k(gsrc + i + lane * 4, base + (unsigned)i * 4u);
+    const int span = nfloats / NWAVES;              // chunk sizes are multiples of NWAVES * 256 floats, except the tails below
+    if ((nfloats % (NWAVES * 256)) == 0) {
+        int i = wave * span;
+        const int end = i + span;
+        for (; i + 1024 <= end; i += 1024) dma_4k(gsrc + i + lane * 4, base + (unsigned)i * 4u);
+        for (; i < end; i += 256) dma_1k(gsrc + i + lane * 4, base + (unsigned)i * 4u);
+    } else {
+        for (int i = wave * 256; i < nfloats; i += NWAVES * 256)
+            dma_1k(gsrc + i + lane * 4, base + (unsigned)i * 4u);
+    }
 }
 
 // Small parameters (biases, density / colour head weights) live in LDS behind the
