@@ -153,7 +153,8 @@ def main():
     net_c.load_state_dict(Pc)
     net_f.load_state_dict(Pf)
     parallel.broadcast_parameters([net_c, net_f])
-    opt = torch.optim.Adam(list(net_c.parameters()) + list(net_f.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    # torch.optim.Adam semantics (run_nerf.py:207), fused over the two flat parameter vectors (state_dict compatible)
+    opt = npa.FlatAdam(list(net_c.parameters()) + list(net_f.parameters()), lr=5e-4, betas=(0.9, 0.999))
 
     # synthetic data, resident in HBM: a pool of ray batches (rank-dependent seeds) + targets
     pool = 8

@@ -128,6 +128,10 @@ int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d
  * partial gradients into grad.  Calling it with phases 1, 2, 4 in that order equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate, int bf16x3, int phases, void* stream);
+/* ---- optimizer.step() of run_nerf.py:776 for torch.optim.Adam(lr, betas=(beta1, beta2), eps) (run_nerf.py:207), fused over
+ * a flat vector: params / grads / exp_avg / exp_avg_sq [n]; step = 1-based step count (bias correction). */
+int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,
+                   float beta2, float eps, int step, void* stream);
 /* test hook (host only): out_host[e] for every 16-bit element e of the weight streams (2 * stream words):
  * 2 * canonical_index + is_low_part, or -1 for zero padding. */
 int nerf_debug_pack3_table(int* out_host);

@@ -12,7 +12,9 @@ from .render import (batchify, batchify_rays, get_rays, get_rays_np, img2mse, ms
                      set_precision, get_precision)
 from .nerf_setup import config_parser, create_nerf  # noqa: F401
 from . import hip_backend, parallel  # noqa: F401
+from .optim import FlatAdam  # noqa: F401
+from .sampling import sample_ray_batch  # noqa: F401
 
 __all__ = ["Embedder", "NeRF", "get_embedder", "batchify", "batchify_rays", "get_rays", "get_rays_np", "img2mse",
            "mse2psnr", "ndc_rays", "query_points", "raw2outputs", "render", "render_path", "render_rays",
-           "run_network", "sample_pdf", "to8b", "config_parser", "create_nerf", "hip_backend", "parallel", "set_precision", "get_precision"]
+           "run_network", "sample_pdf", "to8b", "config_parser", "create_nerf", "hip_backend", "parallel", "set_precision", "get_precision", "FlatAdam", "sample_ray_batch"]

@@ -220,4 +220,12 @@ int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_strid
                                                   (hipStream_t)stream));
 }
 
+int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,
+                   float beta2, float eps, int step, void* stream) {
+    REQUIRE(params && grads && exp_avg && exp_avg_sq, "null pointer");
+    REQUIRE(n >= 0 && step >= 1 && beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "bad argument");
+    return done(__func__, nerf::launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step,
+                                            (hipStream_t)stream));
+}
+
 }  // extern "C"

@@ -293,3 +293,30 @@ hipError_t launch_embed(const float* x, long n_pts, int n_freqs, float* out, hip
 }
 
 }  // namespace nerf
+
+// ------------------------------------------------------------------ fused Adam over a flat parameter vector
+// (torch.optim.Adam defaults of run_nerf.py:207: no amsgrad, no weight decay).  Same operation order as
+// torch's single-tensor Adam: exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2);
+// denom = sqrt(exp_avg_sq)/sqrt(bias2) + eps; p -= (lr/bias1) * exp_avg/denom.
+namespace nerf {
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int n, float lr_over_bc1, float one_minus_b1, float b2, float one_minus_b2, float sqrt_bc2, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] + one_minus_b1 * (gi - m[i]);
+    const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    p[i] = p[i] - lr_over_bc1 * (mi / denom);
+}
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2, float eps, int step,
+                       hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, g, m, v, n, (float)(lr / bc1),
+                       (float)(1.0 - (double)b1), b2, (float)(1.0 - (double)b2), (float)sqrt(bc2), eps);
+    return hipGetLastError();
+}
+}  // namespace nerf

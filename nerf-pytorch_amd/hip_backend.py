@@ -51,6 +51,7 @@ def _declare(lib):
         "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p]),
         "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p]),
+        "nerf_adam_step": (i, [p, p, p, p, i, f, f, f, f, i, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
@@ -64,7 +65,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
-           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase"]
+           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_adam_step"]
 
 
 def lib():
@@ -332,3 +333,11 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32"):
     with _timed("wgrad_reduce_kernel", 0.0, 4.0 * N_PARAMS * (partial.numel() // N_PARAMS + 1)):
         _check(L.nerf_field_wgrad_phase(*args, 4, _stream()), "nerf_field_wgrad_phase")
     return grad
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    """In-place fused Adam over flat fp32 vectors (one launch)."""
+    n = params.numel()
+    _check(lib().nerf_adam_step(_ptr(params, "params"), _ptr(grads, "grads"), _ptr(exp_avg, "exp_avg"),
+                                _ptr(exp_avg_sq, "exp_avg_sq"), n, float(lr), float(beta1), float(beta2), float(eps),
+                                int(step), _stream()), "nerf_adam_step")

@@ -108,8 +108,10 @@ def config_parser():
     return parser
 
 
-def create_nerf(args, device=None):
-    """run_nerf.py:178-259: (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)."""
+def create_nerf(args, device=None, fused_adam=False):
+    """run_nerf.py:178-259: (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer).
+    fused_adam=True returns nerf_pytorch_amd.FlatAdam (same arithmetic and state_dict as torch.optim.Adam, one HIP
+    launch per network) instead of torch.optim.Adam."""
     if device is None:
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
@@ -132,7 +134,11 @@ def create_nerf(args, device=None):
     network_query_fn = lambda inputs, viewdirs, network_fn: run_network(
         inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=netchunk)
 
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    if fused_adam:
+        from .optim import FlatAdam
+        optimizer = FlatAdam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    else:
+        optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
 
     start = 0
     basedir, expname = args.basedir, args.expname

@@ -495,6 +495,27 @@ def test_bf16x3_render_psnr_delta(npa, dev, nets):
     assert dpsnr < 0.01
 
 
+def test_fused_adam_matches_torch_adam(npa, dev):
+    """nerf_adam_step (one launch per flat vector) vs torch.optim.Adam over the 24 tensors."""
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    torch.manual_seed(0)
+    a, b = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
+    b.load_state_dict(a.state_dict())
+    oa, ob = npa.FlatAdam(a.parameters(), lr=5e-4), torch.optim.Adam(b.parameters(), lr=5e-4)
+    table = npa.hip_backend.param_table()
+    for it in range(4):
+        fg = (torch.randn(595844, generator=torch.Generator().manual_seed(it)) * 10 ** (it - 2)).to(dev)
+        for m in (a, b):
+            for (nm, off, shape), p in zip(table, m.param_list()):
+                g = fg[off:off + p.numel()].view(shape)
+                p.grad = g if m is a else g.clone()
+        oa.step()
+        ob.step()
+    d = maxdiff(a.flat_params(), b.flat_params())
+    assert d <= 2e-7, d
+    assert maxdiff(oa.state[a.pts_linears[3].weight]["exp_avg_sq"], ob.state[b.pts_linears[3].weight]["exp_avg_sq"]) <= 1e-6 * 1e2
+
+
 def test_adversarial_scene_psnr_delta(npa, dev):
     """Unrelated coarse/fine networks with full-strength 2^9-frequency columns: per-ray agreement is not
     defined (the reference's own fp32-vs-fp64 runs disagree at 1e-2 here), the image-level criterion is."""

@@ -121,3 +121,70 @@ def test_create_nerf_builds_the_reference_kwargs(tmp_path):
     tr2, _, start2, _, _ = npa.create_nerf(a, device=torch.device("cpu"))
     assert start2 == 7
     assert torch.equal(tr2["network_fn"].flat_params(), tr["network_fn"].flat_params())
+
+
+def test_flat_adam_is_state_dict_compatible_with_torch_adam():
+    """FlatAdam = torch.optim.Adam arithmetic on flat moment buffers; checkpoints round-trip both ways (run_nerf.py:792-800)."""
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    torch.manual_seed(0)
+    a, b = npa.NeRF(**kw), npa.NeRF(**kw)
+    b.load_state_dict(a.state_dict())
+    oa, ob = npa.FlatAdam(a.parameters(), lr=5e-4), torch.optim.Adam(b.parameters(), lr=5e-4)
+    table = npa.hip_backend.param_table()
+
+    def set_grads(seed):
+        fg = torch.randn(595844, generator=torch.Generator().manual_seed(seed))
+        for m in (a, b):
+            for (nm, off, shape), p in zip(table, m.param_list()):
+                g = fg[off:off + p.numel()].view(shape)
+                p.grad = g if m is a else g.clone()          # a: views of one flat bucket, like the HIP backward
+    for it in range(3):
+        set_grads(it)
+        oa.step()
+        ob.step()
+    assert torch.equal(a.flat_params(), b.flat_params())
+    assert len(npa.optim._segments(list(a.parameters()))) == 1
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["param_groups"][0].keys() == sb["param_groups"][0].keys()
+    for i in range(24):
+        assert torch.equal(sa["state"][i]["exp_avg"], sb["state"][i]["exp_avg"])
+        assert float(sa["state"][i]["step"]) == float(sb["state"][i]["step"]) == 3.0
+    # cross-loading, then one more identical step
+    ob2 = torch.optim.Adam(b.parameters(), lr=5e-4)
+    ob2.load_state_dict(sa)
+    oa2 = npa.FlatAdam(a.parameters(), lr=5e-4)
+    oa2.load_state_dict(sb)
+    set_grads(7)
+    oa2.step()
+    ob2.step()
+    assert torch.equal(a.flat_params(), b.flat_params())
+    # lr schedule of train() (run_nerf.py:780-784) reaches the fused step through param_groups
+    for g in oa2.param_groups:
+        g["lr"] = 1e-4
+    before = a.flat_params().clone()
+    set_grads(8)
+    oa2.step()
+    assert 0 < (a.flat_params() - before).abs().max() < 2.1e-4
+
+
+def test_sample_ray_batch_matches_get_rays_on_the_selected_pixels():
+    import numpy as np
+    H, W, focal = 20, 30, 25.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    pose = torch.tensor([[1.0, 0, 0, 0.1], [0, 0.8, -0.6, 0.2], [0, 0.6, 0.8, 4.0]])
+    img = torch.rand(H, W, 3)
+    g = torch.Generator().manual_seed(0)
+    rays, tgt = npa.sample_ray_batch(H, W, K, pose, img, 64, generator=g)
+    assert rays.shape == (2, 64, 3) and tgt.shape == (64, 3)
+    ro, rd = npa.get_rays(H, W, K, pose)
+    # every sampled ray is a ray of the full grid, at the pixel whose colour was taken, and no pixel repeats
+    flat_d, flat_c = rd.reshape(-1, 3), img.reshape(-1, 3)
+    idx = [int(((flat_d - rays[1][n]).abs().sum(-1) < 1e-6).nonzero()[0]) for n in range(64)]
+    assert len(set(idx)) == 64
+    assert torch.equal(flat_c[idx], tgt) and torch.equal(rays[0], ro.reshape(-1, 3)[idx])
+    # central precrop (run_nerf.py:738-747)
+    rays2, _ = npa.sample_ray_batch(H, W, K, pose, img, 32, precrop_frac=0.5, generator=g)
+    dH, dW = int(H // 2 * 0.5), int(W // 2 * 0.5)
+    crop = rd[H // 2 - dH:H // 2 + dH, W // 2 - dW:W // 2 + dW].reshape(-1, 3)
+    for n in range(32):
+        assert ((crop - rays2[1][n]).abs().sum(-1) < 1e-6).any()
