@@ -297,6 +297,14 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     n = rays.shape[0]
     dev = rays.device
     n_f = int(N_importance)
+    if n == 0:      # empty batch: the reference returns empty tensors of the right trailing shapes
+        e = lambda *tail: torch.zeros((0,) + tail, dtype=torch.float32, device=dev)
+        ret = {'rgb_map': e(3), 'disp_map': e(), 'acc_map': e()}
+        if retraw:
+            ret['raw'] = e(N_samples + n_f, 4)
+        if n_f > 0:
+            ret.update(rgb0=e(3), disp0=e(), acc0=e(), z_std=e())
+        return ret
     rnd = {}
     if randoms is not None:
         keys = (["t_rand"] if perturb > 0. else []) + (["noise_c"] if raw_noise_std > 0. else [])

@@ -495,6 +495,36 @@ def test_bf16x3_render_psnr_delta(npa, dev, nets):
     assert dpsnr < 0.01
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("n", [0, 1, 33, 129])
+def test_ragged_and_empty_batches(npa, dev, nets, precision, n):
+    """Edge cases through the full autograd path: empty batch, one ray, and sizes that leave partially filled
+    waves / workgroups (16- and 32-point wave blocks, 128-point workgroups) in both datapaths."""
+    nc, nf, Pc, Pf = nets
+    rays = orc.synthetic_rays(max(n, 1), seed=50 + n)[:n]
+    target = torch.rand(n, 3, generator=torch.Generator().manual_seed(n))
+    for m in (nc, nf):
+        m.zero_grad()
+    npa.set_precision(precision)
+    try:
+        out = npa.render_rays(rays.to(dev), nc, None, 64, N_importance=128, network_fine=nf, white_bkgd=True, retraw=True)
+        assert out["rgb_map"].shape == (n, 3) and out["raw"].shape == (n, 192, 4) and out["z_std"].shape == (n,)
+        if n == 0:
+            return
+        loss = npa.img2mse(out["rgb_map"], target.to(dev)) + npa.img2mse(out["rgb0"], target.to(dev))
+        loss.backward()
+    finally:
+        npa.set_precision("fp32")
+    ref = orc.trace_rays(rays, Pc, Pf, 64, 128, white_bkgd=True)
+    tol = 1e-5 if precision == "fp32" else 3e-4
+    assert maxdiff(out["rgb0"], ref["rgb0"]) <= tol
+    stable = ~orc.endpoint_unstable(ref["_weights0"])
+    if stable.any():
+        assert maxdiff(out["rgb_map"][stable.to(dev)], ref["rgb_map"][stable]) <= max(20 * tol, 2e-3)
+    g = nf.last_flat_grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+
+
 def test_fused_adam_matches_torch_adam(npa, dev):
     """nerf_adam_step (one launch per flat vector) vs torch.optim.Adam over the 24 tensors."""
     kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
