@@ -551,8 +551,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chu
 
 // ------------------------------------------------------------------ host side
 static int wgrad_chunks(long P, int* chunk_pts) {
-    long n = (P + 8191) / 8192;
-    if (n < 28) n = 28;
+    // 128 point chunks: 14 jobs x 128 = 1792 = 7 x 256 workgroups (bf16x3, one workgroup per CU) and 8 x 128 = 4 x 256
+    // (fp32 full-width jobs) -> no partially filled last wave of workgroups; small inputs get >= 256-point chunks
+    long n = 128;
     const long cap = (P + 255) / 256;
     if (n > cap) n = cap;
     if (n < 1) n = 1;
