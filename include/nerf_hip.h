@@ -110,22 +110,27 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
 /* ---- split-bf16 ("bf16x3") datapath of the same functions: every product W*x is evaluated as
  * W_hi*x_hi + W_hi*x_lo + W_lo*x_hi on bf16 MFMA with fp32 accumulation (~1e-5 relative error per product,
  * judged by the PSNR-delta criterion instead of the fp32 tolerances).  Parameters are repacked into (hi, lo)
- * bf16 fragment streams of nerf_packed3_floats() 32-bit words; the activation save buffer has the same size
- * and row layout as the fp32 path (only the ReLU bitmask words are lane-order specific to this datapath,
- * so forward and backward of one evaluation must use the same datapath). */
+ * bf16 fragment streams of nerf_packed3_floats() 32-bit words.  The save buffers (act, delta) of this datapath hold
+ * 32-point feature-major tiles instead of point-major rows (element (p, f) of an F-wide region at
+ * (p/32)*F*32 + f*32 + p%32, sized for n_rays*n_samples rounded up to 32; nerf_act_floats / nerf_delta_floats
+ * cover both datapaths), and the ReLU bitmask words are in this datapath's lane order: forward and backward of one
+ * evaluation must use the same datapath. */
 int nerf_packed3_floats(void);
 int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream);
 int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                           int n_samples, float* raw, float* act, void* stream);
-/* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  The narrow weight-gradient
- * jobs (63- / 27- / 3- / 1-wide) stay on the exact fp32 kernel. */
+/* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  dgrad also leaves a tiled
+ * copy of d_raw inside delta, which is what wgrad contracts with: nerf_field_wgrad_bf16x3 must be given the delta
+ * buffer of nerf_field_dgrad_bf16x3 for the same d_raw (its own d_raw argument is not read).  All 14 weight-gradient
+ * jobs, full-width and narrow, run on the split-bf16 MFMA kernel. */
 int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
                             float* delta, void* stream);
 int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                             float* partial, float* grad, int accumulate, void* stream);
 /* nerf_field_wgrad / nerf_field_wgrad_bf16x3 split into their three launches so that a profiler can bracket each:
- * phases bit 0 = the eight full-width (256x256) jobs, bit 1 = the six narrow jobs, bit 2 = reduction of the per-chunk
- * partial gradients into grad.  Calling it with phases 1, 2, 4 in that order equals one call with 7. */
+ * phases bit 0 = the eight full-width (256x256) jobs (bf16x3: all 14 jobs), bit 1 = the six narrow jobs (fp32 datapath
+ * only), bit 2 = reduction of the per-chunk partial gradients into grad.  Calling it with phases 1, 2, 4 in that order
+ * equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate, int bf16x3, int phases, void* stream);
 /* ---- optimizer.step() of run_nerf.py:776 for torch.optim.Adam(lr, betas=(beta1, beta2), eps) (run_nerf.py:207), fused over

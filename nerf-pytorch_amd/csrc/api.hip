@@ -76,11 +76,15 @@ int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const floa
 
 size_t nerf_act_floats(int n_rays, int n_samples) {
     if (n_rays <= 0 || n_samples <= 0) return 0;
-    return nerf::act_layout((size_t)n_rays * n_samples, (size_t)n_rays).total;
+    const size_t P = (size_t)n_rays * n_samples;      // covers both datapaths' layouts
+    const size_t a = nerf::act_layout(P, (size_t)n_rays).total, b = nerf::act_layout3(P, (size_t)n_rays).total;
+    return a > b ? a : b;
 }
 size_t nerf_delta_floats(int n_rays, int n_samples) {
     if (n_rays <= 0 || n_samples <= 0) return 0;
-    return nerf::delta_layout((size_t)n_rays * n_samples).total;
+    const size_t P = (size_t)n_rays * n_samples;
+    const size_t a = nerf::delta_layout(P).total, b = nerf::delta_layout3(P).total;
+    return a > b ? a : b;
 }
 size_t nerf_wgrad_partial_floats(int n_rays, int n_samples) {
     if (n_rays <= 0 || n_samples <= 0) return 0;

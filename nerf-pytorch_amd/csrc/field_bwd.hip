@@ -93,7 +93,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_dgrad_kernel(FieldBwdA
             float* o = a.delta + dl.hv + p * WV + 4 * q;
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb)
-                *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{dhv[4 * nb], dhv[4 * nb + 1], dhv[4 * nb + 2], dhv[4 * nb + 3]};
+                nt_store(reinterpret_cast<f32x4*>(o + 16 * nb), f32x4{dhv[4 * nb], dhv[4 * nb + 1], dhv[4 * nb + 2], dhv[4 * nb + 3]});
         }
         mma_chunk<16, 16, 0, 32>(acc, dhv, first, lane);
     }
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_dgrad_kernel(FieldBwdA
             float* o = a.delta + off + p * W + 4 * q;
 #pragma unroll
             for (int nb = 0; nb < 16; ++nb)
-                *reinterpret_cast<f32x4*>(o + 16 * nb) = f32x4{d[4 * nb], d[4 * nb + 1], d[4 * nb + 2], d[4 * nb + 3]};
+                nt_store(reinterpret_cast<f32x4*>(o + 16 * nb), f32x4{d[4 * nb], d[4 * nb + 1], d[4 * nb + 2], d[4 * nb + 3]});
         }
     };
 
@@ -380,74 +380,80 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(WgradArgs a) {
     }
 }
 
-// Split-bf16 variant of wgrad256_kernel: dW = delta^T X with every product evaluated as hi*hi + hi*lo + lo*hi on
-// v_mfma_f32_32x32x16_bf16 (contraction over points).  The MFMA wants 8 consecutive POINTS of one feature per lane,
-// the operands are stored point-major, so staging transposes through registers: thread (operand, feature f) loads
-// its feature for the 32 points of a stage (each wave-instruction = 64 consecutive features of one point = 256 B),
-// splits them into (hi, lo) bf16 and writes four 16-byte groups into a feature-major LDS image padded to 144 B per
-// feature (conflict-free ds_write_b128 and ds_read_b128).  Bias gradients fall out of the staging threads exactly
-// (fp32 sums of the values they loaded).  HBM-bound: 64 KiB of operands per 48 MFMAs per wave.
+// ------------------------------------------------------------------ bf16x3 weight gradients
+// dW[n][k] = sum_p delta[p][n] * x[p][k] for all 14 (delta, input) jobs, 3 bf16 MFMAs per product on
+// v_mfma_f32_32x32x16_bf16 (contraction over points).  Operands are stored in 32-point feature-major tiles
+// (nerf_common.h, ActLayout3): a tile is the k-extent of one stage, and the MFMA wants 8 consecutive POINTS of one
+// feature per lane -- exactly how a tile lays them out.  Staging: the 256 threads of an operand read a tile as one
+// contiguous block, 16 B per lane and lane-linear (round r = features 32r..32r+31; thread t holds points
+// 4*(t&7)..+3 of feature 32r + t/8), split the values into (hi, lo) bf16 and write 8 + 8 bytes into a feature-major
+// LDS image padded to 144 B per feature (conflict-free ds_read_b128 for the fragments).  Narrow operands
+// (63 / 27 / 3 / 1 features) run through the same tile: rounds beyond their width re-read the last feature (cache
+// hits) and stage zeros, so padding costs no HBM bytes (the kernel is HBM-bound, idle MFMA blocks are free).  Bias gradients fall out of the staging threads
+// exactly (fp32 sums of the values they loaded).  64 KiB of operands per 48 MFMAs per wave.
 constexpr int WG3_FEAT_BYTES = 144;                              // 32 pts x 2 B x (hi, lo) + 16 B pad
 constexpr int WG3_OPERAND_BYTES = 256 * WG3_FEAT_BYTES;          // 36,864
 constexpr int WG3_LDS_BYTES = 2 * 2 * WG3_OPERAND_BYTES;         // 2 buffers x (A, B) = 147,456
+constexpr int WG3_ROUNDS = 8;                                    // 256 features / 32 per round
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned h = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        hi[i] = h;
+        lo[i] = pack_bf16x2(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+}
 
 __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm3[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_n = wave >> 2, wave_k = wave & 3;
     const int ji = blockIdx.x % a.n_jobs;
     const int chunk = blockIdx.x / a.n_jobs;
     const WgradJob& jb = a.job[ji];
-    const long p_begin = (long)chunk * a.chunk_pts;
+    const long p_begin = (long)chunk * a.chunk_pts;              // multiple of 32: chunks start on a tile
     const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
-    const int n_stages = (int)((p_end - p_begin + WG_STAGE - 1) / WG_STAGE);
-    // staging role: operand 0 = delta (A), 1 = input (B); one feature column per thread.  Narrow jobs (63 / 27 / 3 / 1
-    // valid columns) run through the same tile: threads beyond the operand's width stage zeros and issue no loads, so
-    // padding costs no HBM bytes (the kernel is HBM-bound, idle MFMA blocks are free).
-    const int sop = __builtin_amdgcn_readfirstlane(tid >> 8);      // waves 0-3 stage A, waves 4-7 stage B (wave-uniform)
-    const int sf = tid & 255;
-    const int swidth = sop == 0 ? jb.nA : jb.nB;
-    const bool sactive = sf < swidth;
-    const int sld = sop == 0 ? jb.lda : jb.ldb;
-    // scalar base of this workgroup's chunk + 32-bit per-lane offsets: one v_add per load instead of 64-bit address math
-    const char* cbase = reinterpret_cast<const char*>((sop == 0 ? jb.A : jb.B) + p_begin * (long)sld);
-    const unsigned soff = 4u * (unsigned)min(sf, swidth - 1);          // byte offset of the (clamped, always valid) column
-    const unsigned sldb = 4u * (unsigned)sld;                          // row pitch in bytes; a chunk spans < 4 GiB
     const int nrows = (int)(p_end - p_begin);
-    float rv[WG_STAGE];
-    float colsum = 0.0f;
-    // 32 independent, unconditional loads per stage (zeros are selected afterwards): no control flow between the
-    // loads, they all stay in flight together; only the last stage of the last chunk needs row clamping
-    auto gload_into = [&](float (&dst)[WG_STAGE], int st) {
-        const int q0 = st * WG_STAGE;
-        float v[WG_STAGE];
-        if (q0 + WG_STAGE <= nrows) {
-            unsigned off = soff + (unsigned)q0 * sldb;
+    const int n_stages = (nrows + WG_STAGE - 1) / WG_STAGE;
+    // staging role: waves 0-3 stage delta (A), waves 4-7 the input (B)
+    const int sop = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int st_t = tid & 255;
+    const int sg = st_t & 7;                                       // 4-point group inside the tile
+    const int swidth = sop == 0 ? jb.nA : jb.nB;
+    const int sld = sop == 0 ? jb.lda : jb.ldb;                    // features per tile of the operand's region
+    // scalar base of this workgroup's first tile + 32-bit per-lane byte offsets (a chunk spans < 4 GiB)
+    const char* cbase = reinterpret_cast<const char*>((sop == 0 ? jb.A : jb.B) + (p_begin >> 5) * (long)sld * 32);
+    const unsigned tile_bytes = 128u * (unsigned)sld;
+    const int sf0 = st_t >> 3;                                     // the thread's feature in round 0
+    const int sflast = swidth - 1;
+    float colsum[WG3_ROUNDS];
 #pragma unroll
-            for (int q = 0; q < WG_STAGE; ++q) { v[q] = *reinterpret_cast<const float*>(cbase + off); off += sldb; }
+    for (int r = 0; r < WG3_ROUNDS; ++r) colsum[r] = 0.0f;
+    // 8 independent, unconditional 16-byte loads per stage (rounds beyond a narrow operand's width re-read its last
+    // feature: cache hits, no HBM bytes); zeros (features beyond the width; points >= P in the last stage of the last
+    // chunk) are selected when the values are consumed, so the loads stay in flight across a whole compute phase
+    auto gload_into = [&](f32x4 (&dst)[WG3_ROUNDS], int st) {
+        const unsigned off0 = (unsigned)st * tile_bytes + 16u * (unsigned)sg;
 #pragma unroll
-            for (int q = 0; q < WG_STAGE; ++q) dst[q] = sactive ? v[q] : 0.0f;
-        } else {
-#pragma unroll
-            for (int q = 0; q < WG_STAGE; ++q)
-                v[q] = *reinterpret_cast<const float*>(cbase + (soff + (unsigned)min(q0 + q, nrows - 1) * sldb));
-#pragma unroll
-            for (int q = 0; q < WG_STAGE; ++q) dst[q] = (sactive && q0 + q < nrows) ? v[q] : 0.0f;
-        }
+        for (int r = 0; r < WG3_ROUNDS; ++r)        // feature clamped into the operand: always inside the tile
+            dst[r] = *reinterpret_cast<const f32x4*>(cbase + (off0 + 128u * (unsigned)min(32 * r + sf0, sflast)));
     };
-    auto gload = [&](int st) { gload_into(rv, st); };
-    auto swrite = [&](int buf) {
-        unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + sf * WG3_FEAT_BYTES;
+    auto swrite_from = [&](const f32x4 (&src)[WG3_ROUNDS], int buf, int st) {
+        unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + (st_t >> 3) * WG3_FEAT_BYTES + 8 * sg;
+        const int left = nrows - st * WG_STAGE - 4 * sg;           // points of this thread's group that exist
 #pragma unroll
-        for (int gq = 0; gq < WG_STAGE / 8; ++gq) {
-            u32x4 hi, lo;
-            split8(&rv[8 * gq], hi, lo);
-            *reinterpret_cast<u32x4*>(dst + 16 * gq) = hi;
-            *reinterpret_cast<u32x4*>(dst + 64 + 16 * gq) = lo;
-        }
-        if (sop == 0) {
+        for (int r = 0; r < WG3_ROUNDS; ++r) {
+            const bool fv = 32 * r + sf0 <= sflast;
+            f32x4 v;
 #pragma unroll
-            for (int q = 0; q < WG_STAGE; ++q) colsum += rv[q];
+            for (int e = 0; e < 4; ++e) v[e] = (fv && e < left) ? src[r][e] : 0.0f;
+            u32x2 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<u32x2*>(dst + r * 32 * WG3_FEAT_BYTES) = hi;
+            *reinterpret_cast<u32x2*>(dst + r * 32 * WG3_FEAT_BYTES + 64) = lo;
+            colsum[r] += (v[0] + v[1]) + (v[2] + v[3]);
         }
     };
     f32x16 acc[4][2];
@@ -487,39 +493,25 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
             }
         }
     };
-    // Two stages of operands in flight in registers (rv, rw): the loads issued in iteration st are consumed in
-    // iteration st+1's write-back, i.e. they have a full compute phase plus a barrier to land (the kernel is
-    // load-latency bound with a single stage in flight).
-    float rw[WG_STAGE];
-    auto gload2 = [&](int st) { gload_into(rw, st); };
-    auto swrite2 = [&](int buf) {
-        unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + sf * WG3_FEAT_BYTES;
-#pragma unroll
-        for (int gq = 0; gq < WG_STAGE / 8; ++gq) {
-            u32x4 hi, lo;
-            split8(&rw[8 * gq], hi, lo);
-            *reinterpret_cast<u32x4*>(dst + 16 * gq) = hi;
-            *reinterpret_cast<u32x4*>(dst + 64 + 16 * gq) = lo;
-        }
-        if (sop == 0) {
-#pragma unroll
-            for (int q = 0; q < WG_STAGE; ++q) colsum += rw[q];
-        }
-    };
-    gload(0);
-    swrite(0);
-    if (n_stages > 1) gload(1);
+    // Two stages of operands in flight in registers (rv, rw): the loads issued in one half-iteration are consumed by
+    // the write-back of the next one, i.e. they have a full compute phase plus a barrier to land.  The steady-state
+    // loop is branch-free (a conditional load makes hipcc drain vmcnt before the next batch of loads, which would
+    // leave a single stage in flight); the last stages run through the guarded tail loop.
+    f32x4 rv[WG3_ROUNDS], rw[WG3_ROUNDS];
+    gload_into(rv, 0);
+    swrite_from(rv, 0, 0);
+    if (n_stages > 1) gload_into(rv, 1);
     __syncthreads();
     // invariant at the top of iteration st (even): LDS buf 0 holds stage st, rv holds stage st+1
     for (int st = 0; st < n_stages; st += 2) {
-        if (st + 2 < n_stages) gload2(st + 2);          // -> rw
+        if (st + 2 < n_stages) gload_into(rw, st + 2);
         compute(0);
-        if (st + 1 < n_stages) swrite(1);               // rv (stage st+1) -> buf 1
+        if (st + 1 < n_stages) swrite_from(rv, 1, st + 1);
         __syncthreads();
         if (st + 1 >= n_stages) break;
-        if (st + 3 < n_stages) gload(st + 3);           // -> rv
+        if (st + 3 < n_stages) gload_into(rv, st + 3);
         compute(1);
-        if (st + 2 < n_stages) swrite2(0);              // rw (stage st+2) -> buf 0
+        if (st + 2 < n_stages) swrite_from(rw, 0, st + 2);
         __syncthreads();
     }
     // acc[i][j][r] at lane (col = lane&31, hf) = dW[wave_n*128 + 32*i + d32row(r, hf)][wave_k*64 + 32*j + col]
@@ -538,7 +530,17 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
                 }
             }
         }
-    if (jb.bias_off >= 0 && sop == 0 && sactive) out[jb.bias_off + sf] = colsum;
+    if (jb.bias_off >= 0 && sop == 0) {
+#pragma unroll
+        for (int r = 0; r < WG3_ROUNDS; ++r) {
+                float s = colsum[r];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                const int f = 32 * r + (st_t >> 3);
+                if (sg == 0 && f < swidth) out[jb.bias_off + f] = s;
+            }
+    }
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate) {
@@ -592,6 +594,21 @@ __global__ void expand_dir_kernel(const f32x4* __restrict__ dir_ray, f32x4* __re
     const long p = i >> 3;
     dir_pt[i] = dir_ray[(p / S) * 8 + (i & 7)];
 }
+// the same into 32-point feature-major tiles of 32 features (bf16x3 datapath): thread = (tile, feature, 4-point group)
+__global__ void expand_dir_tiles_kernel(const float* __restrict__ dir_ray, f32x4* __restrict__ dir_pt, long P, int S) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n_tiles = (P + 31) >> 5;
+    if (i >= n_tiles * 256) return;
+    const long tile = i >> 8;
+    const int f = (int)(i >> 3) & 31, g = (int)i & 7;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long p = min(tile * 32 + 4 * g + e, P - 1);
+        v[e] = dir_ray[(p / S) * 32 + f];
+    }
+    dir_pt[i] = v;
+}
 
 // phases: bit 0 = full-width jobs, bit 1 = narrow jobs, bit 2 = chunk reduction (7 = everything)
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
@@ -599,14 +616,38 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     hipError_t e;
-    const ActLayout al = act_layout((size_t)P, (size_t)n_rays);
-    const DeltaLayout dl = delta_layout((size_t)P);
     constexpr Canon cn = canon();
-    if (phases & 1) {       // act is written by the forward; the expanded copy is scratch inside the same buffer
-        hipLaunchKernelGGL(expand_dir_kernel, dim3((unsigned)((P * 8 + 255) / 256)), dim3(256), 0, stream,
-                           reinterpret_cast<const f32x4*>(act + al.dir), reinterpret_cast<f32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
+    // operand bases.  fp32 datapath: point-major rows (lda = row pitch); bf16x3: 32-point feature-major tiles
+    // (lda = features per tile, a feature offset f0 is folded into the base as f0 * 32)
+    const float *d_h[D], *d_feat, *d_hv, *d_rgb, *d_sigma, *x_h[D], *x_feat, *x_hv, *x_enc, *x_dir;
+    int ld_graw;
+    if (bf16x3) {
+        const ActLayout3 al = act_layout3((size_t)P, (size_t)n_rays);
+        const DeltaLayout3 dl = delta_layout3((size_t)P);
+        for (int l = 0; l < D; ++l) { d_h[l] = delta + dl.h[l]; x_h[l] = act + al.h[l]; }
+        d_feat = delta + dl.feat; d_hv = delta + dl.hv; d_rgb = delta + dl.graw; d_sigma = delta + dl.graw + 3 * 32;
+        x_feat = act + al.feat; x_hv = act + al.hv; x_enc = act + al.enc; x_dir = act + al.dir_pt;
+        ld_graw = 4;
+        if (phases & 1) {   // act is written by the forward; the expanded copy is scratch inside the same buffer
+            const long n_thr = ((P + 31) >> 5) * 256;
+            hipLaunchKernelGGL(expand_dir_tiles_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,
+                               act + al.dir, reinterpret_cast<f32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+    } else {
+        const ActLayout al = act_layout((size_t)P, (size_t)n_rays);
+        const DeltaLayout dl = delta_layout((size_t)P);
+        for (int l = 0; l < D; ++l) { d_h[l] = delta + dl.h[l]; x_h[l] = act + al.h[l]; }
+        d_feat = delta + dl.feat; d_hv = delta + dl.hv; d_rgb = d_raw; d_sigma = d_raw + 3;
+        x_feat = act + al.feat; x_hv = act + al.hv; x_enc = act + al.enc; x_dir = act + al.dir_pt;
+        ld_graw = 4;
+        if (phases & 1) {
+            hipLaunchKernelGGL(expand_dir_kernel, dim3((unsigned)((P * 8 + 255) / 256)), dim3(256), 0, stream,
+                               reinterpret_cast<const f32x4*>(act + al.dir), reinterpret_cast<f32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
     }
     WgradArgs wa{};
     int nj = 0, tiles = 0;
@@ -622,21 +663,20 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         j.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && lda % 4 == 0) ? 1 : 0;
         j.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && ldb % 4 == 0) ? 1 : 0;
     };
-    const float* enc = act + al.enc;
-    add(delta + dl.h[0], W, W, enc, 64, IN_XYZ, 1, cn.w[0], IN_XYZ, cn.b[0]);
+    add(d_h[0], W, W, x_enc, 64, IN_XYZ, 1, cn.w[0], IN_XYZ, cn.b[0]);
     for (int l = 1; l < D; ++l) {
         if (l == SKIP + 1) {
-            add(delta + dl.h[l], W, W, enc, 64, IN_XYZ, 1, cn.w[l], W + IN_XYZ, cn.b[l]);
-            add(delta + dl.h[l], W, W, act + al.h[l - 1], W, W, 1, cn.w[l] + IN_XYZ, W + IN_XYZ, -1);
+            add(d_h[l], W, W, x_enc, 64, IN_XYZ, 1, cn.w[l], W + IN_XYZ, cn.b[l]);
+            add(d_h[l], W, W, x_h[l - 1], W, W, 1, cn.w[l] + IN_XYZ, W + IN_XYZ, -1);
         } else {
-            add(delta + dl.h[l], W, W, act + al.h[l - 1], W, W, 1, cn.w[l], W, cn.b[l]);
+            add(d_h[l], W, W, x_h[l - 1], W, W, 1, cn.w[l], W, cn.b[l]);
         }
     }
-    add(delta + dl.feat, W, W, act + al.h[D - 1], W, W, 1, cn.wf, W, cn.bf);
-    add(d_raw + 3, 4, 1, act + al.h[D - 1], W, W, 1, cn.wa, W, cn.ba);
-    add(delta + dl.hv, WV, WV, act + al.feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
-    add(delta + dl.hv, WV, WV, act + al.dir_pt, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
-    add(d_raw, 4, 3, act + al.hv, WV, WV, 1, cn.wr, WV, cn.br);
+    add(d_feat, W, W, x_h[D - 1], W, W, 1, cn.wf, W, cn.bf);
+    add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);
+    add(d_hv, WV, WV, x_feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
+    add(d_hv, WV, WV, x_dir, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
+    add(d_rgb, ld_graw, 3, x_hv, WV, WV, 1, cn.wr, WV, cn.br);
     if (nj != WG_MAX_JOBS) return hipErrorInvalidValue;
     // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
     WgradArgs big{}, small{};

@@ -12,7 +12,7 @@ struct FieldBwd3Args {
     const float* packed3;
     const float* act;       // saved by field_fwd3_kernel<true> (bitmasks in the bf16x3 lane order)
     const float* d_raw;     // [P][4]
-    float* delta;           // delta_layout(P)
+    float* delta;           // delta_layout3(P): 32-point feature-major tiles
     int n_rays, S;
 };
 
@@ -39,9 +39,16 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     ws.start(a.packed3 + P3B_VIEWS, lds, wave, lane, valid);
     stage_small_from(a.packed3 + P3_SMALL, lds, FIELD3_WAVES * 64);
 
-    const ActLayout al = act_layout(P, (size_t)a.n_rays);
-    const DeltaLayout dl = delta_layout(P);
+    const ActLayout3 al = act_layout3(P, (size_t)a.n_rays);
+    const DeltaLayout3 dl = delta_layout3(P);
+    const size_t tile = (size_t)blockIdx.x * FIELD3_WAVES + wave;          // this wave's tile of every delta region
+    const int lslot = half * 128 + (lane & 31);
     const f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);       // (d_rgb3, d_sigma)
+    if (valid) {        // tile-major copy of d_raw: the A operand of the rgb_linear / alpha_linear weight gradients
+        float* gt = a.delta + dl.graw + tile * (4 * 32) + half * 64 + (lane & 31);
+        nt_store(gt, half ? g[2] : g[0]);
+        nt_store(gt + 32, half ? g[3] : g[1]);
+    }
     u32x4 msk[D + 1];
     {
         const u32x4* mp = reinterpret_cast<const u32x4*>(a.act + al.mask) + p * 2 + half;
@@ -79,22 +86,23 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
     };
-    // every delta is written while the NEXT contraction runs, a quarter (8 stores) after each chunk acquire;
-    // the following acquire<8> keeps those stores in flight (counted vmcnt, see WeightStreamT::acquire)
+    // every delta is written while the NEXT contraction runs, a quarter (32 stores) after each chunk acquire;
+    // the following acquire<NQ> keeps those stores in flight (counted vmcnt, see WeightStreamT::acquire)
+    constexpr int NQ = STORES_PER_QUARTER3;
     using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
     auto store_q = [&](auto part, size_t off) {
-        if (valid) store_rows3_part<decltype(part)::value>(a.delta + off + p * W, d, half);
+        if (valid) store_tile3<2 * decltype(part)::value, 2>(a.delta + off + tile * (W * 32) + lslot, d);
     };
 
     // ---- views_linears.0^T (feature columns): 128 -> 256
     zero_acc();
     {
         const float* cur = ws.acquire();
-        if (valid) store_rows3<64>(a.delta + dl.hv + p * WV, dhv, half);         // 16 stores
+        if (valid) store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);   // 64 stores
         mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
     }
-    mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<16>(), lane);
+    mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<63>(), lane);
 #pragma unroll
     for (int i = 0; i < 128; ++i) d[i] = acc[i >> 4][i & 15];
 
@@ -114,13 +122,13 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         const float* cur = ws.acquire();
         store_q(Q0{}, dl.feat);
         mma3_chunk<8, 4, 0, 128>(acc, d, cur, lane);
-        cur = ws.template acquire<8>();
+        cur = ws.template acquire<NQ>();
         store_q(Q1{}, dl.feat);
         mma3_chunk<8, 4, 32, 128>(acc, d, cur, lane);
-        cur = ws.template acquire<8>();
+        cur = ws.template acquire<NQ>();
         store_q(Q2{}, dl.feat);
         mma3_chunk<8, 4, 64, 128>(acc, d, cur, lane);
-        cur = ws.template acquire<8>();
+        cur = ws.template acquire<NQ>();
         store_q(Q3{}, dl.feat);
         mma3_chunk<8, 4, 96, 128>(acc, d, cur, lane);
     }
@@ -130,17 +138,17 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
 #pragma unroll 1
     for (int l = D - 1; l >= 1; --l) {
         zero_acc();
-        const size_t off = (size_t)l * P * W;                              // dl.h[l]: delta of layer l = input of this step
+        const size_t off = (size_t)l * pad32(P) * W;                       // dl.h[l]: delta of layer l = input of this step
         const float* cur = ws.acquire();
         store_q(Q0{}, off);
         mma3_chunk<8, 4, 0, 128>(acc, d, cur, lane);
-        cur = ws.template acquire<8>();
+        cur = ws.template acquire<NQ>();
         store_q(Q1{}, off);
         mma3_chunk<8, 4, 32, 128>(acc, d, cur, lane);
-        cur = ws.template acquire<8>();
+        cur = ws.template acquire<NQ>();
         store_q(Q2{}, off);
         mma3_chunk<8, 4, 64, 128>(acc, d, cur, lane);
-        cur = ws.template acquire<8>();
+        cur = ws.template acquire<NQ>();
         store_q(Q3{}, off);
         mma3_chunk<8, 4, 96, 128>(acc, d, cur, lane);
         u32x4 m = msk[0];
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];
         apply_mask3<128>(d, acc, m);
     }
-    if (valid) store_rows3<128>(a.delta + p * W, d, half);                // dl.h[0]
+    if (valid) store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);   // dl.h[0]
 }
 
 hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,

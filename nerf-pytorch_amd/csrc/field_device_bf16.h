@@ -68,34 +68,25 @@ __device__ inline void load_bias3(f32x16 (&acc)[NB], const float* bias, int half
         }
 }
 
-// lane value i (0..16*NB-1) = feature 32*(i>>4) + d32row(i&15, half): 4 consecutive features per float4
-template <int NV>
-__device__ inline void store_rows3(float* row, const float (&v)[NV], int half) {
+// Saved rows go to 32-point tiles, feature-major (nerf_common.h, ActLayout3).  tp = the lane's slot of feature 4*half
+// in its wave's tile: region + tile * F * 32 + half * 128 + (lane & 31).  Lane value i (0..16*NB-1) is feature
+// 32*(i>>4) + d32row(i&15, half); one store instruction writes one feature of the wave's 32 points per lane half
+// = two full 128-byte lines.
+template <int OB0, int NOB, int NV>
+__device__ inline void store_tile3(float* tp, const float (&v)[NV]) {
 #pragma unroll
-    for (int ob = 0; ob < NV / 16; ++ob)
+    for (int ob = OB0; ob < OB0 + NOB; ++ob)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(row + 32 * ob + 8 * g + 4 * half) =
-                f32x4{v[16 * ob + 4 * g], v[16 * ob + 4 * g + 1], v[16 * ob + 4 * g + 2], v[16 * ob + 4 * g + 3]};
+        for (int r = 0; r < 16; ++r) nt_store(tp + (32 * ob + (r & 3) + 8 * (r >> 2)) * 32, v[16 * ob + r]);
 }
-// quarter PART (0..3) of store_rows3<128>: blocks 2*PART, 2*PART+1  (8 store instructions)
-template <int PART>
-__device__ inline void store_rows3_part(float* row, const float (&v)[128], int half) {
-#pragma unroll
-    for (int ob = 2 * PART; ob < 2 * PART + 2; ++ob)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(row + 32 * ob + 8 * g + 4 * half) =
-                f32x4{v[16 * ob + 4 * g], v[16 * ob + 4 * g + 1], v[16 * ob + 4 * g + 2], v[16 * ob + 4 * g + 3]};
-}
+constexpr int STORES_PER_QUARTER3 = 32;      // store_tile3<2*PART, 2>: a quarter of a 256-feature row set
 // ReLU sign bits of the lane's NV values -> act.mask[layer][p][half] (4 words; NV <= 128)
 template <int NV>
 __device__ inline void save_mask3(float* mask_base, int layer, size_t P, size_t p, int half, const float (&v)[NV]) {
     unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < NV; ++i) w[i >> 5] |= (v[i] > 0.0f ? 1u : 0u) << (i & 31);
-    u32x4* m = reinterpret_cast<u32x4*>(mask_base) + ((size_t)layer * P + p) * 2 + half;
-    *m = u32x4{w[0], w[1], w[2], w[3]};
+    nt_store(reinterpret_cast<u32x4*>(mask_base) + ((size_t)layer * P + p) * 2 + half, u32x4{w[0], w[1], w[2], w[3]});
 }
 
 __device__ inline float half_sum(float v) { return v + __shfl_xor(v, 32); }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int col = encslot(s, q);
-                if (col >= 0) eo[col] = e[s];
+                if (col >= 0) nt_store(eo + col, e[s]);
             }
         }
     }
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
             float* ho = a.act + (size_t)layer * (size_t)P * W + (size_t)p * W + 4 * q;      // == al.h[layer]
 #pragma unroll
             for (int nb = 0; nb < 16; ++nb)
-                *reinterpret_cast<f32x4*>(ho + 16 * nb) = f32x4{h[4 * nb], h[4 * nb + 1], h[4 * nb + 2], h[4 * nb + 3]};
+                nt_store(reinterpret_cast<f32x4*>(ho + 16 * nb), f32x4{h[4 * nb], h[4 * nb + 1], h[4 * nb + 2], h[4 * nb + 3]});
             save_mask<64>(a.act + al.mask, layer, (size_t)P, (size_t)p, q, h);
         }
     };
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
             const int col = dirslot(s, q);
-            if (col >= 0) dout[col] = v[s];
+            if (col >= 0) nt_store(dout + col, v[s]);
         }
     }
     f32x4 av[8];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
             float* ho = a.act + al.feat + (size_t)p * W + 4 * q;
 #pragma unroll
             for (int nb = 0; nb < 16; ++nb)
-                *reinterpret_cast<f32x4*>(ho + 16 * nb) = f32x4{h[4 * nb], h[4 * nb + 1], h[4 * nb + 2], h[4 * nb + 3]};
+                nt_store(reinterpret_cast<f32x4*>(ho + 16 * nb), f32x4{h[4 * nb], h[4 * nb + 1], h[4 * nb + 2], h[4 * nb + 3]});
         }
         mma_chunk<8, 16, 0, 64>(av, h, first, lane);
     }
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd_kernel(FieldFwdArg
         float* ho = a.act + al.hv + (size_t)p * WV + 4 * q;
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb)
-            *reinterpret_cast<f32x4*>(ho + 16 * nb) = f32x4{hv[4 * nb], hv[4 * nb + 1], hv[4 * nb + 2], hv[4 * nb + 3]};
+            nt_store(reinterpret_cast<f32x4*>(ho + 16 * nb), f32x4{hv[4 * nb], hv[4 * nb + 1], hv[4 * nb + 2], hv[4 * nb + 3]});
         save_mask<32>(a.act + al.mask, D, (size_t)P, (size_t)p, q, hv);
     }
 

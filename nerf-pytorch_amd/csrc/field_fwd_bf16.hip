@@ -15,7 +15,7 @@ struct FieldFwd3Args {
     const float* rays;
     const float* z_vals;
     float* raw;
-    float* act;             // nullable
+    float* act;             // nullable: act_layout3 (32-point feature-major tiles)
     int ray_stride, n_rays, S;
 };
 
@@ -30,6 +30,9 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
     const bool valid = p_raw < P;
     const long p = valid ? p_raw : P - 1;
     const int ray = (int)(p / a.S);
+    // this wave's tile of the saved regions and the lane's slot in it (feature 4*half, point lane&31)
+    const size_t tile = (size_t)blockIdx.x * FIELD3_WAVES + wave;
+    const int lslot = half * 128 + (lane & 31);
 
     WeightStreamT<2, FIELD3_WAVES> ws;
     ws.start(a.packed3, lds, wave, lane, SAVE && valid);
@@ -57,15 +60,15 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
         } else if (m == 14) { e[28] = x0; e[29] = x1; }
         else { e[30] = x2; e[31] = 0.0f; }
     }
-    ActLayout al{};
+    ActLayout3 al{};
     if (SAVE) {
-        al = act_layout((size_t)P, (size_t)a.n_rays);
+        al = act_layout3((size_t)P, (size_t)a.n_rays);
         if (valid) {
-            float* eo = a.act + al.enc + (size_t)p * 64;
+            float* eo = a.act + al.enc + tile * (64 * 32) + (lane & 31);
 #pragma unroll
             for (int v = 0; v < 32; ++v) {
                 const int col = enc3slot(v, half);
-                if (col >= 0) eo[col] = e[v];
+                if (col >= 0) nt_store(eo + col * 32, e[v]);
             }
         }
     }
@@ -79,12 +82,15 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[16 * nb + r] = relu ? fmaxf(acc[nb][r], 0.0f) : acc[nb][r];
     };
-    // Saved rows of layer L are written while layer L+1 computes, a quarter (8 stores) after each of its 4 chunk
-    // acquires; the following acquire waits with a counted vmcnt so these stores stay in flight (acquire<N>).
-    constexpr int NQ = SAVE ? 8 : 0;            // stores per quarter
+    // Saved rows of layer L are written while layer L+1 computes, a quarter (32 stores) after each of its 4 chunk
+    // acquires; the following acquire waits with a counted vmcnt so these stores stay in flight (acquire<N>;
+    // the hardware counter holds 63).
+    constexpr int NQ = SAVE ? STORES_PER_QUARTER3 : 0;
+    constexpr int NQ2 = SAVE ? 63 : 0;          // two quarters issued back to back
+    const size_t layer_floats = pad32((size_t)P) * W;
     auto save_quarter = [&](auto part, size_t base_off, bool with_mask, int layer) {
         if (SAVE && valid) {
-            store_rows3_part<decltype(part)::value>(a.act + base_off + (size_t)p * W, h, half);
+            store_tile3<2 * decltype(part)::value, 2>(a.act + base_off + tile * (W * 32) + lslot, h);
             if (with_mask) save_mask3<128>(a.act + al.mask, layer, (size_t)P, (size_t)p, half, h);
         }
     };
@@ -100,12 +106,12 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
 #pragma unroll 1
     for (int l = 1; l < D; ++l) {
         load_bias3<8>(acc, bias + l * W, half);
-        const size_t prev_off = (size_t)(l - 1) * (size_t)P * W;          // al.h[l-1]
+        const size_t prev_off = (size_t)(l - 1) * layer_floats;             // al.h[l-1]
         const float* cur = ws.acquire();
         if (l == SKIP + 1) { mma3_chunk<8, 4, 0, 32>(acc, e, cur, lane); cur = ws.acquire(); }
-        save_quarter(Q0{}, prev_off, true, l - 1);                         // 8 rows + 1 mask store
+        save_quarter(Q0{}, prev_off, true, l - 1);                         // 32 row stores + 1 mask store
         mma3_chunk<8, 4, 0, 128>(acc, h, cur, lane);
-        cur = ws.template acquire<SAVE ? 9 : 0>();
+        cur = ws.template acquire<SAVE ? NQ + 1 : 0>();
         save_quarter(Q1{}, prev_off, false, 0);
         mma3_chunk<8, 4, 32, 128>(acc, h, cur, lane);
         cur = ws.template acquire<NQ>();
@@ -135,11 +141,11 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
     // ---- feature_linear (no activation); layer 7's rows are written meanwhile
     load_bias3<8>(acc, small_ptr(lds, SM_BFEAT), half);
     {
-        const size_t prev_off = (size_t)(D - 1) * (size_t)P * W;
+        const size_t prev_off = (size_t)(D - 1) * layer_floats;
         const float* cur = ws.acquire();
         save_quarter(Q0{}, prev_off, true, D - 1);
         mma3_chunk<8, 4, 0, 128>(acc, h, cur, lane);
-        cur = ws.template acquire<SAVE ? 9 : 0>();
+        cur = ws.template acquire<SAVE ? NQ + 1 : 0>();
         save_quarter(Q1{}, prev_off, false, 0);
         mma3_chunk<8, 4, 32, 128>(acc, h, cur, lane);
         cur = ws.template acquire<NQ>();
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int col = dir3slot(v, half);
-            if (col >= 0) dout[col] = dv[v];
+            if (col >= 0) nt_store(dout + col, dv[v]);
         }
     }
     f32x16 av[4];
@@ -182,11 +188,11 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
         save_quarter(Q0{}, al.feat, false, 0);
         save_quarter(Q1{}, al.feat, false, 0);
         mma3_chunk<4, 8, 0, 128>(av, h, cur, lane);
-        cur = ws.template acquire<2 * NQ>();
+        cur = ws.template acquire<NQ2>();
         save_quarter(Q2{}, al.feat, false, 0);
         save_quarter(Q3{}, al.feat, false, 0);
         mma3_chunk<4, 8, 64, 128>(av, h, cur, lane);
-        mma3_chunk<4, 2, 0, 16>(av, dv, ws.template acquire<2 * NQ>(), lane);
+        mma3_chunk<4, 2, 0, 16>(av, dv, ws.template acquire<NQ2>(), lane);
     }
     float hv[64];
 #pragma unroll
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[16 * nb + r] = fmaxf(av[nb][r], 0.0f);
     if (SAVE && valid) {
-        store_rows3<64>(a.act + al.hv + (size_t)p * WV, hv, half);
+        store_tile3<0, 4>(a.act + al.hv + tile * (WV * 32) + lslot, hv);
         save_mask3<64>(a.act + al.mask, D, (size_t)P, (size_t)p, half, hv);
     }
 

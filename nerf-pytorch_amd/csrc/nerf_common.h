@@ -204,4 +204,51 @@ constexpr int PTS_PER_WAVE3 = 32;
 constexpr int FIELD3_WAVES = 4;                                         // 256-thread workgroups, 1 wave / SIMD
 constexpr int PTS_PER_WG3 = PTS_PER_WAVE3 * FIELD3_WAVES;
 
+// ---- saved activations / deltas of the bf16x3 datapath: 32-POINT TILES, FEATURE-MAJOR INSIDE A TILE.
+// Element (point p, feature f) of an F-feature region lives at  (p >> 5) * F * 32 + f * 32 + (p & 31):
+//   * a wave of field_fwd3 / field_dgrad3 owns exactly one tile, and one store instruction writes one feature of its
+//     32 points per lane half = two full 128-byte lines (the point-major rows of the fp32 datapath would scatter
+//     64 x 16 B per instruction);
+//   * the weight-gradient GEMM contracts over points: a tile is its k-extent of 32, read as one contiguous block
+//     (16 B per lane, lane-linear) and every feature's 32 points land next to each other -- the MFMA fragment order.
+// Regions are sized for P rounded up to a tile; the pad points of the last tile are never written and never used.
+__host__ __device__ constexpr size_t pad32(size_t P) { return (P + 31) & ~(size_t)31; }
+__host__ __device__ inline size_t tile_index(size_t p, int F, int f) { return (p >> 5) * (size_t)(F * 32) + (size_t)f * 32 + (p & 31); }
+struct ActLayout3 {
+    size_t h[D], feat;  // tiles of 256 features
+    size_t hv;          // tiles of 128
+    size_t enc;         // tiles of 64 (canonical column order, feature 63 unused)
+    size_t dir;         // [N][32] per ray, row-major (written by the forward)
+    size_t dir_pt;      // tiles of 32: the same per point, expanded right before the weight-gradient GEMM
+    size_t mask;        // [9][P][2] x 128 ReLU sign bits in the lane order of field_fwd3 (9th = view branch)
+    size_t total;
+};
+__host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N) {
+    ActLayout3 a{};
+    const size_t Pp = pad32(P);
+    size_t o = 0;
+    for (int i = 0; i < D; ++i) { a.h[i] = o; o += Pp * W; }
+    a.feat = o; o += Pp * W;
+    a.hv = o;   o += Pp * WV;
+    a.enc = o;  o += Pp * 64;
+    a.dir = o;  o += N * 32;
+    a.dir_pt = o; o += Pp * 32;
+    o = (o + 3) & ~(size_t)3;
+    a.mask = o; o += (size_t)(D + 1) * P * 8;
+    a.total = o;
+    return a;
+}
+struct DeltaLayout3 { size_t h[D], feat, hv, graw, total; };     // graw: tiles of 4 = copy of d_raw (rgb3, sigma)
+__host__ __device__ inline DeltaLayout3 delta_layout3(size_t P) {
+    DeltaLayout3 a{};
+    const size_t Pp = pad32(P);
+    size_t o = 0;
+    for (int i = 0; i < D; ++i) { a.h[i] = o; o += Pp * W; }
+    a.feat = o; o += Pp * W;
+    a.hv = o;   o += Pp * WV;
+    a.graw = o; o += Pp * 4;
+    a.total = o;
+    return a;
+}
+
 }  // namespace nerf

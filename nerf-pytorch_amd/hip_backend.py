@@ -234,6 +234,24 @@ def act_floats(n_rays, n_samples):
     return lib().nerf_act_floats(n_rays, n_samples)
 
 
+def saved_rows(buf, P, region, precision="fp32"):
+    """Debug/test view of one saved region (activations or deltas) as a point-major [P, F] tensor.
+    region: "h0".."h7", "feat", "hv", "enc".  The fp32 datapath stores point-major rows (act_layout); the bf16x3
+    datapath stores 32-point feature-major tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32."""
+    tiled = precision == "bf16x3"
+    Pa = (P + 31) // 32 * 32 if tiled else P
+    widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
+    off = 0
+    for name, F in widths:
+        if name == region:
+            flat = buf[off:off + Pa * F]
+            if not tiled:
+                return flat.view(P, F)
+            return flat.view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
+        off += Pa * F
+    raise KeyError(region)
+
+
 def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     n, stride = rays.shape
     S = z_vals.shape[1]

@@ -404,13 +404,12 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     feats = torch.cat([orc.posenc(pts.reshape(-1, 3), 10), orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3), 4)], -1)
     _, hidden, feat, hv = orc.field_mlp(Pf, feats, return_hidden=True)
     act = act.cpu()
+    rows = lambda region: npa.hip_backend.saved_rows(act, P, region, "bf16x3")    # 32-point feature-major tiles
     for l in range(8):
-        got = act[l * P * 256:(l + 1) * P * 256].view(P, 256)
-        assert maxdiff(got, hidden[l]) <= 3e-4 * max(1.0, float(hidden[l].abs().max())), l
-    assert maxdiff(act[8 * P * 256:9 * P * 256].view(P, 256), feat) <= 3e-4 * max(1.0, float(feat.abs().max()))
-    assert maxdiff(act[9 * P * 256:9 * P * 256 + P * 128].view(P, 128), hv) <= 3e-4 * max(1.0, float(hv.abs().max()))
-    o = 9 * P * 256 + P * 128
-    assert maxdiff(act[o:o + P * 64].view(P, 64)[:, :63], feats[:, :63]) <= 5e-6
+        assert maxdiff(rows(f"h{l}"), hidden[l]) <= 3e-4 * max(1.0, float(hidden[l].abs().max())), l
+    assert maxdiff(rows("feat"), feat) <= 3e-4 * max(1.0, float(feat.abs().max()))
+    assert maxdiff(rows("hv"), hv) <= 3e-4 * max(1.0, float(hv.abs().max()))
+    assert maxdiff(rows("enc")[:, :63], feats[:, :63]) <= 5e-6
 
 
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192)])

@@ -32,10 +32,11 @@ def test_argument_errors_are_codes_not_crashes():
     assert b"null pointer" in L.nerf_last_error()
     assert L.nerf_field_fwd(None, None, 11, None, 4, 4, None, None, None) == -1
     assert L.nerf_act_floats(0, 64) == 0
-    n, S = 4096, 192
-    P = n * S
-    assert L.nerf_act_floats(n, S) == P * (9 * 256 + 128 + 64 + 32) + n * 32 + 9 * P * 8
-    assert L.nerf_delta_floats(n, S) == P * (9 * 256 + 128)
+    for n, S in ((4096, 192), (5, 3)):
+        P = n * S
+        Pp = (P + 31) // 32 * 32       # the bf16x3 datapath saves 32-point tiles; the sizes cover both layouts
+        assert L.nerf_act_floats(n, S) == Pp * (9 * 256 + 128 + 64 + 32) + n * 32 + 9 * P * 8 + (-(Pp * 32 + n * 32) % 4)
+        assert L.nerf_delta_floats(n, S) == Pp * (9 * 256 + 128 + 4)
     assert L.nerf_wgrad_partial_floats(n, S) % 595844 == 0
 
 

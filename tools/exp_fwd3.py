@@ -27,3 +27,6 @@ if "--bwd" in sys.argv:
     d_raw = torch.randn(N, 192, 4, device=dev); delta = torch.empty(L.nerf_delta_floats(N, 192), device=dev)
     g = lambda: L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), s)
     f(act.data_ptr()); print("   dgrad3 %.3f ms" % timeit(g), flush=True)
+    partial = torch.empty(L.nerf_wgrad_partial_floats(N, 192), device=dev); grad = torch.empty(595844, device=dev)
+    w = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 1, ph, s)
+    print("   wgrad3 %.3f ms  (+reduce %.3f ms)" % (timeit(lambda: w(1)), timeit(lambda: w(4))), flush=True)
