@@ -74,6 +74,8 @@ def kernel_table(kern, precision):
         sec = v["ms"] * 1e-3
         fp32_kernel = precision == "fp32" or k.startswith(("wgrad_kernel", "wgrad_reduce"))
         k_issued, k_peak = (1.0, PEAK_FP32_MFMA_TFLOPS) if fp32_kernel else (issued, peak)
+        if k.startswith(("field_dgrad3_kernel<mixed>", "wgrad1_kernel")):      # single bf16 MFMA per product
+            k_issued = 1.0
         tfl = v["flops"] / sec / 1e12
         gbs = v["bytes"] / sec / 1e9
         out[k] = {"launches": v["launches"], "avg_ms": v["ms"] / v["launches"], "total_ms": v["ms"],
@@ -130,10 +132,12 @@ def main():
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--rays", type=int, default=N_RAND, help="rays per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=os.environ.get("NERF_BENCH_PRECISION", "bf16x3"),
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "mixed"], default=os.environ.get("NERF_BENCH_PRECISION", "bf16x3"),
                     help="headline field datapath: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate; PSNR delta vs the "
                          "reference 2e-5 dB, tests/test_gpu_parity.py) or exact fp32 MFMA (the parity anchor). The other "
-                         "datapath is measured too (fewer steps) and reported in the same JSON line.")
+                         "datapath is measured too (fewer steps) and reported in the same JSON line, and so is the "
+                         "mixed-precision training option (bf16x3 forward + bf16 backward; 'mixed'), which is never the "
+                         "default headline because its gradients are bf16-rounded.")
     ap.add_argument("--single-datapath", action="store_true", help="skip the secondary datapath measurement")
     args = ap.parse_args()
 
@@ -217,9 +221,9 @@ def main():
             infer_step(i)
         barrier()
         other = n * world * max(5, args.steps // 2) / (time.perf_counter() - t1)
-    second = None
+    second = second_mixed = None
     if not args.single_datapath:
-        p2 = "fp32" if args.precision == "bf16x3" else "bf16x3"
+        p2 = "bf16x3" if args.precision == "fp32" else "fp32"
         k2 = max(4, args.steps // 4)
         el2, kern2 = measure(p2, k2, 2)
         tab2 = kernel_table(kern2, p2)
@@ -227,6 +231,15 @@ def main():
                   "steps": k2, "ms_per_step": 1e3 * el2 / k2, "roofline": roofline_of(tab2),
                   "kernels": {k: {"avg_ms": v["avg_ms"], "mfma_frac": v["mfma_frac"], "hbm_frac": v["hbm_frac"]}
                               for k, v in tab2.items()}}
+        if args.mode == "train" and args.precision != "mixed":
+            k3 = max(4, args.steps // 2)
+            el3, kern3 = measure("mixed", k3, 2)
+            tab3 = kernel_table(kern3, "mixed")
+            second_mixed = {"dtype": "bf16x3 forward (outputs identical to the headline datapath) + bf16 backward (saved activations / "
+                                     "deltas rounded to bf16, one bf16 MFMA per product, f32 accumulate)",
+                            "value": n * world * k3 / el3, "unit": "rays/s", "steps": k3, "ms_per_step": 1e3 * el3 / k3,
+                            "kernels": {k: {"avg_ms": v["avg_ms"], "mfma_frac": v["mfma_frac"], "hbm_frac": v["hbm_frac"]}
+                                        for k, v in tab3.items()}}
         npa.set_precision(args.precision)
 
     if rank == 0:
@@ -251,7 +264,8 @@ def main():
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-bf16 MFMA products, f32 accumulate/activations/gradients)",
+            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products, f32 accumulate/activations/gradients)",
+                      "mixed": "bf16x3 forward + bf16 backward (mixed-precision training option)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"lego-like 400x400, N_rand={n} rays/GPU x (64 coarse + 128 fine) samples, "
                                    "two 8x256 networks, perturb=1, white_bkgd; step = render + MSE + backward"
@@ -265,6 +279,8 @@ def main():
             line["inference_rays_per_s"] = other
         if second is not None:
             line["other_datapath"] = second
+        if second_mixed is not None:
+            line["mixed_precision_training"] = second_mixed
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

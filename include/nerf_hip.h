@@ -127,12 +127,25 @@ int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float*
                             float* delta, void* stream);
 int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                             float* partial, float* grad, int accumulate, void* stream);
+/* ---- mixed-precision training variant: the forward is the split-bf16 datapath unchanged (same raw, bit for bit), but
+ * what it saves for the backward is rounded to bf16 (same tiles, 2-byte elements), and the backward runs on single
+ * bf16 MFMA products with fp32 accumulation: dgrad = W_hi^T * delta_hi, wgrad = delta_bf16^T * x_bf16 streamed straight
+ * from HBM into the MFMA (no conversion).  Halves the saved-activation traffic and cuts the backward's matrix work to
+ * a third; rendered outputs are identical to bf16x3, gradients carry bf16 rounding noise (~2^-9 relative per element,
+ * cosine to the fp64 gradient >= 0.999).  act / delta of one evaluation must stay within this variant. */
+int nerf_field_fwd_mixed(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                         int n_samples, float* raw, float* act, void* stream);
+int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
+                           float* delta, void* stream);
+int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
+                           float* partial, float* grad, int accumulate, void* stream);
 /* nerf_field_wgrad / nerf_field_wgrad_bf16x3 split into their three launches so that a profiler can bracket each:
  * phases bit 0 = the eight full-width (256x256) jobs (bf16x3: all 14 jobs), bit 1 = the six narrow jobs (fp32 datapath
  * only), bit 2 = reduction of the per-chunk partial gradients into grad.  Calling it with phases 1, 2, 4 in that order
  * equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                           float* partial, float* grad, int accumulate, int bf16x3, int phases, void* stream);
+                           float* partial, float* grad, int accumulate, int bf16x3 /* 0 fp32, 1 bf16x3, 2 mixed */,
+                           int phases, void* stream);
 /* ---- optimizer.step() of run_nerf.py:776 for torch.optim.Adam(lr, betas=(beta1, beta2), eps) (run_nerf.py:207), fused over
  * a flat vector: params / grads / exp_avg / exp_avg_sq [n]; step = 1-based step count (bias correction). */
 int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,

@@ -176,9 +176,9 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate, int bf16x3, int phases, void* stream) {
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7, "bad size");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && bf16x3 >= 0 && bf16x3 <= 2, "bad size");
     return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate,
-                                                   bf16x3 ? 1 : 0, phases, (hipStream_t)stream));
+                                                   bf16x3, phases, (hipStream_t)stream));
 }
 
 int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
@@ -188,7 +188,25 @@ int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float*
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
             "packed/act/d_raw/delta must be 16-byte aligned");
-    return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, (hipStream_t)stream));
+    return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, 0, (hipStream_t)stream));
+}
+
+int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
+                           float* delta, void* stream) {
+    REQUIRE(packed3 && act && d_raw && delta, "null pointer");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
+            "packed/act/d_raw/delta must be 16-byte aligned");
+    return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, 1, (hipStream_t)stream));
+}
+
+int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
+                           float* partial, float* grad, int accumulate, void* stream) {
+    REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 2, 7,
+                                                   (hipStream_t)stream));
 }
 
 int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
@@ -220,7 +238,18 @@ int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_strid
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
-    return done(__func__, nerf::launch_field_fwd3(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act,
+    return done(__func__, nerf::launch_field_fwd3(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, 0,
+                                                  (hipStream_t)stream));
+}
+
+int nerf_field_fwd_mixed(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                         int n_samples, float* raw, float* act, void* stream) {
+    REQUIRE(packed3 && rays && z_vals && raw && act, "null pointer");
+    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
+    return done(__func__, nerf::launch_field_fwd3(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, 1,
                                                   (hipStream_t)stream));
 }
 

@@ -543,6 +543,162 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ mixed-precision weight gradients (bf16 operands)
+// Same 14 jobs, operands saved as bf16 in the same 32-point feature-major tiles (64-byte rows): a lane's MFMA
+// fragment (8 consecutive points of one feature = 16 B) is in memory as is, so the kernel is pure streaming:
+// HBM -> LDS by DMA into a ring of 4 stages (one stage = one 32-point tile of both operands = 32 KiB = 32
+// wave-instructions of global_load_lds_dwordx4, three stages = 96 KiB per CU in flight), ds_read_b128, one bf16 MFMA
+// per product, fp32 accumulation.  No VALU conversion, no staging registers; 11.4 KB per point instead of 22.7.
+// Every DMA lane picks its own 16-byte source piece, which XOR-swizzles the four pieces of a row inside its 64 LDS
+// bytes: the fragment reads are bank-conflict free.  Bias gradients = fp32 row sums of the delta fragments.
+constexpr int WG1_STAGE_PTS = 32;
+constexpr int WG1_OP_BYTES = 256 * 64;                           // 16 KiB: [256 features][32 points] bf16
+constexpr int WG1_STAGE_BYTES = 2 * WG1_OP_BYTES;
+constexpr int WG1_STAGES = 4;
+constexpr int WG1_LDS_BYTES = WG1_STAGES * WG1_STAGE_BYTES;      // 128 KiB
+
+__device__ inline void dma_1k_s(const void* sbase, unsigned voff, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst_uniform)
+        : "memory");
+}
+__device__ inline float sum_bf16x8(u32x4 w) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += __uint_as_float(w[i] << 16) + __uint_as_float(w[i] & 0xffff0000u);
+    return s;
+}
+
+__global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm1[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_n = wave >> 2, wave_k = wave & 3;
+    const int ji = blockIdx.x % a.n_jobs;
+    const int chunk = blockIdx.x / a.n_jobs;
+    const WgradJob& jb = a.job[ji];
+    const long p_begin = (long)chunk * a.chunk_pts;              // multiple of 32: chunks start on a tile
+    const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
+    const int nrows = (int)(p_end - p_begin);
+    const int n_st = (nrows + WG1_STAGE_PTS - 1) / WG1_STAGE_PTS;
+
+    // DMA role: waves 0-3 copy delta (A), waves 4-7 the input (B); instruction u of a wave copies LDS pieces
+    // [64*m, 64*m + 64) of its operand, m = 4*(wave&3) + u; LDS piece 4*f + jj holds points 8*(jj ^ swz(f))..+7 of
+    // feature f, swz(f) = (f >> 2) & 3.  jb.A / jb.B point at bf16 data, lda / ldb = features per tile.
+    const int sop = wave >> 2;
+    const int swidth = sop == 0 ? jb.nA : jb.nB;
+    const int sld = sop == 0 ? jb.lda : jb.ldb;
+    const unsigned tile_bytes = 64u * (unsigned)sld;
+    const char* cbase = reinterpret_cast<const char*>(sop == 0 ? jb.A : jb.B) + (size_t)(p_begin >> 5) * tile_bytes;
+    unsigned doff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = 64 * (4 * (wave & 3) + u) + lane;
+        const int f = q >> 2, jj = q & 3;
+        doff[u] = 64u * (unsigned)min(f, swidth - 1) + 16u * (unsigned)(jj ^ ((f >> 2) & 3));
+    }
+    const unsigned lds0 = lds_addr(sm1) + (unsigned)(sop * WG1_OP_BYTES + (wave & 3) * 4096);
+    auto issue = [&](int st) {
+        const char* src = cbase + (size_t)st * tile_bytes;
+        const unsigned dst = lds0 + (unsigned)(st & 3) * WG1_STAGE_BYTES;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dma_1k_s(src, doff[u], dst + 1024u * u);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float rowsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int row = lane & 31, hf = lane >> 5;
+    const int ni = min(4, (jb.nA - wave_n * 128 + 31) / 32);     // 32-row output blocks of this wave that hold real rows
+    const int nj = min(2, (jb.nB - wave_k * 64 + 31) / 32);
+    const bool wave_has_work = ni > 0 && nj > 0;
+    const bool want_bias = jb.bias_off >= 0 && wave_k == 0;
+    const int fswz = (row >> 2) & 3;
+    // the lane's fragment of k-step t (points 16*t + 8*hf .. +7) = source piece 2*t + hf of feature `row` of a block
+    const int frag[2] = {row * 64 + ((hf ^ fswz) << 4), row * 64 + (((2 + hf) ^ fswz) << 4)};
+    auto fragment = [&](const unsigned char* blk, int t, int left) {       // left: points of this stage < P
+        u32x4 w = *reinterpret_cast<const u32x4*>(blk + frag[t]);
+        if (left < WG1_STAGE_PTS) {         // ragged last stage of the last chunk: the pad points were never written
+            const int p0 = 16 * t + 8 * hf;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                w[d] &= (p0 + 2 * d < left ? 0x0000ffffu : 0u) | (p0 + 2 * d + 1 < left ? 0xffff0000u : 0u);
+        }
+        return w;
+    };
+    auto compute = [&](int st) {
+        if (!wave_has_work) return;
+        const unsigned char* stage = sm1 + (st & 3) * WG1_STAGE_BYTES;
+        const unsigned char* sa = stage + (wave_n * 128) * 64;
+        const unsigned char* sb = stage + WG1_OP_BYTES + (wave_k * 64) * 64;
+        const int left = nrows - st * WG1_STAGE_PTS;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = fragment(sb + j * 32 * 64, t, left);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i >= ni) break;
+                const u32x4 af = fragment(sa + i * 32 * 64, t, left);
+                if (want_bias) rowsum[i] += sum_bf16x8(af);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af, bf[j], acc[i][j]);
+            }
+        }
+    };
+
+    // ring: stages st+1 .. st+3 are in flight while st is consumed.  vmcnt retires in order: "at most 4 * (younger
+    // stages in flight) outstanding" = this wave's pieces of st have landed
+#pragma unroll
+    for (int st = 0; st < WG1_STAGES - 1; ++st)
+        if (st < n_st) issue(st);
+    for (int st = 0; st < n_st; ++st) {
+        if (st + 2 < n_st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (st + 1 < n_st) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();        // every wave's pieces landed; everybody is done with stage st-1, whose slot is reused now
+        if (st + WG1_STAGES - 1 < n_st) issue(st + WG1_STAGES - 1);
+        compute(st);
+    }
+
+    // acc[i][j][r] at lane (col = lane&31, hf) = dW[wave_n*128 + 32*i + d32row(r, hf)][wave_k*64 + 32*j + col]
+    float* out = a.partial + (size_t)chunk * N_PARAMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = wave_n * 128 + 32 * i + d32row(r, hf);
+            if (n < jb.nA) {
+                float* orow = out + jb.c_off + (size_t)n * jb.ldc;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = wave_k * 64 + 32 * j + row;
+                    if (k < jb.nB) orow[k] = acc[i][j][r];
+                }
+            }
+        }
+    if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = rowsum[i] + __shfl_xor(rowsum[i], 32);
+            const int n = wave_n * 128 + 32 * i + row;
+            if (hf == 0 && n < jb.nA) out[jb.bias_off + n] = t;
+        }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N_PARAMS) return;
@@ -609,10 +765,27 @@ __global__ void expand_dir_tiles_kernel(const float* __restrict__ dir_ray, f32x4
     }
     dir_pt[i] = v;
 }
+// ... and with bf16 elements (mixed-precision backward): thread = (tile, feature, 8-point group)
+__global__ void expand_dir_tiles_bf16_kernel(const float* __restrict__ dir_ray, u32x4* __restrict__ dir_pt, long P, int S) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n_tiles = (P + 31) >> 5;
+    if (i >= n_tiles * 128) return;
+    const long tile = i >> 7;
+    const int f = (int)(i >> 2) & 31, g = (int)i & 3;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const long p = min(tile * 32 + 8 * g + e, P - 1);
+        v[e] = dir_ray[(p / S) * 32 + f];
+    }
+    dir_pt[i] = pack8(v);
+}
 
 // phases: bit 0 = full-width jobs, bit 1 = narrow jobs, bit 2 = chunk reduction (7 = everything)
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
                               float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream) {
+    // bf16x3: 0 = fp32 datapath, 1 = split-bf16 datapath, 2 = mixed-precision backward (bf16 operands, one MFMA per product)
+    const bool mixed = bf16x3 == 2;
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     hipError_t e;
@@ -625,13 +798,22 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         const ActLayout3 al = act_layout3((size_t)P, (size_t)n_rays);
         const DeltaLayout3 dl = delta_layout3((size_t)P);
         for (int l = 0; l < D; ++l) { d_h[l] = delta + dl.h[l]; x_h[l] = act + al.h[l]; }
-        d_feat = delta + dl.feat; d_hv = delta + dl.hv; d_rgb = delta + dl.graw; d_sigma = delta + dl.graw + 3 * 32;
+        d_feat = delta + dl.feat; d_hv = delta + dl.hv; d_rgb = delta + dl.graw;
+        // feature 3 of the 4-wide tile: 3 rows of 32 fp32 (bf16x3) or 32 bf16 (mixed, same region, 2-byte elements)
+        d_sigma = mixed ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(delta + dl.graw) + 3 * 32)
+                        : delta + dl.graw + 3 * 32;
         x_feat = act + al.feat; x_hv = act + al.hv; x_enc = act + al.enc; x_dir = act + al.dir_pt;
         ld_graw = 4;
         if (phases & 1) {   // act is written by the forward; the expanded copy is scratch inside the same buffer
-            const long n_thr = ((P + 31) >> 5) * 256;
-            hipLaunchKernelGGL(expand_dir_tiles_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,
-                               act + al.dir, reinterpret_cast<f32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
+            if (mixed) {
+                const long n_thr = ((P + 31) >> 5) * 128;
+                hipLaunchKernelGGL(expand_dir_tiles_bf16_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,
+                                   act + al.dir, reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
+            } else {
+                const long n_thr = ((P + 31) >> 5) * 256;
+                hipLaunchKernelGGL(expand_dir_tiles_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,
+                                   act + al.dir, reinterpret_cast<f32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
+            }
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
@@ -705,13 +887,22 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    static bool attr3_set = false;
-    if (bf16x3 && !attr3_set) {
+    static bool attr1_set = false, attr3_set = false;
+    if (mixed && !attr1_set) {
+        e = hipFuncSetAttribute((const void*)wgrad1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG1_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr1_set = true;
+    }
+    if (bf16x3 == 1 && !attr3_set) {
         e = hipFuncSetAttribute((const void*)wgrad3_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr3_set = true;
     }
-    if (big.n_jobs > 0 && bf16x3 && (phases & 1)) {
+    if (big.n_jobs > 0 && mixed && (phases & 1)) {
+        hipLaunchKernelGGL(wgrad1_kernel, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    } else if (big.n_jobs > 0 && bf16x3 && (phases & 1)) {
         hipLaunchKernelGGL(wgrad3_256_kernel, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG3_LDS_BYTES, stream, big);
         e = hipGetLastError();
         if (e != hipSuccess) return e;

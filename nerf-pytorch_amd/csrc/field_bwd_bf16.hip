@@ -25,6 +25,9 @@ __device__ inline void apply_mask3(float (&d)[NV], const f32x16* acc, u32x4 m) {
     }
 }
 
+// MIXED = mixed-precision backward: single bf16 product W_hi^T * delta_hi per term (the lo fragments of the same
+// weight stream are skipped) and bf16 deltas in HBM; otherwise the split-bf16 (3-term) chain with fp32 deltas
+template <bool MIXED>
 __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBwd3Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -45,9 +48,16 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     const int lslot = half * 128 + (lane & 31);
     const f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);       // (d_rgb3, d_sigma)
     if (valid) {        // tile-major copy of d_raw: the A operand of the rgb_linear / alpha_linear weight gradients
-        float* gt = a.delta + dl.graw + tile * (4 * 32) + half * 64 + (lane & 31);
-        nt_store(gt, half ? g[2] : g[0]);
-        nt_store(gt + 32, half ? g[3] : g[1]);
+        const size_t goff = tile * (4 * 32) + half * 64 + (lane & 31);
+        if (MIXED) {
+            __bf16* gt = reinterpret_cast<__bf16*>(a.delta + dl.graw) + goff;
+            nt_store(gt, (__bf16)(half ? g[2] : g[0]));
+            nt_store(gt + 32, (__bf16)(half ? g[3] : g[1]));
+        } else {
+            float* gt = a.delta + dl.graw + goff;
+            nt_store(gt, half ? g[2] : g[0]);
+            nt_store(gt + 32, half ? g[3] : g[1]);
+        }
     }
     u32x4 msk[D + 1];
     {
@@ -92,17 +102,33 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
     auto store_q = [&](auto part, size_t off) {
-        if (valid) store_tile3<2 * decltype(part)::value, 2>(a.delta + off + tile * (W * 32) + lslot, d);
+        if (!valid) return;
+        if (MIXED) store_tile3h<2 * decltype(part)::value, 2>(reinterpret_cast<__bf16*>(a.delta + off) + tile * (W * 32) + lslot, d);
+        else store_tile3<2 * decltype(part)::value, 2>(a.delta + off + tile * (W * 32) + lslot, d);
     };
+    auto mma_h = [&](auto voff, const float* cur) {          // 4 k-steps of the 128-value operand d
+        if (MIXED) mma1_chunk<8, 4, decltype(voff)::value, 128>(acc, d, cur, lane);
+        else mma3_chunk<8, 4, decltype(voff)::value, 128>(acc, d, cur, lane);
+    };
+    using V0 = std::integral_constant<int, 0>; using V32 = std::integral_constant<int, 32>;
+    using V64 = std::integral_constant<int, 64>; using V96 = std::integral_constant<int, 96>;
 
     // ---- views_linears.0^T (feature columns): 128 -> 256
     zero_acc();
     {
         const float* cur = ws.acquire();
-        if (valid) store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);   // 64 stores
-        mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
+        if (valid) {                                                                  // 64 stores
+            if (MIXED) store_tile3h<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32) + lslot, dhv);
+            else store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);
+        }
+        if (MIXED) mma1_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
+        else mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
     }
-    mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<63>(), lane);
+    {
+        const float* cur = ws.template acquire<63>();
+        if (MIXED) mma1_chunk<8, 4, 32, 64>(acc, dhv, cur, lane);
+        else mma3_chunk<8, 4, 32, 64>(acc, dhv, cur, lane);
+    }
 #pragma unroll
     for (int i = 0; i < 128; ++i) d[i] = acc[i >> 4][i & 15];
 
@@ -121,16 +147,16 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     {
         const float* cur = ws.acquire();
         store_q(Q0{}, dl.feat);
-        mma3_chunk<8, 4, 0, 128>(acc, d, cur, lane);
+        mma_h(V0{}, cur);
         cur = ws.template acquire<NQ>();
         store_q(Q1{}, dl.feat);
-        mma3_chunk<8, 4, 32, 128>(acc, d, cur, lane);
+        mma_h(V32{}, cur);
         cur = ws.template acquire<NQ>();
         store_q(Q2{}, dl.feat);
-        mma3_chunk<8, 4, 64, 128>(acc, d, cur, lane);
+        mma_h(V64{}, cur);
         cur = ws.template acquire<NQ>();
         store_q(Q3{}, dl.feat);
-        mma3_chunk<8, 4, 96, 128>(acc, d, cur, lane);
+        mma_h(V96{}, cur);
     }
     apply_mask3<128>(d, acc, msk[D - 1]);
 
@@ -141,37 +167,43 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         const size_t off = (size_t)l * pad32(P) * W;                       // dl.h[l]: delta of layer l = input of this step
         const float* cur = ws.acquire();
         store_q(Q0{}, off);
-        mma3_chunk<8, 4, 0, 128>(acc, d, cur, lane);
+        mma_h(V0{}, cur);
         cur = ws.template acquire<NQ>();
         store_q(Q1{}, off);
-        mma3_chunk<8, 4, 32, 128>(acc, d, cur, lane);
+        mma_h(V32{}, cur);
         cur = ws.template acquire<NQ>();
         store_q(Q2{}, off);
-        mma3_chunk<8, 4, 64, 128>(acc, d, cur, lane);
+        mma_h(V64{}, cur);
         cur = ws.template acquire<NQ>();
         store_q(Q3{}, off);
-        mma3_chunk<8, 4, 96, 128>(acc, d, cur, lane);
+        mma_h(V96{}, cur);
         u32x4 m = msk[0];
 #pragma unroll
         for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];
         apply_mask3<128>(d, acc, m);
     }
-    if (valid) store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);   // dl.h[0]
+    if (valid) {                                                           // dl.h[0]
+        if (MIXED) store_tile3h<0, 8>(reinterpret_cast<__bf16*>(a.delta) + tile * (W * 32) + lslot, d);
+        else store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);
+    }
 }
 
 hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
-                               float* delta, hipStream_t stream) {
+                               float* delta, int mixed, hipStream_t stream) {
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)field_dgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     FieldBwd3Args ba{packed3, act, d_raw, delta, n_rays, S};
     const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
-    hipLaunchKernelGGL(field_dgrad3_kernel, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
+    if (mixed) hipLaunchKernelGGL(field_dgrad3_kernel<true>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
+    else hipLaunchKernelGGL(field_dgrad3_kernel<false>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
     return hipGetLastError();
 }
 

@@ -56,6 +56,29 @@ __device__ inline void mma3_chunk(f32x16 (&acc)[NB], const float (&v)[NV], const
     }
 }
 
+// ---- single-term variants for the mixed-precision backward ("bf16x3 forward + bf16 backward"): W_hi * x_hi only
+__device__ inline u32x4 pack8(const float* v) {
+    return u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+}
+// same fragment stream as mma3_kstep (hi, lo interleaved per block), the lo fragments are skipped
+template <int NB>
+__device__ inline void mma1_kstep(f32x16 (&acc)[NB], const u32x4 bhi, const u32x4* kbase) {
+#pragma unroll
+    for (int g = 0; g < NB; g += 4) {
+        u32x4 ahi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ahi[i] = kbase[((g + i) * 2) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g + i] = mfma_bf16(ahi[i], bhi, acc[g + i]);
+    }
+}
+template <int NB, int KS, int VOFF, int NV>
+__device__ inline void mma1_chunk(f32x16 (&acc)[NB], const float (&v)[NV], const float* lbuf, int lane) {
+    const u32x4* a = reinterpret_cast<const u32x4*>(lbuf) + lane;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) mma1_kstep<NB>(acc, pack8(&v[VOFF + 8 * s]), a + s * (NB * 2 * 64));
+}
+
 template <int NB>
 __device__ inline void load_bias3(f32x16 (&acc)[NB], const float* bias, int half) {
 #pragma unroll
@@ -78,6 +101,15 @@ __device__ inline void store_tile3(float* tp, const float (&v)[NV]) {
     for (int ob = OB0; ob < OB0 + NOB; ++ob)
 #pragma unroll
         for (int r = 0; r < 16; ++r) nt_store(tp + (32 * ob + (r & 3) + 8 * (r >> 2)) * 32, v[16 * ob + r]);
+}
+// the same tile layout with bf16 (RNE) elements: what the mixed-precision backward reads.  tp = (bf16*)region + the
+// same element offset as store_tile3
+template <int OB0, int NOB, int NV>
+__device__ inline void store_tile3h(__bf16* tp, const float (&v)[NV]) {
+#pragma unroll
+    for (int ob = OB0; ob < OB0 + NOB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nt_store(tp + (32 * ob + (r & 3) + 8 * (r >> 2)) * 32, (__bf16)v[16 * ob + r]);
 }
 constexpr int STORES_PER_QUARTER3 = 32;      // store_tile3<2*PART, 2>: a quarter of a 256-feature row set
 // ReLU sign bits of the lane's NV values -> act.mask[layer][p][half] (4 words; NV <= 128)

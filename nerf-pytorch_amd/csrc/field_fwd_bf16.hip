@@ -19,7 +19,9 @@ struct FieldFwd3Args {
     int ray_stride, n_rays, S;
 };
 
-template <bool SAVE>
+// SAVE: 0 = inference, 1 = save fp32 tiles (bf16x3 backward), 2 = save bf16 tiles (mixed-precision backward; the
+// arithmetic and raw are identical in all three)
+template <int SAVE>
 __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -64,11 +66,14 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
     if (SAVE) {
         al = act_layout3((size_t)P, (size_t)a.n_rays);
         if (valid) {
-            float* eo = a.act + al.enc + tile * (64 * 32) + (lane & 31);
+            const size_t eoff = tile * (64 * 32) + (lane & 31);
 #pragma unroll
             for (int v = 0; v < 32; ++v) {
                 const int col = enc3slot(v, half);
-                if (col >= 0) nt_store(eo + col * 32, e[v]);
+                if (col >= 0) {
+                    if (SAVE == 2) nt_store(reinterpret_cast<__bf16*>(a.act + al.enc) + eoff + col * 32, (__bf16)e[v]);
+                    else nt_store(a.act + al.enc + eoff + col * 32, e[v]);
+                }
             }
         }
     }
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
     const size_t layer_floats = pad32((size_t)P) * W;
     auto save_quarter = [&](auto part, size_t base_off, bool with_mask, int layer) {
         if (SAVE && valid) {
-            store_tile3<2 * decltype(part)::value, 2>(a.act + base_off + tile * (W * 32) + lslot, h);
+            if (SAVE == 2) store_tile3h<2 * decltype(part)::value, 2>(reinterpret_cast<__bf16*>(a.act + base_off) + tile * (W * 32) + lslot, h);
+            else store_tile3<2 * decltype(part)::value, 2>(a.act + base_off + tile * (W * 32) + lslot, h);
             if (with_mask) save_mask3<128>(a.act + al.mask, layer, (size_t)P, (size_t)p, half, h);
         }
     };
@@ -200,7 +206,8 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[16 * nb + r] = fmaxf(av[nb][r], 0.0f);
     if (SAVE && valid) {
-        store_tile3<0, 4>(a.act + al.hv + tile * (WV * 32) + lslot, hv);
+        if (SAVE == 2) store_tile3h<0, 4>(reinterpret_cast<__bf16*>(a.act + al.hv) + tile * (WV * 32) + lslot, hv);
+        else store_tile3<0, 4>(a.act + al.hv + tile * (WV * 32) + lslot, hv);
         save_mask3<64>(a.act + al.mask, D, (size_t)P, (size_t)p, half, hv);
     }
 
@@ -232,23 +239,27 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
 }
 
 hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
-                             int n_rays, int S, float* raw, float* act, hipStream_t stream) {
+                             int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream) {
     FieldFwd3Args a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S};
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)field_fwd3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
-        hipError_t e2 = hipFuncSetAttribute((const void*)field_fwd3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        hipError_t e0 = hipFuncSetAttribute((const void*)field_fwd3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        hipError_t e1 = hipFuncSetAttribute((const void*)field_fwd3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        hipError_t e2 = hipFuncSetAttribute((const void*)field_fwd3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        if (e0 != hipSuccess) return e0;
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         attr_set = true;
     }
-    if (act)
-        hipLaunchKernelGGL(field_fwd3_kernel<true>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
+    if (act && bf16_save)
+        hipLaunchKernelGGL(field_fwd3_kernel<2>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
+    else if (act)
+        hipLaunchKernelGGL(field_fwd3_kernel<1>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
     else
-        hipLaunchKernelGGL(field_fwd3_kernel<false>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
+        hipLaunchKernelGGL(field_fwd3_kernel<0>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
     return hipGetLastError();
 }
 

@@ -49,7 +49,7 @@ hipError_t launch_field_dgrad(const float* packed, const float* act, const float
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
                               float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream);
 hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
-                               float* delta, hipStream_t stream);
+                               float* delta, int mixed, hipStream_t stream);
 size_t wgrad_partial_floats(long P);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2, float eps, int step,
                        hipStream_t stream);
@@ -57,6 +57,6 @@ void pack_table_host(int* out);
 void pack3_table_host(int* out);
 hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream);
 hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
-                             int n_rays, int S, float* raw, float* act, hipStream_t stream);
+                             int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
 
 }  // namespace nerf

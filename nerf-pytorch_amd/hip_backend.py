@@ -51,6 +51,9 @@ def _declare(lib):
         "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p]),
         "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p]),
+        "nerf_field_fwd_mixed": (i, [p, p, i, p, i, i, p, p, p]),
+        "nerf_field_dgrad_mixed": (i, [p, p, p, i, i, p, p]),
+        "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p]),
         "nerf_adam_step": (i, [p, p, p, p, i, f, f, f, f, i, p]),
     }
     for name, (res, args) in sig.items():
@@ -65,7 +68,8 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
-           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_adam_step"]
+           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed",
+           "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step"]
 
 
 def lib():
@@ -182,7 +186,9 @@ def pack_table():
     return tab
 
 
-PRECISIONS = ("fp32", "bf16x3")
+# "mixed" = the bf16x3 forward (identical outputs) with a bf16 backward: saved activations / deltas rounded to bf16,
+# one bf16 MFMA per product in dgrad and wgrad (fp32 accumulation).  A training-speed option, not a parity datapath.
+PRECISIONS = ("fp32", "bf16x3", "mixed")
 
 
 def pack_table3():
@@ -202,7 +208,7 @@ def _small_offset():
 
 def pack_params(flat, out=None, precision="fp32"):
     L = lib()
-    if precision == "bf16x3":
+    if precision in ("bf16x3", "mixed"):
         if out is None:
             out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
         _check(L.nerf_pack_params_bf16x3(_ptr(flat, "params"), _ptr(out, "packed"), _stream()), "nerf_pack_params_bf16x3")
@@ -238,7 +244,7 @@ def saved_rows(buf, P, region, precision="fp32"):
     """Debug/test view of one saved region (activations or deltas) as a point-major [P, F] tensor.
     region: "h0".."h7", "feat", "hv", "enc".  The fp32 datapath stores point-major rows (act_layout); the bf16x3
     datapath stores 32-point feature-major tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32."""
-    tiled = precision == "bf16x3"
+    tiled = precision in ("bf16x3", "mixed")
     Pa = (P + 31) // 32 * 32 if tiled else P
     widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
     off = 0
@@ -247,6 +253,8 @@ def saved_rows(buf, P, region, precision="fp32"):
             flat = buf[off:off + Pa * F]
             if not tiled:
                 return flat.view(P, F)
+            if precision == "mixed":        # 2-byte elements in the first half of the region
+                flat = flat.view(torch.bfloat16)[:Pa * F].float()
             return flat.view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
         off += Pa * F
     raise KeyError(region)
@@ -258,7 +266,12 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
     act = torch.empty(act_floats(n, S), dtype=torch.float32, device=rays.device) if save_act else None
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
-    if precision == "bf16x3":
+    if precision == "mixed" and save_act:
+        with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD_PER_POINT * n * S, 0.5 * nbytes):
+            _check(lib().nerf_field_fwd_mixed(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                              n, S, _ptr(raw), _ptr(act, "act"), _stream()), "nerf_field_fwd_mixed")
+        return raw, act
+    if precision in ("bf16x3", "mixed"):
         with _timed("field_fwd3_kernel<save>" if save_act else "field_fwd3_kernel", FLOP_FWD_PER_POINT * n * S, nbytes):
             _check(lib().nerf_field_fwd_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                                n, S, _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd_bf16x3")
@@ -327,20 +340,29 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32"):
     delta = torch.empty(L.nerf_delta_floats(n, S), dtype=torch.float32, device=dev)
     partial = torch.empty(L.nerf_wgrad_partial_floats(n, S), dtype=torch.float32, device=dev)
     b3 = precision == "bf16x3"
+    mx = precision == "mixed"
     P = n * S
-    with _timed("field_dgrad3_kernel" if b3 else "field_dgrad_kernel", FLOP_DGRAD_PER_POINT * P, BYTES_DELTA_PER_POINT * P):
-        if b3:
-            _check(L.nerf_field_dgrad_bf16x3(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
-                                             _ptr(delta), _stream()), "nerf_field_dgrad_bf16x3")
-        else:
-            _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
-                                      _stream()), "nerf_field_dgrad")
+    if mx:
+        with _timed("field_dgrad3_kernel<mixed>", FLOP_DGRAD_PER_POINT * P, 0.5 * BYTES_DELTA_PER_POINT * P):
+            _check(L.nerf_field_dgrad_mixed(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
+                                            _ptr(delta), _stream()), "nerf_field_dgrad_mixed")
+    else:
+        with _timed("field_dgrad3_kernel" if b3 else "field_dgrad_kernel", FLOP_DGRAD_PER_POINT * P, BYTES_DELTA_PER_POINT * P):
+            if b3:
+                _check(L.nerf_field_dgrad_bf16x3(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
+                                                 _ptr(delta), _stream()), "nerf_field_dgrad_bf16x3")
+            else:
+                _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
+                                          _stream()), "nerf_field_dgrad")
     args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),
-            int(bool(accumulate)), int(b3))
+            int(bool(accumulate)), 2 if mx else int(b3))
     if TIMER is None:
         _check(L.nerf_field_wgrad_phase(*args, 7, _stream()), "nerf_field_wgrad_phase")
         return grad
-    if b3:      # all 14 jobs (full-width and narrow) run through the masked bf16x3 tile kernel
+    if mx:      # all 14 jobs stream bf16 operands straight into the MFMA
+        with _timed("wgrad1_kernel", FLOP_WGRAD_PER_POINT * P, 0.5 * (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT) * P):
+            _check(L.nerf_field_wgrad_phase(*args, 3, _stream()), "nerf_field_wgrad_phase")
+    elif b3:    # all 14 jobs (full-width and narrow) run through the masked bf16x3 tile kernel
         with _timed("wgrad3_256_kernel", FLOP_WGRAD_PER_POINT * P, (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT) * P):
             _check(L.nerf_field_wgrad_phase(*args, 3, _stream()), "nerf_field_wgrad_phase")
     else:

@@ -18,8 +18,10 @@ _PRECISION = __import__("os").environ.get("NERF_PRECISION", "fp32")
 
 
 def set_precision(mode):
-    """Select the field datapath: "fp32" (exact fp32 MFMA, the parity anchor) or "bf16x3" (split-bf16 MFMA,
-    fp32 accumulate, ~1e-5 relative error; judged by the PSNR-delta criterion)."""
+    """Select the field datapath: "fp32" (exact fp32 MFMA, the parity anchor), "bf16x3" (split-bf16 MFMA,
+    fp32 accumulate, ~1e-5 relative error; judged by the PSNR-delta criterion) or "mixed" (the bf16x3 forward,
+    bit-identical outputs, with a bf16 backward: saved activations / deltas rounded to bf16, single bf16 MFMA
+    products in dgrad / wgrad -- a mixed-precision training option)."""
     global _PRECISION
     if mode not in hb.PRECISIONS:
         raise ValueError(f"precision must be one of {hb.PRECISIONS}")

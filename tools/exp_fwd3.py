@@ -30,3 +30,11 @@ if "--bwd" in sys.argv:
     partial = torch.empty(L.nerf_wgrad_partial_floats(N, 192), device=dev); grad = torch.empty(595844, device=dev)
     w = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 1, ph, s)
     print("   wgrad3 %.3f ms  (+reduce %.3f ms)" % (timeit(lambda: w(1)), timeit(lambda: w(4))), flush=True)
+
+if "--mixed" in sys.argv:
+    fm = lambda: L.nerf_field_fwd_mixed(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, 192, raw.data_ptr(), act.data_ptr(), s)
+    print("   mixed: fwd<save bf16> %.3f ms" % timeit(fm), flush=True)
+    gm = lambda: L.nerf_field_dgrad_mixed(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), s)
+    print("   mixed: dgrad %.3f ms" % timeit(gm), flush=True)
+    wm = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 2, ph, s)
+    print("   mixed: wgrad1 %.3f ms" % timeit(lambda: wm(1)), flush=True)
