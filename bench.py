@@ -96,7 +96,15 @@ def pmc_traffic(kernel_name, precision):
             if line.startswith("#") or "," not in line:
                 continue
             kn, cn, _, val = line.rstrip().rsplit(",", 3)
-            if kn.replace("nerf::", "").split("<")[0] == key or (key in kn and ("<true>" in kn) == ("<save>" in kernel_name)):
+            base = kn.replace("void ", "").replace("nerf::", "")
+            tmpl = base.split("<")[1].split(">")[0] if "<" in base else ""
+            if base.split("<")[0].split("(")[0] != key:
+                continue
+            if key == "field_fwd3_kernel" and (tmpl in ("1", "true")) != ("<save>" in kernel_name):
+                continue
+            if key == "field_dgrad3_kernel" and (tmpl in ("1", "true")) != ("<mixed>" in kernel_name):
+                continue
+            if True:
                 if cn == "FETCH_SIZE":
                     fetch = float(val)
                 elif cn == "WRITE_SIZE":

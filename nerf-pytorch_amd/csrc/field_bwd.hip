@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
         const unsigned off0 = (unsigned)st * tile_bytes + 16u * (unsigned)sg;
 #pragma unroll
         for (int r = 0; r < WG3_ROUNDS; ++r)        // feature clamped into the operand: always inside the tile
-            dst[r] = *reinterpret_cast<const f32x4*>(cbase + (off0 + 128u * (unsigned)min(32 * r + sf0, sflast)));
+            dst[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(cbase + (off0 + 128u * (unsigned)min(32 * r + sf0, sflast))));
     };
     auto swrite_from = [&](const f32x4 (&src)[WG3_ROUNDS], int buf, int st) {
         unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + (st_t >> 3) * WG3_FEAT_BYTES + 8 * sg;

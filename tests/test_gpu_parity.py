@@ -526,9 +526,10 @@ def test_mixed_backward(npa, dev, nets, n_rays, S):
 
 
 def test_mixed_training_tracks_fp32(npa, dev):
-    """Forty Adam steps with the bf16 backward follow the fp32 datapath's loss curve: the early, unstable part of this
-    trajectory (the loss doubles and comes back within four steps) amplifies any gradient noise, so single steps are
-    compared loosely (10 %) and the settled tail tightly (mean of the last ten losses within 1 %)."""
+    """Forty Adam steps with the bf16 backward follow the fp32 datapath's loss curve step by step (measured: within
+    1e-3 relative; stated: 5e-3).  lr = 1e-4 keeps this scene in the stable regime: at the reference's 5e-4 the first
+    steps overshoot (the loss doubles and comes back) and that transient amplifies any perturbation -- there even the
+    fp32 and bf16x3 datapaths drift 4 % apart by step 40, which says nothing about gradient quality."""
     Pc, Pf = orc.scene_params(seed=2)
     kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
     losses = {}
@@ -537,7 +538,7 @@ def test_mixed_training_tracks_fp32(npa, dev):
     for prec in ("fp32", "mixed"):
         nc, nf = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
         nc.load_state_dict(Pc); nf.load_state_dict(Pf)
-        opt = torch.optim.Adam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4)
+        opt = torch.optim.Adam(list(nc.parameters()) + list(nf.parameters()), lr=1e-4)
         npa.set_precision(prec)
         try:
             out_l = []
@@ -552,11 +553,9 @@ def test_mixed_training_tracks_fp32(npa, dev):
             npa.set_precision("fp32")
         losses[prec] = out_l
     print("loss trajectories:", {k: [round(x, 5) for x in v] for k, v in losses.items()})
-    assert losses["fp32"][-1] < losses["fp32"][0]
+    assert losses["fp32"][-1] < 0.7 * losses["fp32"][0]
     for a, b in zip(losses["fp32"], losses["mixed"]):
-        assert abs(a - b) <= 1e-1 * abs(a), losses
-    tail = lambda v: sum(v[-10:]) / 10
-    assert abs(tail(losses["mixed"]) - tail(losses["fp32"])) <= 1e-2 * tail(losses["fp32"]), (tail(losses["mixed"]), tail(losses["fp32"]))
+        assert abs(a - b) <= 5e-3 * abs(a), losses
 
 
 def test_bf16x3_render_psnr_delta(npa, dev, nets):

@@ -1,6 +1,3 @@
 mkdir -p gpurun_out
-{ timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -8
-  timeout 300 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/bench_default.json; cut -c1-250 gpurun_out/bench_default.json
-  python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-} > gpurun_out/exp.log 2>&1
+timeout 300 python tools/exp_traj.py 2>&1 | grep -v amdgpu > gpurun_out/exp.log
 cat gpurun_out/exp.log
