@@ -60,6 +60,15 @@ int nerf_embed(const float* x, long n_pts, int n_freqs, float* out, void* stream
 int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int n_samples,
                        int lindisp, const float* t_rand, float* z_vals, void* stream);
 
+/* ---- ray set-up of render(c2w=...) (run_nerf.py:95-123): get_rays (run_nerf_helpers.py:153-162), normalised view
+ * directions (:100-107; taken from c2w even when c2w_staticcam supplies the rays), ndc_rays(H, W, K[0][0], 1., ...)
+ * (helpers:175-192) when ndc != 0, and the near / far columns, written as rays[H*W][ray_stride] records
+ * (o3, d3, near, far, viewdir3), pixel (row j, column i) at j*W + i.  K_host: HOST pointer to the 3x3 intrinsics,
+ * row-major; c2w_host / c2w_staticcam_host (nullable): HOST pointers to 3x4 row-major poses (they travel as kernel
+ * arguments; no device copy).  rays: device. */
+int nerf_make_rays(int H, int W, const float* K_host, const float* c2w_host, const float* c2w_staticcam_host, int ndc,
+                   float near, float far, float* rays, int ray_stride, void* stream);
+
 /* ---- network_query_fn(pts, viewdirs, network_fn) with pts = o + d*z
  * (run_nerf.py:381,385 -> run_network :37-51 -> Embedder :44-45 -> NeRF.forward helpers:96-119).
  * raw[n_rays][n_samples][4] = (rgb pre-sigmoid, sigma pre-relu).

@@ -66,6 +66,15 @@ int nerf_embed(const float* x, long n_pts, int n_freqs, float* out, void* stream
     return done(__func__, nerf::launch_embed(x, n_pts, n_freqs, out, (hipStream_t)stream));
 }
 
+int nerf_make_rays(int H, int W, const float* K_host, const float* c2w_host, const float* c2w_staticcam_host, int ndc,
+                   float near, float far, float* rays, int ray_stride, void* stream) {
+    REQUIRE(K_host && c2w_host && rays, "null pointer");
+    REQUIRE(H >= 0 && W >= 0 && ray_stride >= 11, "bad size");
+    REQUIRE(K_host[0] != 0.0f && K_host[4] != 0.0f, "K has a zero focal length");
+    return done(__func__, nerf::launch_make_rays(H, W, K_host, c2w_host, c2w_staticcam_host, ndc, near, far, rays,
+                                                 ray_stride, (hipStream_t)stream));
+}
+
 int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int n_samples,
                        int lindisp, const float* t_rand, float* z_vals, void* stream) {
     REQUIRE(rays && t_vals && z_vals, "null pointer");

@@ -235,6 +235,7 @@ __host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N) {
     a.dir_pt = o; o += Pp * 32;
     o = (o + 3) & ~(size_t)3;
     a.mask = o; o += (size_t)(D + 1) * P * 8;
+    o += 2048;          // slack for the weight-gradient staging's reads past a narrow operand's last tile
     a.total = o;
     return a;
 }
@@ -247,6 +248,7 @@ __host__ __device__ inline DeltaLayout3 delta_layout3(size_t P) {
     a.feat = o; o += Pp * W;
     a.hv = o;   o += Pp * WV;
     a.graw = o; o += Pp * 4;
+    o += 2048;          // the weight-gradient staging reads 64 rows of 128 B from a tile of this 4-row region
     a.total = o;
     return a;
 }

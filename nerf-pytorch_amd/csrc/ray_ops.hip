@@ -261,6 +261,55 @@ __global__ void embed_kernel(const float* __restrict__ x, long n_pts, int n_freq
     out[idx] = v;
 }
 
+// ------------------------------------------------------------------ ray set-up of render(c2w=...)
+// get_rays (run_nerf_helpers.py:153-162) + view directions (run_nerf.py:100-107) + ndc_rays (helpers:175-192) +
+// near / far columns (run_nerf.py:117-123) in one pass: pixel (j, i) -> rays[j*W + i][0..10] = (o3, d3, near, far,
+// viewdir3).  No [H,W,3] intermediates; the arithmetic follows the reference's operation order.
+struct RayGenArgs {
+    int H, W;
+    float fx, fy, cx, cy;
+    float pose[12];         // c2w[:3,:4] row-major
+    float pose_static[12];  // c2w_staticcam[:3,:4] (rays come from this camera, view directions from `pose`)
+    int has_static, ndc;
+    float near, far;
+    float* rays;
+    int stride;
+};
+__device__ inline void camera_ray(const float* m, float dx, float dy, float dz, float (&o)[3], float (&d)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d[k] = (dx * m[4 * k] + dy * m[4 * k + 1]) + dz * m[4 * k + 2];      // torch.sum(dirs[..., None, :] * c2w[:3,:3], -1)
+        o[k] = m[4 * k + 3];
+    }
+}
+__global__ void make_rays_kernel(RayGenArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)a.H * a.W) return;
+    const int j = (int)(idx / a.W), i = (int)(idx - (long)j * a.W);
+    const float dx = ((float)i - a.cx) / a.fx, dy = -((float)j - a.cy) / a.fy, dz = -1.0f;
+    float o[3], d[3];
+    camera_ray(a.pose, dx, dy, dz, o, d);
+    const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float v0 = d[0] / nrm, v1 = d[1] / nrm, v2 = d[2] / nrm;
+    if (a.has_static) camera_ray(a.pose_static, dx, dy, dz, o, d);
+    if (a.ndc) {            // ndc_rays(H, W, focal = K[0][0], near = 1.)
+        const float t = -(1.0f + o[2]) / d[2];
+        o[0] = o[0] + t * d[0];
+        o[1] = o[1] + t * d[1];
+        o[2] = o[2] + t * d[2];
+        const float sw = -1.0f / ((float)a.W / (2.0f * a.fx)), sh = -1.0f / ((float)a.H / (2.0f * a.fx));
+        const float n0 = sw * o[0] / o[2], n1 = sh * o[1] / o[2], n2 = 1.0f + 2.0f * 1.0f / o[2];
+        const float e0 = sw * (d[0] / d[2] - o[0] / o[2]), e1 = sh * (d[1] / d[2] - o[1] / o[2]), e2 = -2.0f * 1.0f / o[2];
+        o[0] = n0; o[1] = n1; o[2] = n2;
+        d[0] = e0; d[1] = e1; d[2] = e2;
+    }
+    float* r = a.rays + idx * a.stride;
+    r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+    r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
+    r[6] = a.near; r[7] = a.far;
+    r[8] = v0; r[9] = v1; r[10] = v2;
+}
+
 // ------------------------------------------------------------------ launchers
 hipError_t launch_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int S,
                                 int lindisp, const float* t_rand, float* z_out, hipStream_t stream) {
@@ -282,6 +331,20 @@ hipError_t launch_sample_fine(const FineArgs& a, hipStream_t stream) {
     if (a.n_rays <= 0) return hipSuccess;
     const size_t lds = (size_t)(3 * a.n_in + a.Nf) * sizeof(float);
     hipLaunchKernelGGL(sample_fine_kernel, dim3(a.n_rays), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_make_rays(int H, int W, const float* K9, const float* pose12, const float* pose_static12, int ndc,
+                            float near, float far, float* rays, int ray_stride, hipStream_t stream) {
+    const long n = (long)H * W;
+    if (n <= 0) return hipSuccess;
+    RayGenArgs a{};
+    a.H = H; a.W = W;
+    a.fx = K9[0]; a.cx = K9[2]; a.fy = K9[4]; a.cy = K9[5];
+    for (int i = 0; i < 12; ++i) { a.pose[i] = pose12[i]; a.pose_static[i] = pose_static12 ? pose_static12[i] : 0.0f; }
+    a.has_static = pose_static12 ? 1 : 0;
+    a.ndc = ndc; a.near = near; a.far = far; a.rays = rays; a.stride = ray_stride;
+    hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ def _declare(lib):
         "nerf_debug_pack_table": (i, [p]),
         "nerf_embed": (i, [p, l, i, p, p]),
         "nerf_sample_coarse": (i, [p, i, i, p, i, i, p, p, p]),
+        "nerf_make_rays": (i, [i, i, p, p, p, i, f, f, p, i, p]),
         "nerf_act_floats": (sz, [i, i]),
         "nerf_field_fwd": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_raw2outputs": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p, p]),
@@ -64,7 +65,7 @@ def _declare(lib):
 
 
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
-           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_sample_coarse", "nerf_act_floats", "nerf_field_fwd",
+           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_sample_coarse", "nerf_act_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
@@ -234,6 +235,24 @@ def sample_coarse(rays, t_vals, lindisp, t_rand):
     _check(lib().nerf_sample_coarse(_ptr(rays, "rays"), stride, n, _ptr(t_vals, "t_vals"), S, int(bool(lindisp)),
                                     _ptr(t_rand, "t_rand", True), _ptr(z), _stream()), "nerf_sample_coarse")
     return z
+
+
+def make_rays(H, W, K, c2w, c2w_staticcam, ndc, near, far, device):
+    """[H*W, 11] ray records of render(c2w=...) in one launch (get_rays + viewdirs + ndc_rays + near/far)."""
+    import numpy as np
+
+    def host(m, shape):
+        if m is None:
+            return None
+        if isinstance(m, torch.Tensor):
+            m = m.detach().cpu().numpy()
+        return np.ascontiguousarray(np.asarray(m, dtype=np.float32)[:shape[0], :shape[1]])
+    Kh, ph, sh = host(K, (3, 3)), host(c2w, (3, 4)), host(c2w_staticcam, (3, 4))
+    rays = torch.empty((H * W, 11), dtype=torch.float32, device=device)
+    as_p = lambda arr: None if arr is None else arr.ctypes.data_as(ctypes.c_void_p)
+    _check(lib().nerf_make_rays(int(H), int(W), as_p(Kh), as_p(ph), as_p(sh), int(bool(ndc)), float(near), float(far),
+                                _ptr(rays), 11, _stream()), "nerf_make_rays")
+    return rays
 
 
 def act_floats(n_rays, n_samples):

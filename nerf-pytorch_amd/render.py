@@ -417,25 +417,29 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
 
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
            c2w_staticcam=None, **kwargs):
-    """run_nerf.py:69-134: [rgb_map, disp_map, acc_map, extras]."""
-    if c2w is not None:
-        rays_o, rays_d = get_rays(H, W, K, c2w)
-    else:
-        rays_o, rays_d = rays
+    """run_nerf.py:69-134: [rgb_map, disp_map, acc_map, extras].  With c2w the ray records are built by one HIP
+    launch (get_rays + view directions + ndc_rays + near / far: SURVEY 8 f-2), no [H,W,3] intermediates."""
     if not use_viewdirs:
         raise NotImplementedError("render: use_viewdirs=False is not implemented on gfx950 (all BASELINE configs use it)")
-    viewdirs = rays_d
-    if c2w_staticcam is not None:
-        rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
-    viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
-    viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
-    sh = rays_d.shape
-    if ndc:
-        rays_o, rays_d = ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
-    rays_o = torch.reshape(rays_o, [-1, 3]).float()
-    rays_d = torch.reshape(rays_d, [-1, 3]).float()
-    near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
-    rays = torch.cat([rays_o, rays_d, near, far, viewdirs], -1)
+    if c2w is not None:
+        net = kwargs.get("network_fn")
+        dev = next(net.parameters()).device if net is not None else (c2w.device if isinstance(c2w, torch.Tensor) else None)
+        rays = hb.make_rays(H, W, K, c2w, c2w_staticcam, ndc, near, far, dev)
+        sh = (H, W, 3)
+    else:
+        rays_o, rays_d = rays
+        viewdirs = rays_d
+        if c2w_staticcam is not None:       # run_nerf.py:103-105
+            rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
+        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+        sh = rays_d.shape
+        if ndc:
+            rays_o, rays_d = ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+        rays_o = torch.reshape(rays_o, [-1, 3]).float()
+        rays_d = torch.reshape(rays_d, [-1, 3]).float()
+        near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+        rays = torch.cat([rays_o, rays_d, near, far, viewdirs], -1)
     all_ret = batchify_rays(rays, chunk, **kwargs)
     for k in all_ret:
         k_sh = list(sh[:-1]) + list(all_ret[k].shape[1:])
@@ -467,6 +471,64 @@ def _write_png(path, rgb8):
         f.write(png)
 
 
+class _FrameSink:
+    """Output side of render_path.  The reference blocks on `.cpu().numpy()` and encodes every frame on
+    the rendering thread (run_nerf.py:155-169).  Here frame i's device->host copies go to pinned memory asynchronously,
+    `to8b` runs on the device, and the PNG of frame i-1 is encoded by a worker thread while frame i+1 renders; the
+    returned arrays and files are the same."""
+
+    def __init__(self, savedir=None, workers=2):
+        self.savedir = savedir
+        self.rgbs, self.disps, self.jobs = [], [], []
+        self.pending = None
+        self.pool = None
+        if savedir is not None:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=workers)
+
+    @staticmethod
+    def _to_host(t):
+        if not t.is_cuda:
+            return t.detach().clone()
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t.detach(), non_blocking=True)
+        return h
+
+    def push(self, index, rgb, disp):
+        rgb8 = None
+        if self.savedir is not None:
+            rgb8 = self._to_host((255 * rgb.detach().clamp(0, 1)).to(torch.uint8))      # to8b (helpers:11) on the device
+        entry = (index, self._to_host(rgb), self._to_host(disp), rgb8)
+        event = None
+        if rgb.is_cuda:
+            event = torch.cuda.Event()
+            event.record()
+        self._finish()                      # the previous frame: its copies had a whole frame time to land
+        self.pending = (entry, event)
+
+    def _finish(self):
+        if self.pending is None:
+            return
+        (index, rgb, disp, rgb8), event = self.pending
+        self.pending = None
+        if event is not None:
+            event.synchronize()
+        self.rgbs.append(rgb.numpy())
+        self.disps.append(disp.numpy())
+        if rgb8 is not None:
+            import os
+            path = os.path.join(self.savedir, '{:03d}.png'.format(index))
+            self.jobs.append(self.pool.submit(_write_png, path, rgb8.numpy()))
+
+    def close(self):
+        self._finish()
+        for j in self.jobs:
+            j.result()                      # re-raises an encoder / IO error
+        if self.pool is not None:
+            self.pool.shutdown()
+        return np.stack(self.rgbs, 0), np.stack(self.disps, 0)
+
+
 def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
     """run_nerf.py:137-175: (rgbs[F,H,W,3], disps[F,H,W]) as numpy."""
     import os
@@ -475,11 +537,9 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
         H = H // render_factor
         W = W // render_factor
         focal = focal / render_factor
-    rgbs, disps = [], []
+    sink = _FrameSink(savedir)
     for i, c2w in enumerate(render_poses):
         rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
-        rgbs.append(rgb.cpu().numpy())
-        disps.append(disp.cpu().numpy())
-        if savedir is not None:
-            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
-    return np.stack(rgbs, 0), np.stack(disps, 0)
+        sink.push(i, rgb, disp)
+    return sink.close()
+

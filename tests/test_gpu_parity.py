@@ -686,6 +686,59 @@ def test_render_boundary_and_chunking(npa, dev, nets):
     assert maxdiff(got2.reshape(7, 5, 4), ref) <= 2e-4 * max(1.0, float(ref.abs().max()) / 10)
 
 
+@pytest.mark.parametrize("ndc", [False, True])
+@pytest.mark.parametrize("static", [False, True])
+def test_make_rays_matches_reference_ray_setup(npa, dev, ndc, static):
+    """One launch = get_rays + view directions + ndc_rays + near / far of render(c2w=...) (run_nerf.py:95-123).
+    Same operation order as the reference; stated 2e-6 relative (torch's 3-term sums / norm may associate differently)."""
+    H, W, focal = 19, 23, 31.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal * 1.1, 0.5 * H], [0, 0, 1]], dtype=np.float32)
+    c2w = torch.tensor([[0.96, 0.0, 0.28, 0.1], [0.0, 1.0, 0.0, -0.2], [-0.28, 0.0, 0.96, 0.4]])
+    c2w_s = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, 0.8, -0.6, 0.1], [0.0, 0.6, 0.8, 0.3]]) if static else None
+    near, far = (0., 1.) if ndc else (2., 6.)
+    got = npa.hip_backend.make_rays(H, W, K, c2w, c2w_s, ndc, near, far, dev).cpu()
+    ro, rd = orc.pinhole_rays(H, W, K, c2w)
+    view = rd / torch.norm(rd, dim=-1, keepdim=True)
+    if static:
+        ro, rd = orc.pinhole_rays(H, W, K, c2w_s)
+    if ndc:
+        ro, rd = orc.ndc_warp(H, W, K[0][0], 1., ro, rd)
+    want = torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), torch.full((H * W, 1), near), torch.full((H * W, 1), far),
+                      view.reshape(-1, 3)], -1).float()
+    assert got.shape == (H * W, 11)
+    scale = want.abs().amax(0).clamp_min(1.0)
+    assert float(((got - want).abs() / scale).max()) <= 2e-6
+    assert torch.equal(got[:, 6:8], want[:, 6:8])
+
+
+def test_render_path_overlapped_output(npa, dev, nets, tmp_path):
+    """render_path (run_nerf.py:137-175): frames rendered from poses, device-side to8b, asynchronous copies and PNG
+    encoding on worker threads -- arrays and files equal to the synchronous formulation."""
+    nc, nf, Pc, Pf = nets
+    H, W, focal = 10, 12, 15.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    poses = torch.stack([torch.tensor([[1.0, 0, 0, 0.1 * i], [0, 0.8, -0.6, 0.2], [0, 0.6, 0.8, 4.0], [0, 0, 0, 1.0]]) for i in range(3)]).to(dev)
+    kw = dict(network_fn=nc, network_query_fn=None, N_samples=64, N_importance=128, network_fine=nf, perturb=0.,
+              white_bkgd=True, raw_noise_std=0., ndc=False, near=2., far=6., use_viewdirs=True)
+    with torch.no_grad():
+        rgbs, disps = npa.render_path(poses, (H, W, focal), K, 1 << 15, kw, savedir=str(tmp_path))
+        one = npa.render(H, W, K, chunk=1 << 15, c2w=poses[1][:3, :4], **kw)
+    assert rgbs.shape == (3, H, W, 3) and disps.shape == (3, H, W) and rgbs.dtype == np.float32
+    assert np.array_equal(rgbs[1], one[0].cpu().numpy()) and np.array_equal(disps[1], one[1].cpu().numpy(), equal_nan=True)
+    import zlib, struct
+    for i in range(3):
+        data = open(tmp_path / f"{i:03d}.png", "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat = 8, b""
+        while pos < len(data):
+            n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+            if tag == b"IDAT":
+                idat += data[pos + 8:pos + 8 + n]
+            pos += 12 + n
+        rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(H, 1 + 3 * W)
+        assert np.array_equal(rows[:, 1:].reshape(H, W, 3), npa.to8b(rgbs[i]))
+
+
 def test_training_step_moves_parameters_like_the_oracle(npa, dev):
     """Two Adam steps through the drop-in surface == two Adam steps of the oracle."""
     Pc, Pf = orc.scene_params(seed=1)

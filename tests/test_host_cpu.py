@@ -35,8 +35,8 @@ def test_argument_errors_are_codes_not_crashes():
     for n, S in ((4096, 192), (5, 3)):
         P = n * S
         Pp = (P + 31) // 32 * 32       # the bf16x3 datapath saves 32-point tiles; the sizes cover both layouts
-        assert L.nerf_act_floats(n, S) == Pp * (9 * 256 + 128 + 64 + 32) + n * 32 + 9 * P * 8 + (-(Pp * 32 + n * 32) % 4)
-        assert L.nerf_delta_floats(n, S) == Pp * (9 * 256 + 128 + 4)
+        assert L.nerf_act_floats(n, S) == Pp * (9 * 256 + 128 + 64 + 32) + n * 32 + 9 * P * 8 + (-(Pp * 32 + n * 32) % 4) + 2048
+        assert L.nerf_delta_floats(n, S) == Pp * (9 * 256 + 128 + 4) + 2048
     assert L.nerf_wgrad_partial_floats(n, S) % 595844 == 0
 
 
@@ -189,3 +189,21 @@ def test_sample_ray_batch_matches_get_rays_on_the_selected_pixels():
     crop = rd[H // 2 - dH:H // 2 + dH, W // 2 - dW:W // 2 + dW].reshape(-1, 3)
     for n in range(32):
         assert ((crop - rays2[1][n]).abs().sum(-1) < 1e-6).any()
+
+
+def test_frame_sink_orders_frames_and_writes_the_same_pngs(tmp_path):
+    """render_path's output side (f-4) on host tensors: worker-thread PNGs == synchronous writer, frames in order."""
+    import sys
+    R = sys.modules[npa.render.__module__]      # the module (the package exports the function under the same name)
+    g = torch.Generator().manual_seed(3)
+    frames = [(torch.rand(9, 7, 3, generator=g) * 1.4 - 0.2, torch.rand(9, 7, generator=g)) for _ in range(5)]
+    sink = R._FrameSink(str(tmp_path))
+    for i, (rgb, disp) in enumerate(frames):
+        sink.push(i, rgb, disp)
+    rgbs, disps = sink.close()
+    assert rgbs.shape == (5, 9, 7, 3) and disps.shape == (5, 9, 7)
+    for i, (rgb, disp) in enumerate(frames):
+        assert np.array_equal(rgbs[i], rgb.numpy()) and np.array_equal(disps[i], disp.numpy())
+        ref = tmp_path / f"ref{i}.png"
+        R._write_png(str(ref), R.to8b(rgb.numpy()))
+        assert open(tmp_path / f"{i:03d}.png", "rb").read() == open(ref, "rb").read()
