@@ -38,8 +38,8 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     const bool valid = p_raw < P;
     const size_t p = valid ? p_raw : P - 1;
 
-    WeightStreamT<3, FIELD3_WAVES> ws;
-    ws.start(a.packed3 + P3B_VIEWS, lds, wave, lane, valid);
+    WeightStreamT<MIXED ? 4 : 3, FIELD3_WAVES> ws;       // MIXED: the hi-only stream, 8 k-steps per 64 KiB chunk
+    ws.start(a.packed3 + (MIXED ? P1B : P3B_VIEWS), lds, wave, lane, valid);
     stage_small_from(a.packed3 + P3_SMALL, lds, FIELD3_WAVES * 64);
 
     const ActLayout3 al = act_layout3(P, (size_t)a.n_rays);
@@ -106,34 +106,9 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         if (MIXED) store_tile3h<2 * decltype(part)::value, 2>(reinterpret_cast<__bf16*>(a.delta + off) + tile * (W * 32) + lslot, d);
         else store_tile3<2 * decltype(part)::value, 2>(a.delta + off + tile * (W * 32) + lslot, d);
     };
-    auto mma_h = [&](auto voff, const float* cur) {          // 4 k-steps of the 128-value operand d
-        if (MIXED) mma1_chunk<8, 4, decltype(voff)::value, 128>(acc, d, cur, lane);
-        else mma3_chunk<8, 4, decltype(voff)::value, 128>(acc, d, cur, lane);
-    };
     using V0 = std::integral_constant<int, 0>; using V32 = std::integral_constant<int, 32>;
     using V64 = std::integral_constant<int, 64>; using V96 = std::integral_constant<int, 96>;
-
-    // ---- views_linears.0^T (feature columns): 128 -> 256
-    zero_acc();
-    {
-        const float* cur = ws.acquire();
-        if (valid) {                                                                  // 64 stores
-            if (MIXED) store_tile3h<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32) + lslot, dhv);
-            else store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);
-        }
-        if (MIXED) mma1_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
-        else mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
-    }
-    {
-        const float* cur = ws.template acquire<63>();
-        if (MIXED) mma1_chunk<8, 4, 32, 64>(acc, dhv, cur, lane);
-        else mma3_chunk<8, 4, 32, 64>(acc, dhv, cur, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < 128; ++i) d[i] = acc[i >> 4][i & 15];
-
-    // ---- feature_linear^T + alpha_linear^T, ReLU mask of layer 7
-    {
+    auto load_alpha = [&]() {           // acc = alpha_linear^T * d_sigma (the feature_linear^T contraction adds to it)
         const float* wa = small_ptr(lds, SM_WALPHA);
 #pragma unroll
         for (int ob = 0; ob < 8; ++ob)
@@ -143,44 +118,98 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ob][4 * q4 + r] = g[3] * w[r];
             }
-    }
-    {
-        const float* cur = ws.acquire();
-        store_q(Q0{}, dl.feat);
-        mma_h(V0{}, cur);
-        cur = ws.template acquire<NQ>();
-        store_q(Q1{}, dl.feat);
-        mma_h(V32{}, cur);
-        cur = ws.template acquire<NQ>();
-        store_q(Q2{}, dl.feat);
-        mma_h(V64{}, cur);
-        cur = ws.template acquire<NQ>();
-        store_q(Q3{}, dl.feat);
-        mma_h(V96{}, cur);
-    }
-    apply_mask3<128>(d, acc, msk[D - 1]);
+    };
 
-    // ---- trunk: delta_{l-1} = (W_l^T delta_l) * relu'(h_{l-1}),  l = 7 .. 1
-#pragma unroll 1
-    for (int l = D - 1; l >= 1; --l) {
+    if constexpr (MIXED) {
+        // one 64 KiB chunk = 8 k-steps of the hi-only stream: views^T is one chunk, every 256-wide contraction two;
+        // half of the input's rows (64 stores) go out after each acquire
         zero_acc();
-        const size_t off = (size_t)l * pad32(P) * W;                       // dl.h[l]: delta of layer l = input of this step
-        const float* cur = ws.acquire();
-        store_q(Q0{}, off);
-        mma_h(V0{}, cur);
-        cur = ws.template acquire<NQ>();
-        store_q(Q1{}, off);
-        mma_h(V32{}, cur);
-        cur = ws.template acquire<NQ>();
-        store_q(Q2{}, off);
-        mma_h(V64{}, cur);
-        cur = ws.template acquire<NQ>();
-        store_q(Q3{}, off);
-        mma_h(V96{}, cur);
-        u32x4 m = msk[0];
+        {
+            const float* cur = ws.acquire();
+            if (valid) store_tile3h<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32) + lslot, dhv);
+            mma1_chunk<8, 8, 0, 0, 64>(acc, dhv, cur, lane);
+        }
 #pragma unroll
-        for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];
-        apply_mask3<128>(d, acc, m);
+        for (int i = 0; i < 128; ++i) d[i] = acc[i >> 4][i & 15];
+        load_alpha();
+        {
+            const float* cur = ws.template acquire<63>();
+            store_q(Q0{}, dl.feat); store_q(Q1{}, dl.feat);
+            mma1_chunk<8, 8, 0, 0, 128>(acc, d, cur, lane);
+            cur = ws.template acquire<63>();
+            store_q(Q2{}, dl.feat); store_q(Q3{}, dl.feat);
+            mma1_chunk<8, 8, 0, 64, 128>(acc, d, cur, lane);
+        }
+        apply_mask3<128>(d, acc, msk[D - 1]);
+#pragma unroll 1
+        for (int l = D - 1; l >= 1; --l) {
+            zero_acc();
+            const size_t off = (size_t)l * pad32(P) * W;                       // dl.h[l]
+            const float* cur = ws.template acquire<63>();
+            store_q(Q0{}, off); store_q(Q1{}, off);
+            mma1_chunk<8, 8, 0, 0, 128>(acc, d, cur, lane);
+            cur = ws.template acquire<63>();
+            store_q(Q2{}, off); store_q(Q3{}, off);
+            mma1_chunk<8, 8, 0, 64, 128>(acc, d, cur, lane);
+            u32x4 m = msk[0];                   // ReLU bitmask of h_{l-1} (static indices only: msk stays in registers)
+#pragma unroll
+            for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];
+            apply_mask3<128>(d, acc, m);
+        }
+    } else {
+        auto mma_h = [&](auto voff, const float* cur) { mma3_chunk<8, 4, decltype(voff)::value, 128>(acc, d, cur, lane); };
+
+        // ---- views_linears.0^T (feature columns): 128 -> 256
+        zero_acc();
+        {
+            const float* cur = ws.acquire();
+            if (valid) store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);   // 64 stores
+            mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
+        }
+        mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<63>(), lane);
+#pragma unroll
+        for (int i = 0; i < 128; ++i) d[i] = acc[i >> 4][i & 15];
+
+        // ---- feature_linear^T + alpha_linear^T, ReLU mask of layer 7
+        load_alpha();
+        {
+            const float* cur = ws.acquire();
+            store_q(Q0{}, dl.feat);
+            mma_h(V0{}, cur);
+            cur = ws.template acquire<NQ>();
+            store_q(Q1{}, dl.feat);
+            mma_h(V32{}, cur);
+            cur = ws.template acquire<NQ>();
+            store_q(Q2{}, dl.feat);
+            mma_h(V64{}, cur);
+            cur = ws.template acquire<NQ>();
+            store_q(Q3{}, dl.feat);
+            mma_h(V96{}, cur);
+        }
+        apply_mask3<128>(d, acc, msk[D - 1]);
+
+        // ---- trunk: delta_{l-1} = (W_l^T delta_l) * relu'(h_{l-1}),  l = 7 .. 1
+#pragma unroll 1
+        for (int l = D - 1; l >= 1; --l) {
+            zero_acc();
+            const size_t off = (size_t)l * pad32(P) * W;                   // dl.h[l]: delta of layer l = input of this step
+            const float* cur = ws.acquire();
+            store_q(Q0{}, off);
+            mma_h(V0{}, cur);
+            cur = ws.template acquire<NQ>();
+            store_q(Q1{}, off);
+            mma_h(V32{}, cur);
+            cur = ws.template acquire<NQ>();
+            store_q(Q2{}, off);
+            mma_h(V64{}, cur);
+            cur = ws.template acquire<NQ>();
+            store_q(Q3{}, off);
+            mma_h(V96{}, cur);
+            u32x4 m = msk[0];                   // ReLU bitmask of h_{l-1} (static indices only: msk stays in registers)
+#pragma unroll
+            for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];
+            apply_mask3<128>(d, acc, m);
+        }
     }
     if (valid) {                                                           // dl.h[0]
         if (MIXED) store_tile3h<0, 8>(reinterpret_cast<__bf16*>(a.delta) + tile * (W * 32) + lslot, d);

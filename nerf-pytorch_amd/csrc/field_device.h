@@ -97,12 +97,13 @@ __device__ inline const float* small_ptr(const float* lds, int sm_offset) {
 }
 
 // chunk sizes (32-bit words) of the four weight streams, in consumption order
-//   MODE 0: fp32 forward   1: fp32 backward   2: bf16x3 forward   3: bf16x3 backward
+//   MODE 0: fp32 forward   1: fp32 backward   2: bf16x3 forward   3: bf16x3 backward   4: hi-only backward (mixed)
 template <int MODE>
 __device__ constexpr int stream_chunk_words(int c) {
     if (MODE == 0) return fwd_chunk_floats(c);
     if (MODE == 1) return bwd_chunk_floats(c);
     if (MODE == 2) return c < 36 ? CHUNK_FLOATS : (c == 36 ? KS3_DIR * KSTEP3_W4 : 0);   // 34 full + views 2 x 8 k-steps + 2 k-steps
+    if (MODE == 4) return c < 17 ? CHUNK_FLOATS : 0;                                    // views^T 1 | feat^T 2 | L7..L1 14
     return c < 34 ? CHUNK_FLOATS : 0;                                                  // views^T 2 | feat^T 4 | L7..L1 28
 }
 

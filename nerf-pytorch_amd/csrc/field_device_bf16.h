@@ -60,23 +60,24 @@ __device__ inline void mma3_chunk(f32x16 (&acc)[NB], const float (&v)[NV], const
 __device__ inline u32x4 pack8(const float* v) {
     return u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
 }
-// same fragment stream as mma3_kstep (hi, lo interleaved per block), the lo fragments are skipped
+// hi-only fragment stream (nerf_common.h, P1B): k-step = NB blocks x 64 lanes x 16 B
 template <int NB>
 __device__ inline void mma1_kstep(f32x16 (&acc)[NB], const u32x4 bhi, const u32x4* kbase) {
 #pragma unroll
     for (int g = 0; g < NB; g += 4) {
         u32x4 ahi[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ahi[i] = kbase[((g + i) * 2) * 64];
+        for (int i = 0; i < 4; ++i) ahi[i] = kbase[(g + i) * 64];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[g + i] = mfma_bf16(ahi[i], bhi, acc[g + i]);
     }
 }
-template <int NB, int KS, int VOFF, int NV>
+// KS k-steps starting at k-step K0 of the chunk in lbuf, B operands v[VOFF + 8*s ..]
+template <int NB, int KS, int K0, int VOFF, int NV>
 __device__ inline void mma1_chunk(f32x16 (&acc)[NB], const float (&v)[NV], const float* lbuf, int lane) {
-    const u32x4* a = reinterpret_cast<const u32x4*>(lbuf) + lane;
+    const u32x4* a = reinterpret_cast<const u32x4*>(lbuf) + lane + K0 * (NB * 64);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) mma1_kstep<NB>(acc, pack8(&v[VOFF + 8 * s]), a + s * (NB * 2 * 64));
+    for (int s = 0; s < KS; ++s) mma1_kstep<NB>(acc, pack8(&v[VOFF + 8 * s]), a + s * (NB * 64));
 }
 
 template <int NB>

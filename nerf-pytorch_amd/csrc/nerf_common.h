@@ -197,7 +197,13 @@ constexpr int P3B_FEAT = P3B_VIEWS + KS3_HV * KSTEP3_W8;
 constexpr int P3B_L7 = P3B_FEAT + KS3_H * KSTEP3_W8;                    // then L6 .. L1
 constexpr int P3B_END = P3B_L7 + 7 * KS3_H * KSTEP3_W8;
 constexpr int P3_SMALL = P3B_END;                                       // fp32 small parameters, same order as SM_*
-constexpr int PACKED3_WORDS = P3_SMALL + (PACKED_FLOATS - SM_BIAS);
+// hi-only copy of the transposed streams (mixed-precision dgrad: W_hi^T * delta_hi needs no lo fragments, and half
+// the L2 -> LDS weight traffic is what that kernel is bound by): k-step = 8 blocks x 64 lanes x 16 B
+constexpr int KSTEP1_W8 = 8 * 64 * 4;                                   // 2048 words = 8 KiB
+constexpr int P1B_KSTEPS = KS3_HV + KS3_H + 7 * KS3_H;                  // views^T 8 | feat^T 16 | L7^T..L1^T 7 x 16 = 136
+constexpr int P1B = P3_SMALL + (PACKED_FLOATS - SM_BIAS);
+constexpr int PACKED3_WORDS = P1B + P1B_KSTEPS * KSTEP1_W8;
+static_assert(P1B % 4 == 0 && (P1B_KSTEPS * KSTEP1_W8) % 16384 == 0, "hi-only stream: whole 64 KiB chunks");
 static_assert(P3F_VIEWS % 4096 == 0 && P3B_VIEWS % 4 == 0, "chunk alignment");
 
 constexpr int PTS_PER_WAVE3 = 32;

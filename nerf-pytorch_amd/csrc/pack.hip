@@ -148,12 +148,23 @@ void pack3_table_host(int* out) {
     for (int e = 0; e < 2 * P3B_END; ++e) { int lo; const int s = pack3_source(e, &lo); out[e] = s < 0 ? -1 : 2 * s + lo; }
 }
 
+// hi-only copy of the transposed (hi, lo) streams: 16-byte fragment (k-step s, block nb, lane) of P3B -> P1B
+__global__ void pack3_hi_only_kernel(float* __restrict__ packed) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P1B_KSTEPS * 8 * 64) return;
+    const int s = idx >> 9, nb = (idx >> 6) & 7, lane = idx & 63;
+    const u32x4_t* src = reinterpret_cast<const u32x4_t*>(packed + P3B_VIEWS) + ((s * 16 + nb * 2) * 64 + lane);
+    reinterpret_cast<u32x4_t*>(packed + P1B)[idx] = *src;
+}
+
 hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream) {
     const int threads = 256;
     hipLaunchKernelGGL(pack3_params_kernel, dim3((2 * P3B_END + threads - 1) / threads), dim3(threads), 0, stream,
                        canon_params, reinterpret_cast<unsigned short*>(packed));
     hipLaunchKernelGGL(pack3_small_kernel, dim3((PACKED_FLOATS - SM_BIAS + threads - 1) / threads), dim3(threads), 0, stream,
                        canon_params, packed);
+    hipLaunchKernelGGL(pack3_hi_only_kernel, dim3((P1B_KSTEPS * 8 * 64 + threads - 1) / threads), dim3(threads), 0, stream, packed);
     return hipGetLastError();
 }
 

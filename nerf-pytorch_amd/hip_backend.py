@@ -196,7 +196,9 @@ def pack_table3():
     """Host-side gather table of the split-bf16 repack: per 16-bit element 2*canonical_index + is_lo, -1 = padding."""
     import numpy as np
     L = lib()
-    n16 = 2 * (L.nerf_packed3_floats() - (L.nerf_packed_floats() - _small_offset()))
+    # packed3 = (hi, lo) fragment streams | fp32 small parameters | hi-only copy of the transposed streams (136 k-steps
+    # x 2048 words, csrc/nerf_common.h P1B); the table covers the fragment streams
+    n16 = 2 * (L.nerf_packed3_floats() - (L.nerf_packed_floats() - _small_offset()) - 136 * 2048)
     tab = np.empty(n16, dtype=np.int32)
     _check(L.nerf_debug_pack3_table(tab.ctypes.data_as(ctypes.c_void_p)), "nerf_debug_pack3_table")
     return tab
