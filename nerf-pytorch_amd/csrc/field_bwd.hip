@@ -493,10 +493,12 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
             }
         }
     };
-    // Two stages of operands in flight in registers (rv, rw): the loads issued in one half-iteration are consumed by
-    // the write-back of the next one, i.e. they have a full compute phase plus a barrier to land.  The steady-state
-    // loop is branch-free (a conditional load makes hipcc drain vmcnt before the next batch of loads, which would
-    // leave a single stage in flight); the last stages run through the guarded tail loop.
+    // Two register sets (rv, rw): the loads issued in one half-iteration are consumed by the write-back of the next
+    // one, i.e. they have a full compute phase plus a barrier to land.  Known limit: because the loads below are
+    // guarded, hipcc's waitcnt insertion drains vmcnt(0) before each new batch, so effectively one batch is in flight.
+    // A branch-free variant with two batches really in flight (16-point stages, counted vmcnt, no spills) was built and
+    // measured: same speed -- the kernel is paced by its MFMA issue + conversion VALU + barriers, not by load latency
+    //  -- so the simpler form with clamped, always-in-bounds addresses stays.
     f32x4 rv[WG3_ROUNDS], rw[WG3_ROUNDS];
     gload_into(rv, 0);
     swrite_from(rv, 0, 0);
