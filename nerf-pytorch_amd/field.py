@@ -118,7 +118,8 @@ class NeRF(nn.Module):
     def packed_params(self, precision="fp32"):
         """Fragment repack of the current parameters for the given datapath (cached on the parameters' versions)."""
         flat = self.flat_params()
-        key = tuple(p._version for p in self.parameters()) + (flat.data_ptr(),)
+        # torch-side updates advance the parameters' version counters; the fused Adam kernel advances hb.PARAM_EPOCH
+        key = tuple(p._version for p in self.parameters()) + (flat.data_ptr(), hb.PARAM_EPOCH)
         if self._packed is None or key != self._packed_key:
             self._packed = {}
             self._packed_key = key

@@ -396,8 +396,15 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32"):
     return grad
 
 
+# Bumped by every raw-pointer update of parameters (the fused Adam kernel writes through data_ptr(), which does not
+# advance the tensors' autograd version counters): NeRF.packed_params() keys its fragment-repack cache on it.
+PARAM_EPOCH = 0
+
+
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     """In-place fused Adam over flat fp32 vectors (one launch)."""
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
     n = params.numel()
     _check(lib().nerf_adam_step(_ptr(params, "params"), _ptr(grads, "grads"), _ptr(exp_avg, "exp_avg"),
                                 _ptr(exp_avg_sq, "exp_avg_sq"), n, float(lr), float(beta1), float(beta2), float(eps),

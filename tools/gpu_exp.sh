@@ -1,6 +1,5 @@
 mkdir -p gpurun_out
-{ timeout 200 python tools/exp_fwd3.py - --bwd --mixed 2>&1 | grep -v amdgpu
-  timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "mixed or bf16x3 or ragged" 2>&1 | tail -5
-  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --single-datapath --precision mixed 2>&1 | tail -1 > gpurun_out/b.json; cut -c1-200 gpurun_out/b.json
+{ timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "fused_adam" 2>&1 | tail -4
+  timeout 400 python tools/exp_converge.py 2>&1 | grep -v amdgpu
 } > gpurun_out/exp.log 2>&1
 cat gpurun_out/exp.log
