@@ -119,7 +119,8 @@ class NeRF(nn.Module):
         """Fragment repack of the current parameters for the given datapath (cached on the parameters' versions)."""
         flat = self.flat_params()
         # torch-side updates advance the parameters' version counters; the fused Adam kernel advances hb.PARAM_EPOCH
-        key = tuple(p._version for p in self.parameters()) + (flat.data_ptr(), hb.PARAM_EPOCH)
+        # (and in-place torch ops on the flat vector itself, e.g. the DP parameter broadcast, advance flat._version)
+        key = tuple(p._version for p in self.parameters()) + (flat.data_ptr(), flat._version, hb.PARAM_EPOCH)
         if self._packed is None or key != self._packed_key:
             self._packed = {}
             self._packed_key = key
