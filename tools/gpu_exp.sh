@@ -1,5 +1,3 @@
 mkdir -p gpurun_out
-{ timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -4
-  timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/b.json; cut -c1-220 gpurun_out/b.json
-} > gpurun_out/exp.log 2>&1
+timeout 300 python tools/exp_render_path.py 2>&1 | grep -v amdgpu > gpurun_out/exp.log
 cat gpurun_out/exp.log
