@@ -128,6 +128,13 @@ int nerf_packed3_floats(void);
 int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream);
 int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                           int n_samples, float* raw, float* act, void* stream);
+/* inference-only form of nerf_field_fwd_bf16x3 (same arithmetic class: 3 bf16 MFMAs per product, fp32 accumulate):
+ * 16 points per wavefront at 2 waves / SIMD instead of 32 at 1, which hides the LDS latency the saving kernel
+ * leaves exposed.  Sums the products in a different order, so it agrees with nerf_field_fwd_bf16x3 to rounding
+ * (~1e-5 of |raw|), not bit for bit.  nerf_debug_pack16_table: host gather table of its fragment stream (tests). */
+int nerf_field_infer_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                            int n_samples, float* raw, void* stream);
+int nerf_debug_pack16_table(int* out_host);
 /* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  dgrad also leaves a tiled
  * copy of d_raw inside delta, which is what wgrad contracts with: nerf_field_wgrad_bf16x3 must be given the delta
  * buffer of nerf_field_dgrad_bf16x3 for the same d_raw (its own d_raw argument is not read).  All 14 weight-gradient

@@ -235,6 +235,23 @@ int nerf_debug_pack3_table(int* out_host) {
     return 0;
 }
 
+int nerf_debug_pack16_table(int* out_host) {
+    REQUIRE(out_host, "null pointer");
+    nerf::pack16_table_host(out_host);
+    return 0;
+}
+
+int nerf_field_infer_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                            int n_samples, float* raw, void* stream) {
+    REQUIRE(packed3 && rays && z_vals && raw, "null pointer");
+    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
+            "packed/raw must be 16-byte aligned");
+    return done(__func__, nerf::launch_field_fwd16(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw,
+                                                   (hipStream_t)stream));
+}
+
 int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream) {
     REQUIRE(params && packed3, "null pointer");
     return done(__func__, nerf::launch_pack3(params, packed3, (hipStream_t)stream));

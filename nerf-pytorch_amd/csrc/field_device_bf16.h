@@ -80,6 +80,38 @@ __device__ inline void mma1_chunk(f32x16 (&acc)[NB], const float (&v)[NV], const
     for (int s = 0; s < KS; ++s) mma1_kstep<NB>(acc, pack8(&v[VOFF + 8 * s]), a + s * (NB * 64));
 }
 
+// ---- 16-point-per-wave variant (v_mfma_f32_16x16x32_bf16): the fp32 kernels' register shape (64 accumulators + 64
+// activations per lane, 2 waves / SIMD) on the bf16 pipe.  One k-step = 32 contraction slots = the lane's values
+// v[8*s .. 8*s+7]; LDS fragments: ((nb*2 + hl)*64 + lane) x 16 B per k-step (nerf_common.h, P16F)
+__device__ inline f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int NB>
+__device__ inline void mma16_kstep(f32x4 (&acc)[NB], const u32x4 bhi, const u32x4 blo, const u32x4* kbase) {
+#pragma unroll
+    for (int g = 0; g < NB; g += 4) {
+        u32x4 ahi[4], alo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ahi[i] = kbase[((g + i) * 2) * 64]; alo[i] = kbase[((g + i) * 2 + 1) * 64]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g + i] = mfma16_bf16(ahi[i], bhi, acc[g + i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g + i] = mfma16_bf16(ahi[i], blo, acc[g + i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g + i] = mfma16_bf16(alo[i], bhi, acc[g + i]);
+    }
+}
+template <int NB, int KS, int VOFF, int NV>
+__device__ inline void mma16_chunk(f32x4 (&acc)[NB], const float (&v)[NV], const float* lbuf, int lane) {
+    const u32x4* a = reinterpret_cast<const u32x4*>(lbuf) + lane;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        u32x4 bhi, blo;
+        split8(&v[VOFF + 8 * s], bhi, blo);
+        mma16_kstep<NB>(acc, bhi, blo, a + s * (NB * 2 * 64));
+    }
+}
+
 template <int NB>
 __device__ inline void load_bias3(f32x16 (&acc)[NB], const float* bias, int half) {
 #pragma unroll

@@ -238,6 +238,141 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
     if (valid && half == 0) *reinterpret_cast<f32x4*>(a.raw + (size_t)p * 4) = f32x4{c0, c1, c2, sigma};
 }
 
+// ------------------------------------------------------------------ inference forward, 16 points per wave
+// Same arithmetic class as field_fwd3_kernel<0> (3 bf16 MFMAs per product, fp32 accumulate) on
+// v_mfma_f32_16x16x32_bf16 with the fp32 kernel's shape: a wave owns 16 points, 64 accumulator + 64 activation
+// registers per lane => 2 waves / SIMD (8 waves = 128 points share the 2 x 64 KiB weight buffers), so a second wave
+// covers the LDS latency and conversion VALU work that the 32-point kernel leaves exposed at 1 wave / SIMD.  Price:
+// every A fragment serves 16 instead of 32 points (2x the ds_read_b128 traffic per MAC).  The contraction-slot maps
+// are the fp32 datapath's (hcol / encslot / dirslot with value index 8*s + j); the products are summed in a different
+// order than in the 32-point kernel, so the two agree to rounding (~1e-5 of |raw|), not bit for bit.
+__global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4;
+    const long P = (long)a.n_rays * a.S;
+    const long p_raw = ((long)blockIdx.x * FIELD_WAVES + wave) * PTS_PER_WAVE + (lane & 15);
+    const bool valid = p_raw < P;
+    const long p = valid ? p_raw : P - 1;
+    const int ray = (int)(p / a.S);
+
+    WeightStreamT<2, FIELD_WAVES> ws;                  // same chunk sizes as the 32-point forward stream
+    ws.start(a.packed3 + P16F, lds, wave, lane);
+    stage_small_from(a.packed3 + P3_SMALL, lds, FIELD_WAVES * 64);
+
+    const float* rp = a.rays + (long)ray * a.ray_stride;
+    const float z = a.z_vals[p];
+    const float x0 = rp[0] + rp[3] * z;
+    const float x1 = rp[1] + rp[4] * z;
+    const float x2 = rp[2] + rp[5] * z;
+    const float vd0 = rp[8], vd1 = rp[9], vd2 = rp[10];
+    float e[16];
+    encode_xyz(e, x0, x1, x2, q);
+
+    const float* bias = small_ptr(lds, SM_BIAS);
+    f32x4 acc[16];
+    float h[64];
+    auto take = [&](bool relu) {
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[4 * nb + r] = relu ? fmaxf(acc[nb][r], 0.0f) : acc[nb][r];
+    };
+
+    // ---- layer 0: 63 -> 256 (2 k-steps = one chunk)
+    load_bias<16>(acc, bias, q);
+    mma16_chunk<16, 2, 0, 16>(acc, e, ws.acquire(), lane);
+    take(true);
+    // ---- layers 1..7 (layer 5 also contracts the xyz encoding: skip connection); 8 k-steps = 4 chunks
+#pragma unroll 1
+    for (int l = 1; l < D; ++l) {
+        load_bias<16>(acc, bias + l * W, q);
+        const float* cur = ws.acquire();
+        if (l == SKIP + 1) { mma16_chunk<16, 2, 0, 16>(acc, e, cur, lane); cur = ws.acquire(); }
+        mma16_chunk<16, 2, 0, 64>(acc, h, cur, lane);
+        mma16_chunk<16, 2, 16, 64>(acc, h, ws.acquire(), lane);
+        mma16_chunk<16, 2, 32, 64>(acc, h, ws.acquire(), lane);
+        mma16_chunk<16, 2, 48, 64>(acc, h, ws.acquire(), lane);
+        take(true);
+    }
+    // ---- density head: alpha_linear 256 -> 1 (VALU dot + quarter reduction)
+    float sigma = 0.0f;
+    {
+        const float* wa = small_ptr(lds, SM_WALPHA) + 4 * q;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wa + 16 * nb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sigma = fmaf(h[4 * nb + r], w[r], sigma);
+        }
+        sigma = quarter_sum(sigma) + small_ptr(lds, SM_BALPHA)[0];
+    }
+    // ---- feature_linear 256 -> 256 (no activation)
+    load_bias<16>(acc, small_ptr(lds, SM_BFEAT), q);
+    mma16_chunk<16, 2, 0, 64>(acc, h, ws.acquire(), lane);
+    mma16_chunk<16, 2, 16, 64>(acc, h, ws.acquire(), lane);
+    mma16_chunk<16, 2, 32, 64>(acc, h, ws.acquire(), lane);
+    mma16_chunk<16, 2, 48, 64>(acc, h, ws.acquire(), lane);
+    take(false);
+    // ---- view branch: [feature, enc(dir)] 283 -> 128, ReLU: 4 + 4 k-steps of 128 outputs, then the dir k-step
+    float dv[8];
+    {
+        float v7[7];
+        encode_dir(v7, vd0, vd1, vd2, q);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dv[i] = v7[i];
+        dv[7] = 0.0f;
+    }
+    f32x4 av[8];
+    load_bias<8>(av, small_ptr(lds, SM_BVIEWS), q);
+    mma16_chunk<8, 4, 0, 64>(av, h, ws.acquire(), lane);
+    mma16_chunk<8, 4, 32, 64>(av, h, ws.acquire(), lane);
+    mma16_chunk<8, 1, 0, 8>(av, dv, ws.acquire(), lane);
+    float hv[32];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[4 * nb + r] = fmaxf(av[nb][r], 0.0f);
+    // ---- rgb_linear 128 -> 3
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    {
+        const float* wr = small_ptr(lds, SM_WRGB) + 4 * q;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + 16 * nb);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + WV + 16 * nb);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 2 * WV + 16 * nb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                c0 = fmaf(hv[4 * nb + r], w0[r], c0);
+                c1 = fmaf(hv[4 * nb + r], w1[r], c1);
+                c2 = fmaf(hv[4 * nb + r], w2[r], c2);
+            }
+        }
+        c0 = quarter_sum(c0) + small_ptr(lds, SM_BRGB)[0];
+        c1 = quarter_sum(c1) + small_ptr(lds, SM_BRGB)[1];
+        c2 = quarter_sum(c2) + small_ptr(lds, SM_BRGB)[2];
+    }
+    if (valid && q == 0) *reinterpret_cast<f32x4*>(a.raw + (size_t)p * 4) = f32x4{c0, c1, c2, sigma};
+}
+
+hipError_t launch_field_fwd16(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
+                              int n_rays, int S, float* raw, hipStream_t stream) {
+    FieldFwd3Args a{packed3, rays, z_vals, raw, nullptr, ray_stride, n_rays, S};
+    const long P = (long)n_rays * S;
+    if (P <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((P + PTS_PER_WG - 1) / PTS_PER_WG);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)field_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(field_fwd16_kernel, dim3(blocks), dim3(FIELD_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                              int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream) {
     FieldFwd3Args a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S};

@@ -202,7 +202,22 @@ constexpr int P3_SMALL = P3B_END;                                       // fp32 
 constexpr int KSTEP1_W8 = 8 * 64 * 4;                                   // 2048 words = 8 KiB
 constexpr int P1B_KSTEPS = KS3_HV + KS3_H + 7 * KS3_H;                  // views^T 8 | feat^T 16 | L7^T..L1^T 7 x 16 = 136
 constexpr int P1B = P3_SMALL + (PACKED_FLOATS - SM_BIAS);
-constexpr int PACKED3_WORDS = P1B + P1B_KSTEPS * KSTEP1_W8;
+// forward (hi, lo) fragments for the 16-point-per-wave inference kernel (v_mfma_f32_16x16x32_bf16: lane = (row l&15,
+// k-group l>>4), 8 consecutive contraction slots per lane; the contraction slots are the fp32 datapath's hcol /
+// encslot / dirslot maps with value index 8*s + j).  k-step = NB blocks x (hi, lo) x 64 lanes x 16 B; same region
+// sizes and chunking as the 32-point forward stream (P3F_*): L0 | L1..L4 | L5(enc,h) | L6 L7 | FEAT | VIEWS(feat,dir)
+constexpr int P16F = P1B + P1B_KSTEPS * KSTEP1_W8;
+constexpr int KSTEP16_W16 = 16 * 2 * 64 * 4;                             // 8192 words = 32 KiB (256 outputs)
+constexpr int KSTEP16_W8 = 8 * 2 * 64 * 4;                               // 4096 words (128 outputs)
+constexpr int KS16_ENC = 2, KS16_H = 8, KS16_DIR = 1;                    // k-steps of 32 contraction slots
+constexpr int P16F_L1 = KS16_ENC * KSTEP16_W16;                          // offsets inside the region
+constexpr int P16F_L5 = P16F_L1 + 4 * KS16_H * KSTEP16_W16;
+constexpr int P16F_L6 = P16F_L5 + (KS16_ENC + KS16_H) * KSTEP16_W16;
+constexpr int P16F_FEAT = P16F_L6 + 2 * KS16_H * KSTEP16_W16;
+constexpr int P16F_VIEWS = P16F_FEAT + KS16_H * KSTEP16_W16;
+constexpr int P16F_WORDS = P16F_VIEWS + (KS16_H + KS16_DIR) * KSTEP16_W8;
+static_assert(P16F_WORDS == P3F_END && P16F % 4 == 0, "the 16-point forward stream has the 32-point stream's size");
+constexpr int PACKED3_WORDS = P16F + P16F_WORDS;
 static_assert(P1B % 4 == 0 && (P1B_KSTEPS * KSTEP1_W8) % 16384 == 0, "hi-only stream: whole 64 KiB chunks");
 static_assert(P3F_VIEWS % 4096 == 0 && P3B_VIEWS % 4 == 0, "chunk alignment");
 

@@ -144,6 +144,57 @@ __global__ void pack3_small_kernel(const float* __restrict__ canon_params, float
     packed[P3_SMALL + i] = src < 0 ? 0.0f : canon_params[src];
 }
 
+// 16-point-per-wave forward stream (nerf_common.h, P16F): canonical source of 16-bit element e16 of the region
+__host__ __device__ inline int pack16_source(int e16, int* is_lo) {
+    constexpr Canon c = canon();
+    const int word = e16 >> 1;
+    int base, kind;          // kind: 0..7 trunk layer, 8 feature, 9 views
+    if (word < P16F_L1) { base = 0; kind = 0; }
+    else if (word < P16F_L5) { kind = 1 + (word - P16F_L1) / (KS16_H * KSTEP16_W16); base = P16F_L1 + (kind - 1) * KS16_H * KSTEP16_W16; }
+    else if (word < P16F_L6) { base = P16F_L5; kind = 5; }
+    else if (word < P16F_FEAT) { kind = 6 + (word - P16F_L6) / (KS16_H * KSTEP16_W16); base = P16F_L6 + (kind - 6) * KS16_H * KSTEP16_W16; }
+    else if (word < P16F_VIEWS) { base = P16F_FEAT; kind = 8; }
+    else { base = P16F_VIEWS; kind = 9; }
+    const int nblk = kind == 9 ? 8 : 16;
+    const int per_kstep16 = nblk * 2 * 64 * 8;
+    const int r = e16 - 2 * base;
+    const int s = r / per_kstep16, rem = r % per_kstep16;
+    const int nb = rem / 1024, hl = (rem / 512) & 1, lane = (rem >> 3) & 63, j = rem & 7;
+    const int row = 16 * nb + (lane & 15), kq = lane >> 4;
+    *is_lo = hl;
+    if (kind <= 7) {
+        const int ld = fan_in(kind);
+        if (kind == 0) { const int e = encslot(8 * s + j, kq); return e < 0 ? -1 : c.w[0] + row * ld + e; }
+        if (kind == SKIP + 1) {
+            if (s < KS16_ENC) { const int e = encslot(8 * s + j, kq); return e < 0 ? -1 : c.w[kind] + row * ld + e; }
+            return c.w[kind] + row * ld + IN_XYZ + hcol(8 * (s - KS16_ENC) + j, kq);
+        }
+        return c.w[kind] + row * ld + hcol(8 * s + j, kq);
+    }
+    if (kind == 8) return c.wf + row * W + hcol(8 * s + j, kq);
+    if (s < KS16_H) return c.wv + row * (W + IN_DIR) + hcol(8 * s + j, kq);
+    const int d = j < KS_DIR ? dirslot(j, kq) : -1;
+    return d < 0 ? -1 : c.wv + row * (W + IN_DIR) + W + d;
+}
+
+__global__ void pack16_params_kernel(const float* __restrict__ canon_params, unsigned short* __restrict__ region16) {
+    const int e16 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e16 >= 2 * P16F_WORDS) return;
+    int is_lo;
+    const int src = pack16_source(e16, &is_lo);
+    unsigned short v = 0;
+    if (src >= 0) {
+        const float x = canon_params[src];
+        const unsigned short hi = bf16_rne(x);
+        v = is_lo ? bf16_rne(x - __uint_as_float((unsigned)hi << 16)) : hi;
+    }
+    region16[e16] = v;
+}
+
+void pack16_table_host(int* out) {
+    for (int e = 0; e < 2 * P16F_WORDS; ++e) { int lo; const int s = pack16_source(e, &lo); out[e] = s < 0 ? -1 : 2 * s + lo; }
+}
+
 void pack3_table_host(int* out) {
     for (int e = 0; e < 2 * P3B_END; ++e) { int lo; const int s = pack3_source(e, &lo); out[e] = s < 0 ? -1 : 2 * s + lo; }
 }
@@ -165,6 +216,8 @@ hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t st
     hipLaunchKernelGGL(pack3_small_kernel, dim3((PACKED_FLOATS - SM_BIAS + threads - 1) / threads), dim3(threads), 0, stream,
                        canon_params, packed);
     hipLaunchKernelGGL(pack3_hi_only_kernel, dim3((P1B_KSTEPS * 8 * 64 + threads - 1) / threads), dim3(threads), 0, stream, packed);
+    hipLaunchKernelGGL(pack16_params_kernel, dim3((2 * P16F_WORDS + threads - 1) / threads), dim3(threads), 0, stream,
+                       canon_params, reinterpret_cast<unsigned short*>(packed + P16F));
     return hipGetLastError();
 }
 

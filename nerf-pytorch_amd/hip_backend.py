@@ -53,6 +53,8 @@ def _declare(lib):
         "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p]),
         "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p]),
         "nerf_field_fwd_mixed": (i, [p, p, i, p, i, i, p, p, p]),
+        "nerf_field_infer_bf16x3": (i, [p, p, i, p, i, i, p, p]),
+        "nerf_debug_pack16_table": (i, [p]),
         "nerf_field_dgrad_mixed": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p]),
         "nerf_adam_step": (i, [p, p, p, p, i, f, f, f, f, i, p]),
@@ -69,7 +71,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
-           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed",
+           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_infer_bf16x3", "nerf_debug_pack16_table",
            "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step"]
 
 
@@ -197,11 +199,26 @@ def pack_table3():
     import numpy as np
     L = lib()
     # packed3 = (hi, lo) fragment streams | fp32 small parameters | hi-only copy of the transposed streams (136 k-steps
-    # x 2048 words, csrc/nerf_common.h P1B); the table covers the fragment streams
-    n16 = 2 * (L.nerf_packed3_floats() - (L.nerf_packed_floats() - _small_offset()) - 136 * 2048)
+    # x 2048 words, csrc/nerf_common.h P1B) | 16-point forward stream (P16F); the table covers the fragment streams
+    n16 = 2 * (L.nerf_packed3_floats() - (L.nerf_packed_floats() - _small_offset()) - 136 * 2048 - P16F_WORDS)
     tab = np.empty(n16, dtype=np.int32)
     _check(L.nerf_debug_pack3_table(tab.ctypes.data_as(ctypes.c_void_p)), "nerf_debug_pack3_table")
     return tab
+
+
+P16F_WORDS = 593920        # csrc/nerf_common.h: the 16-point forward stream has the 32-point forward stream's size
+
+
+def pack_table16():
+    """Host-side gather table of the 16-point inference stream: per 16-bit element 2*canonical_index + is_lo, -1 = padding."""
+    import numpy as np
+    tab = np.empty(2 * P16F_WORDS, dtype=np.int32)
+    _check(lib().nerf_debug_pack16_table(tab.ctypes.data_as(ctypes.c_void_p)), "nerf_debug_pack16_table")
+    return tab
+
+
+# inference (no saved activations) in the bf16x3 / mixed datapaths runs the 16-point-per-wave kernel
+INFER_16PT = __import__("os").environ.get("NERF_INFER16", "1") != "0"
 
 
 def _small_offset():
@@ -292,6 +309,11 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
             _check(lib().nerf_field_fwd_mixed(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                               n, S, _ptr(raw), _ptr(act, "act"), _stream()), "nerf_field_fwd_mixed")
         return raw, act
+    if precision in ("bf16x3", "mixed") and not save_act and INFER_16PT:
+        with _timed("field_fwd16_kernel", FLOP_FWD_PER_POINT * n * S, nbytes):
+            _check(lib().nerf_field_infer_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                                 n, S, _ptr(raw), _stream()), "nerf_field_infer_bf16x3")
+        return raw, None
     if precision in ("bf16x3", "mixed"):
         with _timed("field_fwd3_kernel<save>" if save_act else "field_fwd3_kernel", FLOP_FWD_PER_POINT * n * S, nbytes):
             _check(lib().nerf_field_fwd_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),

@@ -399,7 +399,16 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     print(f"bf16x3 max|raw-ref64| = {e3:.2e} (fp32 kernel: {e32:.2e}) at |raw|max = {scale:.1f}")
     assert e3 <= 3e-4 * scale, (e3, scale)
     raw_s, act = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
-    assert torch.equal(raw, raw_s)
+    # inference runs the 16-point-per-wave kernel (different summation order): equal to rounding, not bit for bit;
+    # the 32-point kernel's own inference instantiation is bit-identical to the saving one
+    assert maxdiff(raw, raw_s) <= 1e-4 * scale, maxdiff(raw, raw_s)
+    npa.hip_backend.INFER_16PT = False
+    try:
+        raw_w32, _ = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=False, precision="bf16x3")
+    finally:
+        npa.hip_backend.INFER_16PT = True
+    assert torch.equal(raw_w32, raw_s)
+    assert maxdiff(raw_w32, ref64) <= 3e-4 * scale
     P = n_rays * S
     feats = torch.cat([orc.posenc(pts.reshape(-1, 3), 10), orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3), 4)], -1)
     _, hidden, feat, hv = orc.field_mlp(Pf, feats, return_hidden=True)
