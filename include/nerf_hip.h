@@ -128,12 +128,14 @@ int nerf_packed3_floats(void);
 int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream);
 int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                           int n_samples, float* raw, float* act, void* stream);
-/* inference-only form of nerf_field_fwd_bf16x3 (same arithmetic class: 3 bf16 MFMAs per product, fp32 accumulate):
- * 16 points per wavefront at 2 waves / SIMD instead of 32 at 1, which hides the LDS latency the saving kernel
- * leaves exposed.  Sums the products in a different order, so it agrees with nerf_field_fwd_bf16x3 to rounding
- * (~1e-5 of |raw|), not bit for bit.  nerf_debug_pack16_table: host gather table of its fragment stream (tests). */
-int nerf_field_infer_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                            int n_samples, float* raw, void* stream);
+/* the same forward on 16 points per wavefront at 2 waves / SIMD instead of 32 at 1 (same arithmetic class: 3 bf16
+ * MFMAs per product, fp32 accumulate): a second resident wave hides the LDS latency and the save work the 32-point
+ * kernel leaves exposed.  act NULL = inference; otherwise it writes EXACTLY the save buffer of nerf_field_fwd_bf16x3
+ * (bf16_save = 0) or nerf_field_fwd_mixed (bf16_save != 0), so the backward entry points are shared.  Sums the
+ * products in a different order than the 32-point kernel: the two agree to rounding (~1e-5 of |raw|), not bit for bit.
+ * nerf_debug_pack16_table: host gather table of its fragment stream (tests). */
+int nerf_field_fwd16_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                            int n_samples, float* raw, float* act, int bf16_save, void* stream);
 int nerf_debug_pack16_table(int* out_host);
 /* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  dgrad also leaves a tiled
  * copy of d_raw inside delta, which is what wgrad contracts with: nerf_field_wgrad_bf16x3 must be given the delta

@@ -86,19 +86,20 @@ __device__ inline void mma1_chunk(f32x16 (&acc)[NB], const float (&v)[NV], const
 __device__ inline f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-template <int NB>
+// fragments of G blocks are requested together (2 x G x 4 registers)
+template <int NB, int G = 4>
 __device__ inline void mma16_kstep(f32x4 (&acc)[NB], const u32x4 bhi, const u32x4 blo, const u32x4* kbase) {
 #pragma unroll
-    for (int g = 0; g < NB; g += 4) {
-        u32x4 ahi[4], alo[4];
+    for (int g = 0; g < NB; g += G) {
+        u32x4 ahi[G], alo[G];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ahi[i] = kbase[((g + i) * 2) * 64]; alo[i] = kbase[((g + i) * 2 + 1) * 64]; }
+        for (int i = 0; i < G; ++i) { ahi[i] = kbase[((g + i) * 2) * 64]; alo[i] = kbase[((g + i) * 2 + 1) * 64]; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[g + i] = mfma16_bf16(ahi[i], bhi, acc[g + i]);
+        for (int i = 0; i < G; ++i) acc[g + i] = mfma16_bf16(ahi[i], bhi, acc[g + i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[g + i] = mfma16_bf16(ahi[i], blo, acc[g + i]);
+        for (int i = 0; i < G; ++i) acc[g + i] = mfma16_bf16(ahi[i], blo, acc[g + i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[g + i] = mfma16_bf16(alo[i], bhi, acc[g + i]);
+        for (int i = 0; i < G; ++i) acc[g + i] = mfma16_bf16(alo[i], bhi, acc[g + i]);
     }
 }
 template <int NB, int KS, int VOFF, int NV>

@@ -238,14 +238,18 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
     if (valid && half == 0) *reinterpret_cast<f32x4*>(a.raw + (size_t)p * 4) = f32x4{c0, c1, c2, sigma};
 }
 
-// ------------------------------------------------------------------ inference forward, 16 points per wave
-// Same arithmetic class as field_fwd3_kernel<0> (3 bf16 MFMAs per product, fp32 accumulate) on
+// ------------------------------------------------------------------ forward, 16 points per wave
+// Same arithmetic class as field_fwd3_kernel (3 bf16 MFMAs per product, fp32 accumulate) on
 // v_mfma_f32_16x16x32_bf16 with the fp32 kernel's shape: a wave owns 16 points, 64 accumulator + 64 activation
 // registers per lane => 2 waves / SIMD (8 waves = 128 points share the 2 x 64 KiB weight buffers), so a second wave
 // covers the LDS latency and conversion VALU work that the 32-point kernel leaves exposed at 1 wave / SIMD.  Price:
 // every A fragment serves 16 instead of 32 points (2x the ds_read_b128 traffic per MAC).  The contraction-slot maps
 // are the fp32 datapath's (hcol / encslot / dirslot with value index 8*s + j); the products are summed in a different
 // order than in the 32-point kernel, so the two agree to rounding (~1e-5 of |raw|), not bit for bit.
+// SAVE (0 none / 1 fp32 tiles / 2 bf16 tiles) writes EXACTLY the act buffer of field_fwd3_kernel<SAVE>: the same
+// 32-point tiles (a wave fills its 16-point half of every row) and the same ReLU bitmask words (lane (pt, q) owns
+// nibbles 8*nb + 4*(q>>1) of the 128-bit half q&1; lanes q and q^2 are OR-ed), so the backward kernels are shared.
+template <int SAVE>
 __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -270,6 +274,27 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     float e[16];
     encode_xyz(e, x0, x1, x2, q);
 
+    // ---- saving: tile = 32 points = two waves; this lane's point is column pp of the tile
+    ActLayout3 al{};
+    const size_t tile = (size_t)(p_raw >> 5);
+    const int pp = (int)(p_raw & 31);
+    const size_t layer_floats = pad32((size_t)P) * W;
+    auto store_val = [&](size_t region, int F, int f, float v) {
+        const size_t idx = tile * (size_t)(F * 32) + (size_t)f * 32 + pp;
+        if (SAVE == 2) nt_store(reinterpret_cast<__bf16*>(a.act + region) + idx, (__bf16)v);
+        else nt_store(a.act + region + idx, v);
+    };
+    if (SAVE) {
+        al = act_layout3((size_t)P, (size_t)a.n_rays);
+        if (valid) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int col = encslot(s, q);
+                if (col >= 0) store_val(al.enc, 64, col, e[s]);
+            }
+        }
+    }
+
     const float* bias = small_ptr(lds, SM_BIAS);
     f32x4 acc[16];
     float h[64];
@@ -279,11 +304,35 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[4 * nb + r] = relu ? fmaxf(acc[nb][r], 0.0f) : acc[nb][r];
     };
+    // rows of h (value 4*nb + r = feature 16*nb + 4*q + r) -> region; optionally the ReLU bitmask of `layer`
+    auto save_rows = [&](size_t region, bool with_mask, int layer) {
+        if (!SAVE) return;
+        if (valid) {
+#pragma unroll
+            for (int nb = 0; nb < 16; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) store_val(region, W, 16 * nb + 4 * q + r, h[4 * nb + r]);
+        }
+        if (with_mask) {
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int nb = 0; nb < 16; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[nb >> 2] |= (h[4 * nb + r] > 0.0f ? 1u : 0u) << (8 * (nb & 3) + 4 * (q >> 1) + r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] |= __shfl_xor(w[i], 32);            // the other nibbles: lane q ^ 2
+            if (valid && q < 2)
+                nt_store(reinterpret_cast<u32x4*>(a.act + al.mask) + ((size_t)layer * P + p) * 2 + q, u32x4{w[0], w[1], w[2], w[3]});
+        }
+    };
 
     // ---- layer 0: 63 -> 256 (2 k-steps = one chunk)
     load_bias<16>(acc, bias, q);
     mma16_chunk<16, 2, 0, 16>(acc, e, ws.acquire(), lane);
     take(true);
+    // rows are written right after take(), while the accumulators are dead (the registers the store addressing needs
+    // are free then); the wave's next acquire() drains them, the SIMD's other wave computes meanwhile
+    save_rows(0, true, 0);
     // ---- layers 1..7 (layer 5 also contracts the xyz encoding: skip connection); 8 k-steps = 4 chunks
 #pragma unroll 1
     for (int l = 1; l < D; ++l) {
@@ -295,6 +344,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
         mma16_chunk<16, 2, 32, 64>(acc, h, ws.acquire(), lane);
         mma16_chunk<16, 2, 48, 64>(acc, h, ws.acquire(), lane);
         take(true);
+        save_rows((size_t)l * layer_floats, true, l);
     }
     // ---- density head: alpha_linear 256 -> 1 (VALU dot + quarter reduction)
     float sigma = 0.0f;
@@ -315,6 +365,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     mma16_chunk<16, 2, 32, 64>(acc, h, ws.acquire(), lane);
     mma16_chunk<16, 2, 48, 64>(acc, h, ws.acquire(), lane);
     take(false);
+    save_rows(al.feat, false, 0);
     // ---- view branch: [feature, enc(dir)] 283 -> 128, ReLU: 4 + 4 k-steps of 128 outputs, then the dir k-step
     float dv[8];
     {
@@ -323,6 +374,14 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
 #pragma unroll
         for (int i = 0; i < 7; ++i) dv[i] = v7[i];
         dv[7] = 0.0f;
+    }
+    if (SAVE && valid && (p - (long)ray * a.S) == 0) {
+        float* dout = a.act + al.dir + (size_t)ray * 32;
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const int col = dirslot(s, q);
+            if (col >= 0) nt_store(dout + col, dv[s]);
+        }
     }
     f32x4 av[8];
     load_bias<8>(av, small_ptr(lds, SM_BVIEWS), q);
@@ -334,6 +393,24 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[4 * nb + r] = fmaxf(av[nb][r], 0.0f);
+    if (SAVE) {
+        if (valid) {
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) store_val(al.hv, WV, 16 * nb + 4 * q + r, hv[4 * nb + r]);
+        }
+        // view-branch mask: 128 features = 64 bits per half; value 4*nb + r -> bit 8*nb + 4*(q>>1) + r of half q&1
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[nb >> 2] |= (hv[4 * nb + r] > 0.0f ? 1u : 0u) << (8 * (nb & 3) + 4 * (q >> 1) + r);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w[i] |= __shfl_xor(w[i], 32);
+        if (valid && q < 2)
+            nt_store(reinterpret_cast<u32x4*>(a.act + al.mask) + ((size_t)D * P + p) * 2 + q, u32x4{w[0], w[1], w[2], w[3]});
+    }
     // ---- rgb_linear 128 -> 3
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     {
@@ -358,18 +435,27 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
 }
 
 hipError_t launch_field_fwd16(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
-                              int n_rays, int S, float* raw, hipStream_t stream) {
-    FieldFwd3Args a{packed3, rays, z_vals, raw, nullptr, ray_stride, n_rays, S};
+                              int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream) {
+    FieldFwd3Args a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S};
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((P + PTS_PER_WG - 1) / PTS_PER_WG);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)field_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
-        if (e != hipSuccess) return e;
+        hipError_t e0 = hipFuncSetAttribute((const void*)field_fwd16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        hipError_t e1 = hipFuncSetAttribute((const void*)field_fwd16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        hipError_t e2 = hipFuncSetAttribute((const void*)field_fwd16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        if (e0 != hipSuccess) return e0;
+        if (e1 != hipSuccess) return e1;
+        if (e2 != hipSuccess) return e2;
         attr_set = true;
     }
-    hipLaunchKernelGGL(field_fwd16_kernel, dim3(blocks), dim3(FIELD_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
+    if (act && bf16_save)
+        hipLaunchKernelGGL(field_fwd16_kernel<2>, dim3(blocks), dim3(FIELD_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
+    else if (act)
+        hipLaunchKernelGGL(field_fwd16_kernel<1>, dim3(blocks), dim3(FIELD_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
+    else
+        hipLaunchKernelGGL(field_fwd16_kernel<0>, dim3(blocks), dim3(FIELD_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, a);
     return hipGetLastError();
 }
 

@@ -62,6 +62,6 @@ hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t st
 hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                              int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
 hipError_t launch_field_fwd16(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
-                              int n_rays, int S, float* raw, hipStream_t stream);
+                              int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
 
 }  // namespace nerf

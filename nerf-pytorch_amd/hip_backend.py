@@ -53,7 +53,7 @@ def _declare(lib):
         "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p]),
         "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p]),
         "nerf_field_fwd_mixed": (i, [p, p, i, p, i, i, p, p, p]),
-        "nerf_field_infer_bf16x3": (i, [p, p, i, p, i, i, p, p]),
+        "nerf_field_fwd16_bf16x3": (i, [p, p, i, p, i, i, p, p, i, p]),
         "nerf_debug_pack16_table": (i, [p]),
         "nerf_field_dgrad_mixed": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p]),
@@ -71,7 +71,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
-           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_infer_bf16x3", "nerf_debug_pack16_table",
+           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_debug_pack16_table",
            "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step"]
 
 
@@ -217,8 +217,9 @@ def pack_table16():
     return tab
 
 
-# inference (no saved activations) in the bf16x3 / mixed datapaths runs the 16-point-per-wave kernel
-INFER_16PT = __import__("os").environ.get("NERF_INFER16", "1") != "0"
+# the bf16x3 / mixed forward runs the 16-point-per-wave kernel (2 waves / SIMD); "0" selects the 32-point kernel
+# (1 wave / SIMD), which writes the same save buffer and agrees to rounding
+FWD_16PT = __import__("os").environ.get("NERF_FWD16", "1") != "0"
 
 
 def _small_offset():
@@ -304,16 +305,19 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
     act = torch.empty(act_floats(n, S), dtype=torch.float32, device=rays.device) if save_act else None
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
+    if precision in ("bf16x3", "mixed") and FWD_16PT:
+        bf16_save = int(precision == "mixed")
+        label = "field_fwd16_kernel" + (("<save bf16>" if bf16_save else "<save>") if save_act else "")
+        with _timed(label, FLOP_FWD_PER_POINT * n * S, (0.5 if bf16_save and save_act else 1.0) * nbytes):
+            _check(lib().nerf_field_fwd16_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                                 n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
+                   "nerf_field_fwd16_bf16x3")
+        return raw, act
     if precision == "mixed" and save_act:
         with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD_PER_POINT * n * S, 0.5 * nbytes):
             _check(lib().nerf_field_fwd_mixed(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                               n, S, _ptr(raw), _ptr(act, "act"), _stream()), "nerf_field_fwd_mixed")
         return raw, act
-    if precision in ("bf16x3", "mixed") and not save_act and INFER_16PT:
-        with _timed("field_fwd16_kernel", FLOP_FWD_PER_POINT * n * S, nbytes):
-            _check(lib().nerf_field_infer_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
-                                                 n, S, _ptr(raw), _stream()), "nerf_field_infer_bf16x3")
-        return raw, None
     if precision in ("bf16x3", "mixed"):
         with _timed("field_fwd3_kernel<save>" if save_act else "field_fwd3_kernel", FLOP_FWD_PER_POINT * n * S, nbytes):
             _check(lib().nerf_field_fwd_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),

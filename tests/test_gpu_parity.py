@@ -399,15 +399,15 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     print(f"bf16x3 max|raw-ref64| = {e3:.2e} (fp32 kernel: {e32:.2e}) at |raw|max = {scale:.1f}")
     assert e3 <= 3e-4 * scale, (e3, scale)
     raw_s, act = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
-    # inference runs the 16-point-per-wave kernel (different summation order): equal to rounding, not bit for bit;
-    # the 32-point kernel's own inference instantiation is bit-identical to the saving one
-    assert maxdiff(raw, raw_s) <= 1e-4 * scale, maxdiff(raw, raw_s)
-    npa.hip_backend.INFER_16PT = False
+    # inference and the saving forward are the same 16-point kernel: bit-identical; the 32-point kernel (FWD_16PT off)
+    # sums in a different order: equal to rounding, and it writes the same save buffer (compared below)
+    assert torch.equal(raw, raw_s)
+    npa.hip_backend.FWD_16PT = False
     try:
         raw_w32, _ = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=False, precision="bf16x3")
     finally:
-        npa.hip_backend.INFER_16PT = True
-    assert torch.equal(raw_w32, raw_s)
+        npa.hip_backend.FWD_16PT = True
+    assert maxdiff(raw_w32, raw_s) <= 1e-4 * scale, maxdiff(raw_w32, raw_s)
     assert maxdiff(raw_w32, ref64) <= 3e-4 * scale
     P = n_rays * S
     feats = torch.cat([orc.posenc(pts.reshape(-1, 3), 10), orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3), 4)], -1)
@@ -419,6 +419,34 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     assert maxdiff(rows("feat"), feat) <= 3e-4 * max(1.0, float(feat.abs().max()))
     assert maxdiff(rows("hv"), hv) <= 3e-4 * max(1.0, float(hv.abs().max()))
     assert maxdiff(rows("enc")[:, :63], feats[:, :63]) <= 5e-6
+    # the ReLU bitmasks the backward reads must be exactly the signs of the rows saved next to them: word (layer, p,
+    # half), bit i <-> feature 32*(i>>4) + d32row(i&15, half) (csrc/nerf_common.h); checked for both forward kernels
+    Pp = (P + 31) // 32 * 32
+    mask_off = (Pp * (9 * 256 + 128 + 64) + n_rays * 32 + Pp * 32 + 3) // 4 * 4
+    i = torch.arange(128)
+    feat_of = lambda half: 32 * (i >> 4) + ((i & 15) & 3) + 8 * ((i & 15) >> 2) + 4 * half
+
+    def check_masks(buf):
+        words = buf[mask_off:mask_off + 9 * P * 8].view(torch.int32).view(9, P, 2, 4)
+        for layer, region, width in [(l, f"h{l}", 256) for l in range(8)] + [(8, "hv", 128)]:
+            pos = npa.hip_backend.saved_rows(buf, P, region, "bf16x3") > 0
+            for half in range(2):
+                bits = ((words[layer, :, half, :, None] >> torch.arange(32)) & 1).reshape(P, 128).bool()
+                n = width // 2
+                assert torch.equal(bits[:, :n], pos[:, feat_of(half)[:n]]), (layer, half)
+    check_masks(act)
+    npa.hip_backend.FWD_16PT = False
+    try:
+        _, act32 = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
+    finally:
+        npa.hip_backend.FWD_16PT = True
+    act32 = act32.cpu()
+    check_masks(act32)
+    for region in [f"h{l}" for l in range(8)] + ["feat", "hv", "enc"]:
+        a16, a32 = npa.hip_backend.saved_rows(act, P, region, "bf16x3"), npa.hip_backend.saved_rows(act32, P, region, "bf16x3")
+        if region == "enc":
+            a16, a32 = a16[:, :63], a32[:, :63]
+        assert maxdiff(a16, a32) <= 1e-4 * max(1.0, float(a32.abs().max())), region
 
 
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192)])

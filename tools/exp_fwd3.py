@@ -23,9 +23,8 @@ act = torch.empty(hb.act_floats(N, 192), device=dev); raw = torch.empty(N, 192, 
 L = hb.lib(); s = torch.cuda.current_stream().cuda_stream
 f = lambda a: L.nerf_field_fwd_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, 192, raw.data_ptr(), a, s)
 print(sys.argv[1:], "fwd3 nosave %.3f ms | save %.3f ms" % (timeit(lambda: f(None)), timeit(lambda: f(act.data_ptr()))), flush=True)
-if hasattr(L, "nerf_field_infer_bf16x3"):
-    f16 = lambda: L.nerf_field_infer_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, 192, raw.data_ptr(), s)
-    print("   fwd16 (inference, 16 pts/wave) %.3f ms" % timeit(f16), flush=True)
+f16 = lambda a, bf: L.nerf_field_fwd16_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, 192, raw.data_ptr(), a, bf, s)
+print("   fwd16 nosave %.3f ms | save %.3f ms | save bf16 %.3f ms" % (timeit(lambda: f16(None, 0)), timeit(lambda: f16(act.data_ptr(), 0)), timeit(lambda: f16(act.data_ptr(), 1))), flush=True)
 if "--bwd" in sys.argv:
     d_raw = torch.randn(N, 192, 4, device=dev); delta = torch.empty(L.nerf_delta_floats(N, 192), device=dev)
     g = lambda: L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), s)
