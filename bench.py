@@ -100,7 +100,7 @@ def pmc_traffic(kernel_name, precision):
             tmpl = base.split("<")[1].split(">")[0] if "<" in base else ""
             if base.split("<")[0].split("(")[0] != key:
                 continue
-            if key == "field_fwd3_kernel" and (tmpl in ("1", "true")) != ("<save>" in kernel_name):
+            if key in ("field_fwd3_kernel", "field_fwd16_kernel") and (tmpl in ("1", "true")) != ("<save>" in kernel_name):
                 continue
             if key == "field_dgrad3_kernel" and (tmpl in ("1", "true")) != ("<mixed>" in kernel_name):
                 continue
