@@ -1,5 +1,6 @@
 mkdir -p gpurun_out
-{ timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -6
-  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/b.json; cut -c1-200 gpurun_out/b.json
+{ timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+  python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+  timeout 400 python bench.py 2>&1 | tail -1 > gpurun_out/bench_default.json; cut -c1-300 gpurun_out/bench_default.json
 } > gpurun_out/exp.log 2>&1
 cat gpurun_out/exp.log
