@@ -207,3 +207,36 @@ def test_frame_sink_orders_frames_and_writes_the_same_pngs(tmp_path):
         ref = tmp_path / f"ref{i}.png"
         R._write_png(str(ref), R.to8b(rgb.numpy()))
         assert open(tmp_path / f"{i:03d}.png", "rb").read() == open(ref, "rb").read()
+
+
+def test_precision_selection_and_saved_row_views():
+    """set_precision accepts the three datapaths and rejects anything else; saved_rows inverts the tile layout of
+    csrc/nerf_common.h (element (p, f) of an F-wide region at (p/32)*F*32 + f*32 + p%32, fp32 or bf16)."""
+    assert npa.hip_backend.PRECISIONS == ("fp32", "bf16x3", "mixed")
+    prev = npa.get_precision()
+    try:
+        for mode in npa.hip_backend.PRECISIONS:
+            npa.set_precision(mode)
+            assert npa.get_precision() == mode
+        with pytest.raises(ValueError):
+            npa.set_precision("fp16")
+    finally:
+        npa.set_precision(prev)
+    P, Pp = 70, 96
+    widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
+    total = sum(Pp * F for _, F in widths)
+    want = {name: torch.randn(P, F).bfloat16().float() for name, F in widths}        # bf16-exact values for both element types
+    buf32 = torch.zeros(total)
+    buf16 = torch.zeros(total).view(torch.bfloat16)                                  # 2-byte elements, same float offsets
+    off = 0
+    for name, F in widths:
+        p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
+        idx = (p // 32) * F * 32 + f * 32 + p % 32
+        buf32[off + idx] = want[name]
+        buf16[2 * off + idx] = want[name].bfloat16()
+        off += Pp * F
+    for name, F in widths:
+        assert torch.equal(npa.hip_backend.saved_rows(buf32, P, name, "bf16x3"), want[name])
+        assert torch.equal(npa.hip_backend.saved_rows(buf16.view(torch.float32), P, name, "mixed"), want[name])
+    flat = torch.arange(P * 2688, dtype=torch.float32)
+    assert torch.equal(npa.hip_backend.saved_rows(flat, P, "h1", "fp32"), flat[P * 256:2 * P * 256].view(P, 256))
