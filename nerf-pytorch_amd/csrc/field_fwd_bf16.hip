@@ -262,8 +262,11 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     const int ray = (int)(p / a.S);
 
     WeightStreamT<2, FIELD_WAVES> ws;                  // same chunk sizes as the 32-point forward stream
-    ws.start(a.packed3 + P16F, lds, wave, lane);
+    ws.start(a.packed3 + P16F, lds, wave, lane, SAVE && valid);
     stage_small_from(a.packed3 + P3_SMALL, lds, FIELD_WAVES * 64);
+    // After a save_rows() (>= 64 store instructions, all issued after the DMA of the next chunk) the next acquire
+    // waits with a counted vmcnt: the DMA has landed, the newest 63 stores keep draining under that chunk's MFMAs
+    constexpr int NSAVED = SAVE ? 63 : 0;
 
     const float* rp = a.rays + (long)ray * a.ray_stride;
     const float z = a.z_vals[p];
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
 #pragma unroll 1
     for (int l = 1; l < D; ++l) {
         load_bias<16>(acc, bias + l * W, q);
-        const float* cur = ws.acquire();
+        const float* cur = ws.template acquire<NSAVED>();
         if (l == SKIP + 1) { mma16_chunk<16, 2, 0, 16>(acc, e, cur, lane); cur = ws.acquire(); }
         mma16_chunk<16, 2, 0, 64>(acc, h, cur, lane);
         mma16_chunk<16, 2, 16, 64>(acc, h, ws.acquire(), lane);
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     }
     // ---- feature_linear 256 -> 256 (no activation)
     load_bias<16>(acc, small_ptr(lds, SM_BFEAT), q);
-    mma16_chunk<16, 2, 0, 64>(acc, h, ws.acquire(), lane);
+    mma16_chunk<16, 2, 0, 64>(acc, h, ws.template acquire<NSAVED>(), lane);
     mma16_chunk<16, 2, 16, 64>(acc, h, ws.acquire(), lane);
     mma16_chunk<16, 2, 32, 64>(acc, h, ws.acquire(), lane);
     mma16_chunk<16, 2, 48, 64>(acc, h, ws.acquire(), lane);
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     }
     f32x4 av[8];
     load_bias<8>(av, small_ptr(lds, SM_BVIEWS), q);
-    mma16_chunk<8, 4, 0, 64>(av, h, ws.acquire(), lane);
+    mma16_chunk<8, 4, 0, 64>(av, h, ws.template acquire<NSAVED>(), lane);
     mma16_chunk<8, 4, 32, 64>(av, h, ws.acquire(), lane);
     mma16_chunk<8, 1, 0, 8>(av, dv, ws.acquire(), lane);
     float hv[32];
