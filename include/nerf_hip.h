@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 1
+#define NERF_ABI_VERSION 2
 #define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
 
@@ -83,10 +83,12 @@ int nerf_field_fwd(const float* packed, const float* rays, int ray_stride, const
 int nerf_raw2outputs(const float* raw, const float* z_vals, const float* rays_d, int dir_stride, int n_rays,
                      int n_samples, const float* noise, float raw_noise_std, int white_bkgd, float* rgb_map,
                      float* disp_map, float* acc_map, float* weights, float* depth_map, void* stream);
-/* autograd of raw2outputs w.r.t. raw: d_rgb[n_rays][3] required, d_acc / d_disp [n_rays] may be NULL. */
+/* autograd of raw2outputs w.r.t. raw (all five outputs of run_nerf.py:305 are differentiable in the reference):
+ * d_rgb[n_rays][3] required; d_acc / d_disp / d_depth [n_rays] and d_weights [n_rays][n_samples] may be NULL. */
 int nerf_raw2outputs_bwd(const float* raw, const float* z_vals, const float* rays_d, int dir_stride, int n_rays,
                          int n_samples, const float* noise, float raw_noise_std, int white_bkgd,
-                         const float* d_rgb, const float* d_acc, const float* d_disp, float* d_raw, void* stream);
+                         const float* d_rgb, const float* d_acc, const float* d_disp, const float* d_weights,
+                         const float* d_depth, float* d_raw, void* stream);
 
 /* ---- hierarchical sampling (run_nerf.py:392-396,412 + sample_pdf, run_nerf_helpers.py:196-239):
  * z_mid, sample_pdf(z_mid, weights[1:-1], n_fine, det = (u == NULL)), sort(cat(z_vals, z_samples)), z_std.

@@ -118,20 +118,21 @@ int nerf_raw2outputs(const float* raw, const float* z_vals, const float* rays_d,
     REQUIRE(dir_stride >= 3 && n_rays >= 0 && n_samples >= 1 && n_samples <= 4096, "bad size");
     nerf::CompositeArgs a{raw, z_vals, rays_d, raw_noise_std > 0.0f ? noise : nullptr, raw_noise_std,
                           dir_stride, n_rays, n_samples, white_bkgd,
-                          rgb_map, disp_map, acc_map, weights, depth_map, nullptr, nullptr, nullptr, nullptr};
+                          rgb_map, disp_map, acc_map, weights, depth_map, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     REQUIRE(!(raw_noise_std > 0.0f) || noise, "raw_noise_std > 0 needs noise draws");
     return done(__func__, nerf::launch_composite(a, false, (hipStream_t)stream));
 }
 
 int nerf_raw2outputs_bwd(const float* raw, const float* z_vals, const float* rays_d, int dir_stride, int n_rays,
                          int n_samples, const float* noise, float raw_noise_std, int white_bkgd,
-                         const float* d_rgb, const float* d_acc, const float* d_disp, float* d_raw, void* stream) {
+                         const float* d_rgb, const float* d_acc, const float* d_disp, const float* d_weights,
+                         const float* d_depth, float* d_raw, void* stream) {
     REQUIRE(raw && z_vals && rays_d && d_rgb && d_raw, "null pointer");
     REQUIRE(dir_stride >= 3 && n_rays >= 0 && n_samples >= 1 && n_samples <= 4096, "bad size");
     REQUIRE(!(raw_noise_std > 0.0f) || noise, "raw_noise_std > 0 needs noise draws");
     nerf::CompositeArgs a{raw, z_vals, rays_d, raw_noise_std > 0.0f ? noise : nullptr, raw_noise_std,
                           dir_stride, n_rays, n_samples, white_bkgd,
-                          nullptr, nullptr, nullptr, nullptr, nullptr, d_rgb, d_acc, d_disp, d_raw};
+                          nullptr, nullptr, nullptr, nullptr, nullptr, d_rgb, d_acc, d_disp, d_raw, d_weights, d_depth};
     return done(__func__, nerf::launch_composite(a, true, (hipStream_t)stream));
 }
 

@@ -19,6 +19,8 @@ struct CompositeArgs {
     const float* d_acc;     // [N] nullable
     const float* d_disp;    // [N] nullable
     float* d_raw;           // [N][S][4]
+    const float* d_weights; // [N][S] nullable: upstream gradient of the `weights` output
+    const float* d_depth;   // [N] nullable: upstream gradient of `depth_map`
 };
 
 struct FineArgs {

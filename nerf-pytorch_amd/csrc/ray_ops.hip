@@ -138,13 +138,14 @@ __global__ __launch_bounds__(64) void composite_kernel(CompositeArgs a) {
     //      dL/dalpha_i = g_i T_i - R_i / t_i
     const float g0 = a.d_rgb[(size_t)ray * 3], g1 = a.d_rgb[(size_t)ray * 3 + 1], g2 = a.d_rgb[(size_t)ray * 3 + 2];
     float gacc = a.d_acc ? a.d_acc[ray] : 0.0f;
-    float gdepth = 0.0f;
+    float gdepth = a.d_depth ? a.d_depth[ray] : 0.0f;
+    const float* gw = a.d_weights ? a.d_weights + (size_t)ray * S : nullptr;
     if (a.white_bkgd) gacc -= (g0 + g1 + g2);
     if (a.d_disp) {
         const float gd = a.d_disp[ray];
         if (ratio > 1e-10f) {               // disp = acc / depth on this branch
             const float inv = -gd / (m * m);
-            gdepth = inv / asum;
+            gdepth += inv / asum;
             gacc += inv * (-dsum / (asum * asum));
         }
     }
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(64) void composite_kernel(CompositeArgs a) {
     for (int i = lo; i < hi; ++i) {
         const float w = s_alpha[i] * T;
         const float c0 = sigmoidf_(raw[4 * i]), c1 = sigmoidf_(raw[4 * i + 1]), c2 = sigmoidf_(raw[4 * i + 2]);
-        const float g = g0 * c0 + g1 * c1 + g2 * c2 + gacc + gdepth * z[i];
+        float g = g0 * c0 + g1 * c1 + g2 * c2 + gacc + gdepth * z[i];
+        if (gw) g += gw[i];
         s_gw[i] = g * w;
         segsum += g * w;
         // colour gradients are local

@@ -118,8 +118,9 @@ class NeRF(nn.Module):
     def packed_params(self, precision="fp32"):
         """Fragment repack of the current parameters for the given datapath (cached on the parameters' versions)."""
         flat = self.flat_params()
-        # torch-side updates advance the parameters' version counters; the fused Adam kernel advances hb.PARAM_EPOCH
-        # (and in-place torch ops on the flat vector itself, e.g. the DP parameter broadcast, advance flat._version)
+        # torch-side in-place updates advance the version counters of the parameters / of the flat vector; the fused
+        # Adam kernel advances hb.PARAM_EPOCH.  Writers that do neither (c10d collectives such as the DP parameter
+        # broadcast, `.data` writes, raw pointers) must call invalidate_packed().
         key = tuple(p._version for p in self.parameters()) + (flat.data_ptr(), flat._version, hb.PARAM_EPOCH)
         if self._packed is None or key != self._packed_key:
             self._packed = {}
@@ -130,6 +131,12 @@ class NeRF(nn.Module):
             # fresh tensor each time: a pending backward keeps a reference to the old one
             self._packed[precision] = hb.pack_params(flat, precision=precision)
         return self._packed[precision]
+
+    def invalidate_packed(self):
+        """Drop the cached fragment repacks: call after writing the parameters through a path that does not advance
+        tensor version counters (dist.broadcast / all_reduce on flat_params(), `.data` writes, raw device pointers)."""
+        self._packed = None
+        self._packed_key = None
 
     def param_list(self):
         return [p for _, _, _, p in self._ordered_params()]

@@ -15,6 +15,7 @@ from . import build as _build
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
+ABI_VERSION = 2        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
 
 
 class NerfHipError(RuntimeError):
@@ -37,7 +38,7 @@ def _declare(lib):
         "nerf_act_floats": (sz, [i, i]),
         "nerf_field_fwd": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_raw2outputs": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p, p]),
-        "nerf_raw2outputs_bwd": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p]),
+        "nerf_raw2outputs_bwd": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p, p, p]),
         "nerf_sample_fine": (i, [p, p, i, i, i, p, p, p, p, p, p]),
         "nerf_sample_pdf": (i, [p, p, i, i, i, p, p, p, p]),
         "nerf_delta_floats": (sz, [i, i]),
@@ -86,7 +87,7 @@ def lib():
                 "There is no PyTorch fallback for the render hot path.")
         _LIB = ctypes.CDLL(path)
         _declare(_LIB)
-        if _LIB.nerf_abi_version() != 1:
+        if _LIB.nerf_abi_version() != ABI_VERSION:
             raise NerfHipError("libnerf_hip.so ABI version mismatch")
     return _LIB
 
@@ -348,13 +349,14 @@ def raw2outputs(raw, z_vals, rays_d, dir_stride, noise, raw_noise_std, white_bkg
 
 
 def raw2outputs_bwd(raw, z_vals, rays_d, dir_stride, noise, raw_noise_std, white_bkgd, d_rgb, d_acc, d_disp,
-                    rays_d_offset=0):
+                    rays_d_offset=0, d_weights=None, d_depth=None):
     n, S = z_vals.shape
     d_raw = torch.empty((n, S, 4), dtype=torch.float32, device=raw.device)
     dptr = _ptr(rays_d, "rays_d") + 4 * rays_d_offset
     _check(lib().nerf_raw2outputs_bwd(_ptr(raw, "raw"), _ptr(z_vals, "z_vals"), dptr, dir_stride, n, S,
                                       _ptr(noise, "noise", True), float(raw_noise_std), int(bool(white_bkgd)),
                                       _ptr(d_rgb, "d_rgb"), _ptr(d_acc, "d_acc", True), _ptr(d_disp, "d_disp", True),
+                                      _ptr(d_weights, "d_weights", True), _ptr(d_depth, "d_depth", True),
                                       _ptr(d_raw), _stream()), "nerf_raw2outputs_bwd")
     return d_raw
 

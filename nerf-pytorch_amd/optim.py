@@ -56,8 +56,20 @@ class FlatAdam(torch.optim.Optimizer):
             self._flat[key] = (m, v)
         return self._flat[key]
 
+    _UNSUPPORTED = (("weight_decay", 0), ("amsgrad", False), ("maximize", False), ("decoupled_weight_decay", False))
+
+    def _check_groups(self):
+        """The fused kernel is plain Adam (run_nerf.py:207).  The other torch.optim.Adam keys exist in the groups only
+        so that state_dicts interchange; a group that sets one of them must not silently train as plain Adam."""
+        for group in self.param_groups:
+            for key, off in self._UNSUPPORTED:
+                if group.get(key, off) not in (off, None):
+                    raise NotImplementedError(f"FlatAdam: {key}={group[key]!r} is not implemented by the fused kernel "
+                                              "(use torch.optim.Adam for this configuration)")
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._check_groups()
         self._flat = {}        # moments are re-flattened (values adopted) at the next step
 
     @torch.no_grad()
@@ -66,6 +78,7 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._check_groups()
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
             if not params:

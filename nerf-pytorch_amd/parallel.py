@@ -122,6 +122,9 @@ def broadcast_parameters(models, src=0, group=None):
         flat = m.flat_params() if hasattr(m, "flat_params") else None
         if flat is not None:
             dist.broadcast(flat, src=src, group=group)
+            # c10d collectives write through the storage WITHOUT advancing tensor version counters, so the
+            # fragment-repack cache (NeRF.packed_params) cannot see this update: drop it explicitly
+            m.invalidate_packed()
         else:
             for p in m.parameters():
                 dist.broadcast(p.data, src=src, group=group)

@@ -46,6 +46,11 @@ def _f32c(t):
 
 
 # --------------------------------------------------------------------------- autograd glue
+_FREED_MSG = ("nerf-pytorch_amd: the saved activations of this render were already consumed by a backward pass and "
+              "freed; backward through the same graph a second time is not supported (sum the losses and call "
+              "backward once)")
+
+
 class _FieldQuery(torch.autograd.Function):
     """raw = field(rays, z) for explicit rays/depths; gradients w.r.t. the parameters only."""
 
@@ -54,18 +59,20 @@ class _FieldQuery(torch.autograd.Function):
         prec = _PRECISION
         packed = model.packed_params(prec)
         raw, act = hb.field_fwd(packed, rays, z_vals, save_act=need, precision=prec)
-        ctx.model, ctx.packed, ctx.act, ctx.prec = model, packed, act, prec
+        ctx.model, ctx.packed, ctx.act, ctx.prec, ctx.saved_any = model, packed, act, prec, bool(need)
         ctx.set_materialize_grads(False)
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
         model = ctx.model
-        if d_raw is None or ctx.act is None:
+        if d_raw is None or not ctx.saved_any:      # nothing requires grad: forward saved nothing on purpose
             return (None, None, None, None) + (None,) * len(_param_slices(model))
+        if ctx.act is None:
+            raise RuntimeError(_FREED_MSG)
         grad = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=d_raw.device)
         hb.field_bwd(ctx.packed, ctx.act, d_raw.contiguous(), grad, accumulate=False, precision=ctx.prec)
-        ctx.act = None
+        ctx.act = None      # ~10 KB per point: released as soon as the gradient exists (like autograd frees its buffers)
         model.last_flat_grad = grad
         return (None, None, None, None) + _grad_views(model, grad)
 
@@ -102,7 +109,6 @@ class _RenderRays(torch.autograd.Function):
         if n_f <= 0:
             ctx.save_for_backward(rays, z_c, raw_c)
             ctx.saved = dict(act_c=act_c, packed_c=packed_c, rnd=rnd)
-            ctx.mark_non_differentiable(raw_c)
             return rgb_c, disp_c, acc_c, raw_c
         u = rnd.get("u")
         z_f, z_std, _ = hb.sample_fine(z_c, w_c, n_f, u, None if u is not None else _linspace01(n_f, dev))
@@ -113,11 +119,13 @@ class _RenderRays(torch.autograd.Function):
                                                     want_weights=False, want_depth=False, rays_d_offset=3)
         ctx.save_for_backward(rays, z_c, raw_c, z_f, raw_f)
         ctx.saved = dict(act_c=act_c, packed_c=packed_c, rnd=rnd, act_f=act_f, packed_f=packed_f)
-        ctx.mark_non_differentiable(raw_f, z_std)
+        ctx.mark_non_differentiable(z_std)     # the reference detaches z_samples (run_nerf.py:394)
         return rgb_f, disp_f, acc_f, raw_f, rgb_c, disp_c, acc_c, z_std
 
     @staticmethod
     def backward(ctx, *gouts):
+        if ctx.saved is None:
+            raise RuntimeError(_FREED_MSG)
         s, cfg = dict(ctx.saved), ctx.cfg
         tens = ctx.saved_tensors
         s.update(rays=tens[0], z_c=tens[1], raw_c=tens[2])
@@ -132,22 +140,27 @@ class _RenderRays(torch.autograd.Function):
         dev = rays.device
         n = rays.shape[0]
 
-        def cgrads(d_rgb, d_disp, d_acc):
+        def cgrads(d_rgb, d_disp, d_acc, d_raw_up=None):
             zero = lambda t, shape: t.contiguous() if t is not None else None
-            if d_rgb is None and d_disp is None and d_acc is None:
+            if d_rgb is None and d_disp is None and d_acc is None and d_raw_up is None:
                 return None
-            if d_rgb is None:
+            if d_rgb is None and not (d_disp is None and d_acc is None):
                 d_rgb = torch.zeros((n, 3), dtype=torch.float32, device=dev)
-            return d_rgb.contiguous(), zero(d_acc, n), zero(d_disp, n)
+            return (d_rgb.contiguous() if d_rgb is not None else None), zero(d_acc, n), zero(d_disp, n), d_raw_up
 
         def field_grad(model, packed, act, raw, z, noise, g, grad, accumulate):
-            d_rgb, d_acc, d_disp = g
-            d_raw = hb.raw2outputs_bwd(raw, z, rays, rays.shape[1], noise, std, wb, d_rgb, d_acc, d_disp,
-                                       rays_d_offset=3)
+            d_rgb, d_acc, d_disp, d_raw_up = g
+            if d_rgb is None:       # only `raw` itself (extras['raw'], e.g. a sigma regulariser) carries a gradient
+                d_raw = d_raw_up.to(torch.float32).contiguous()
+            else:
+                d_raw = hb.raw2outputs_bwd(raw, z, rays, rays.shape[1], noise, std, wb, d_rgb, d_acc, d_disp,
+                                           rays_d_offset=3)
+                if d_raw_up is not None:
+                    d_raw += d_raw_up
             hb.field_bwd(packed, act, d_raw, grad, accumulate, precision=cfg.get("precision", "fp32"))
 
         if cfg["N_importance"] <= 0:
-            g = cgrads(gouts[0], gouts[1], gouts[2])
+            g = cgrads(gouts[0], gouts[1], gouts[2], gouts[3])
             if g is None:
                 return (None,) * n_lead + none_c
             grad_c = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
@@ -156,7 +169,7 @@ class _RenderRays(torch.autograd.Function):
             ctx.saved = None
             return (None,) * n_lead + _grad_views(ctx.model_c, grad_c)
 
-        g_f = cgrads(gouts[0], gouts[1], gouts[2])
+        g_f = cgrads(gouts[0], gouts[1], gouts[2], gouts[3])
         g_c = cgrads(gouts[4], gouts[5], gouts[6])
         grad_c = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
         wrote_c = False
@@ -189,19 +202,20 @@ class _Composite(torch.autograd.Function):
     def forward(ctx, raw, z_vals, rays_d, noise, raw_noise_std, white_bkgd):
         rgb, disp, acc, w, depth = hb.raw2outputs(raw, z_vals, rays_d, 3, noise, raw_noise_std, white_bkgd)
         ctx.args = (raw, z_vals, rays_d, noise, raw_noise_std, white_bkgd)
-        ctx.mark_non_differentiable(w, depth)
         ctx.set_materialize_grads(False)
         return rgb, disp, acc, w, depth
 
     @staticmethod
     def backward(ctx, d_rgb, d_disp, d_acc, d_w, d_depth):
+        # all five outputs carry gradients to raw, as in the reference (a depth / weight / sparsity loss term works)
         raw, z_vals, rays_d, noise, std, wb = ctx.args
-        if d_rgb is None and d_disp is None and d_acc is None:
+        if all(g is None for g in (d_rgb, d_disp, d_acc, d_w, d_depth)):
             return (None,) * 6
         if d_rgb is None:
             d_rgb = torch.zeros((raw.shape[0], 3), dtype=torch.float32, device=raw.device)
-        c = lambda t: t.contiguous() if t is not None else None
-        d_raw = hb.raw2outputs_bwd(raw, z_vals, rays_d, 3, noise, std, wb, d_rgb.contiguous(), c(d_acc), c(d_disp))
+        c = lambda t: t.to(torch.float32).contiguous() if t is not None else None
+        d_raw = hb.raw2outputs_bwd(raw, z_vals, rays_d, 3, noise, std, wb, c(d_rgb), c(d_acc), c(d_disp),
+                                   d_weights=c(d_w), d_depth=c(d_depth))
         return d_raw, None, None, None, None, None
 
 

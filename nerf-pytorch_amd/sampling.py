@@ -23,6 +23,8 @@ def sample_ray_batch(H, W, K, pose, image, N_rand, precrop_frac=None, generator=
         h0, w0, nh, nw = H // 2 - dH, W // 2 - dW, 2 * dH, 2 * dW
     else:
         h0, w0, nh, nw = 0, 0, H, W
+    if N_rand > nh * nw:        # np.random.choice(..., replace=False) raises here too (run_nerf.py:752)
+        raise ValueError(f"cannot take N_rand={N_rand} rays without replacement from {nh}x{nw} = {nh * nw} pixels")
     sel = torch.randperm(nh * nw, device=dev, generator=generator)[:N_rand]
     jj = h0 + torch.div(sel, nw, rounding_mode="floor")      # row (y)
     ii = w0 + sel - torch.div(sel, nw, rounding_mode="floor") * nw      # column (x)

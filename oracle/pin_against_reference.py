@@ -148,6 +148,24 @@ def main(n_rays=96):
     same(got["disp_map"], ref_list[1], "render() disp_map")
     same(got["acc_map"], ref_list[2], "render() acc_map")
     same(got["raw"], ref_list[3]["raw"], "render() raw")
+    print("render(ndc=True) on forward-facing rays (configs/fern.txt: near=0, far=1, raw_noise_std=1, no white_bkgd)")
+    cfg = orc.FERN
+    Kf = orc.intrinsics(cfg)
+    batch = orc.fern_batch(48, seed=2)
+    kw_f = dict(kw)
+    kw_f.update(perturb=1.0, raw_noise_std=1.0, white_bkgd=False)
+    torch.manual_seed(21)
+    ref_list = run_nerf.render(cfg["H"], cfg["W"], Kf, chunk=1024, rays=batch, ndc=True, near=0.0, far=1.0,
+                               use_viewdirs=True, **kw_f)
+    torch.manual_seed(21)
+    rnd = dict(t_rand=torch.rand(48, 64), noise_c=torch.randn(48, 64), u=torch.rand(48, 128), noise_f=torch.randn(48, 192))
+    flat = orc.assemble_render_rays(cfg["H"], cfg["W"], Kf, batch[0], batch[1], True, 0.0, 1.0)
+    got = orc.trace_rays(flat, Pc, Pf, 64, 128, perturb=1.0, white_bkgd=False, raw_noise_std=1.0, retraw=True, **rnd)
+    same(got["rgb_map"], ref_list[0], "render(ndc) rgb_map")
+    same(got["disp_map"], ref_list[1], "render(ndc) disp_map")
+    same(got["acc_map"], ref_list[2], "render(ndc) acc_map")
+    same(got["raw"], ref_list[3]["raw"], "render(ndc) raw")
+    same(got["z_std"], ref_list[3]["z_std"], "render(ndc) z_std")
     print("ORACLE PINNED: every function bit-identical to the reference on CPU")
 
 

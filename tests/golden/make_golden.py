@@ -76,6 +76,9 @@ def draw_randoms(seed, kw, n=N_RAYS):
 
 
 def run_case(name, run_nerf, helpers, rays, nets, Pc, Pf, target, **cfg):
+    """rays: [N,11] records fed to the reference's render_rays, or -- with cfg['render'] = dict(H, W, K, ndc, near, far)
+    -- a [2,N,3] (rays_o, rays_d) batch fed to the reference's render() (run_nerf.py:69-134), whose ray assembly
+    (view directions, NDC warp) is then part of what the fixture pins."""
     net_c, net_f = nets
     for n in nets:
         n.zero_grad()
@@ -89,12 +92,25 @@ def run_case(name, run_nerf, helpers, rays, nets, Pc, Pf, target, **cfg):
     seed = cfg.get("seed")
     if seed is not None:
         torch.manual_seed(seed)
-    out = run_nerf.render_rays(rays, **kw)
+    rcfg = cfg.get("render")
+    if rcfg is None:
+        out = run_nerf.render_rays(rays, **kw)
+        rays64 = rays.double()
+    else:
+        rgb, disp, acc, extras = run_nerf.render(rcfg["H"], rcfg["W"], rcfg["K"], chunk=1024 * 32, rays=rays, ndc=rcfg["ndc"],
+                                                 near=rcfg["near"], far=rcfg["far"], use_viewdirs=True, **kw)
+        out = dict(extras, rgb_map=rgb, disp_map=disp, acc_map=acc)
+        o64, d64 = rays[0].double(), rays[1].double()
+        vd = d64 / torch.norm(d64, dim=-1, keepdim=True)
+        if rcfg["ndc"]:
+            o64, d64 = orc.ndc_warp(rcfg["H"], rcfg["W"], rcfg["K"][0][0], 1.0, o64, d64)
+        one = torch.ones_like(d64[..., :1])
+        rays64 = torch.cat([o64, d64, rcfg["near"] * one, rcfg["far"] * one, vd], -1)
     loss = helpers.img2mse(out["rgb_map"], target)
     if "rgb0" in out:
         loss = loss + helpers.img2mse(out["rgb0"], target)
     loss.backward()
-    out64, g64c, g64f = oracle_fp64(rays, Pc, Pf, target, kw, draw_randoms(seed, kw))
+    out64, g64c, g64f = oracle_fp64(rays64, Pc, Pf, target, kw, draw_randoms(seed, kw, n=rays64.shape[0]))
     rec = {"loss": np.float64(loss.item()), "rays_checksum": checksum(rays),
            "params_checksum": checksum(torch.cat([v.reshape(-1) for v in Pc.values()])) +
            checksum(torch.cat([v.reshape(-1) for v in Pf.values()]))}
@@ -133,5 +149,57 @@ def main():
              kw=dict(perturb=1.0, N_importance=0, network_fine=None))
 
 
+def gate_case(name, run_nerf, helpers, batch, cfg, n_importance=128):
+    """PSNR-gate fixture: the reference's render() (test-time configuration: perturb=0, raw_noise_std=0,
+    run_nerf.py:255-257) of `batch` with the networks under test (scene_params) and with the teacher scene
+    (teacher_params) whose image is the target.  Stored: both images; bench.py and the GPU tests compute
+    workloads.precision_gate(our image, reference image, target) from them."""
+    embed_fn, _ = helpers.get_embedder(10, 0)
+    embeddirs_fn, _ = helpers.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, network_fn: run_nerf.run_network(
+        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
+    K = orc.intrinsics(cfg)
+    imgs = {}
+    for tag, (Pc, Pf) in (("ref", orc.scene_params()), ("target", orc.teacher_params())):
+        nc, nf = reference_networks(helpers, Pc), reference_networks(helpers, Pf)
+        with torch.no_grad():
+            rgb, disp, acc, extras = run_nerf.render(
+                cfg["H"], cfg["W"], K, chunk=1024 * 32, rays=batch, ndc=cfg["ndc"], near=cfg["near"], far=cfg["far"],
+                use_viewdirs=True, network_fn=nc, network_query_fn=qfn, N_samples=64, N_importance=n_importance,
+                network_fine=nf, perturb=0.0, raw_noise_std=0.0, white_bkgd=cfg["white_bkgd"], lindisp=False)
+        imgs[tag] = rgb.numpy()
+        imgs[tag + "_acc"] = acc.numpy()
+    mse = float(((imgs["ref"] - imgs["target"]) ** 2).mean())
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, rgb_ref=imgs["ref"], target=imgs["target"], acc_ref=imgs["ref_acc"],
+                        rays_checksum=checksum(batch), target_psnr_db=np.float64(orc.psnr(mse)))
+    print(f"{name}: {batch.shape[1]} rays, PSNR(reference image, teacher target) = {orc.psnr(mse):.2f} dB, "
+          f"mean acc {imgs['ref_acc'].mean():.3f} -> {os.path.basename(path)} ({os.path.getsize(path)} B)")
+
+
+def main_round2():
+    """Round-2 fixtures: BASELINE.json configs[2] (fern, NDC) end to end through the reference's render(), and the
+    PSNR-gate images of the lego-like and fern-like workloads."""
+    run_nerf, helpers = load_reference()
+    Pc, Pf = orc.scene_params()
+    nets = (reference_networks(helpers, Pc), reference_networks(helpers, Pf))
+    target = torch.tensor(np.random.RandomState(99).rand(N_RAYS, 3), dtype=torch.float32)
+    cfg = orc.FERN
+    rcfg = dict(H=cfg["H"], W=cfg["W"], K=orc.intrinsics(cfg), ndc=True, near=0.0, far=1.0)
+    # 5. configs/fern.txt through render(): NDC rays, near=0/far=1, raw_noise_std=1, perturb=1, no white_bkgd, 64+128
+    run_case("fern_ndc_train", run_nerf, helpers, orc.fern_batch(N_RAYS, seed=3), nets, Pc, Pf, target, seed=77,
+             render=rcfg, kw=dict(perturb=1.0, raw_noise_std=1.0, white_bkgd=False, N_importance=128))
+    # 6. the same through render() without NDC (lego): pins the rays=... branch of the boundary for configs[1]
+    lcfg = orc.LEGO
+    run_case("lego_render_train", run_nerf, helpers, orc.lego_batch(N_RAYS, seed=7), nets, Pc, Pf, target, seed=123,
+             render=dict(H=lcfg["H"], W=lcfg["W"], K=orc.intrinsics(lcfg), ndc=False, near=2.0, far=6.0),
+             kw=dict(perturb=1.0))
+    gate_case("gate_lego", run_nerf, helpers, orc.lego_batch(1024, seed=31), orc.LEGO)
+    gate_case("gate_fern", run_nerf, helpers, orc.fern_batch(1024, seed=32), orc.FERN)
+
+
 if __name__ == "__main__":
-    main()
+    if "--round2" in sys.argv:
+        main_round2()
+    else:
+        main()

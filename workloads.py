@@ -1,0 +1,303 @@
+"""Seeded synthetic workloads for the render hot path: parameters, ray batches, random draws.
+
+Neutral data module: numpy + torch only.  It imports neither the HIP product (``nerf-pytorch_amd``) nor the oracle
+(``oracle/``), and both sides consume it -- ``bench.py`` / ``__graft_entry__`` / ``tests`` feed the product with it,
+``oracle/nerf_oracle.py`` re-exports the same generators for the checker, ``tests/golden/make_golden.py`` feeds the
+real reference with it.  Everything is generated from numpy's MT19937 (version independent), never from torch's
+generator, so the GPU box reproduces exactly the inputs the golden fixtures were produced from (their checksums are
+stored in the fixtures).
+
+There is no dataset in this environment (no lego / fern files, no network): the BASELINE.json configs are realised as
+  * cfg1/cfg2/cfg4/cfg5 "lego-like": rays toward the origin from cameras at distance ~4, near = 2, far = 6,
+    white background, no NDC  (configs/lego.txt);
+  * cfg3 "fern-like": forward-facing cameras (rays with d_z < 0) of a 504 x 378 image, focal ~ 408, rendered through
+    the NDC warp with near = 0, far = 1, raw_noise_std = 1, no white background  (configs/fern.txt).
+"""
+import math
+
+import numpy as np
+import torch
+
+# --------------------------------------------------------------------------- parameters
+# state_dict layout of the reference NeRF(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True)
+# (run_nerf_helpers.py:68-94)
+def param_shapes(D=8, W=256, in_xyz=63, in_dir=27, skip=4):
+    shapes = []
+    for i in range(D):
+        fan_in = in_xyz if i == 0 else (W + in_xyz if (i - 1) == skip else W)
+        shapes.append((f"pts_linears.{i}.weight", (W, fan_in)))
+        shapes.append((f"pts_linears.{i}.bias", (W,)))
+    shapes.append(("views_linears.0.weight", (W // 2, W + in_dir)))
+    shapes.append(("views_linears.0.bias", (W // 2,)))
+    shapes.append(("feature_linear.weight", (W, W)))
+    shapes.append(("feature_linear.bias", (W,)))
+    shapes.append(("alpha_linear.weight", (1, W)))
+    shapes.append(("alpha_linear.bias", (1,)))
+    shapes.append(("rgb_linear.weight", (3, W // 2)))
+    shapes.append(("rgb_linear.bias", (3,)))
+    return shapes
+
+
+def make_params(seed, dtype=torch.float32, device="cpu", gain=1.0, sigma_gain=1.0, sigma_bias=0.0):
+    """Deterministic, version-independent parameters (numpy MT19937, not torch RNG).
+
+    He-uniform weights so activations keep O(1) scale through the 8 layers and the density head produces non-trivial
+    opacity (an untrained default-init network gives sigma ~ 0 everywhere, which exercises nothing)."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name, shp in param_shapes():
+        if name.endswith("weight"):
+            bound = gain * math.sqrt(6.0 / shp[1])
+            a = rs.uniform(-bound, bound, size=shp)
+            if name == "alpha_linear.weight":
+                a = a * sigma_gain
+        else:
+            a = rs.uniform(-0.1, 0.1, size=shp)
+            if name == "alpha_linear.bias":
+                a = a + sigma_bias
+        out[name] = torch.tensor(a, dtype=dtype, device=device)
+    return out
+
+
+def _damp_bands(P, n_xyz_freqs=10):
+    """Scale the columns of encoding band k (sin/cos of 2^k x) by 2^-k in the two layers that read the xyz encoding:
+    every band then contributes the same spatial gradient, the spectral decay a trained NeRF shows, instead of a field
+    whose value changes by O(1) over 1e-3 scene units."""
+    for name in ("pts_linears.0.weight", "pts_linears.5.weight"):
+        w = P[name]
+        for k in range(n_xyz_freqs):
+            w[:, 3 + 6 * k: 9 + 6 * k] *= 2.0 ** (-k)
+    return P
+
+
+def scene_params(seed=0, dtype=torch.float32, device="cpu"):
+    """The (coarse, fine) parameter pair tests / bench / fixtures use.  NeRF-like on purpose:
+      * density heads scaled so rays see empty space, semi-transparent shells and opaque hits;
+      * spectral decay over the encoding bands (_damp_bands);
+      * fine = coarse + 0.3 % relative perturbation: hierarchical sampling assumes the two networks describe the SAME
+        scene (samples drawn in bins the coarse pass found empty must land in space the fine network also finds
+        empty).  With unrelated networks the few samples whose position is ill-conditioned in the reference itself
+        (sample_pdf divides by denom ~ 1e-5 in empty bins, helpers:234-236, amplifying 1e-7 cdf rounding to ~1e-3 in
+        depth) dominate any per-ray comparison; scene_params_adversarial() keeps that case for the PSNR criterion."""
+    pc = _damp_bands(make_params(11 + 2 * seed, torch.float64, device, sigma_gain=30.0, sigma_bias=6.0))
+    rs = np.random.RandomState(500 + seed)
+    pf = {k: v * torch.tensor(1.0 + 3e-3 * rs.standard_normal(tuple(v.shape)), dtype=torch.float64, device=device)
+          for k, v in pc.items()}
+    return ({k: v.to(dtype) for k, v in pc.items()}, {k: v.to(dtype) for k, v in pf.items()})
+
+
+def scene_params_adversarial(seed=0, dtype=torch.float32, device="cpu"):
+    """Unrelated coarse / fine networks with full-strength 2^9 frequency columns (see scene_params)."""
+    pc = make_params(11 + 2 * seed, dtype, device, sigma_gain=12.0, sigma_bias=-5.0)
+    pf = make_params(12 + 2 * seed, dtype, device, sigma_gain=12.0, sigma_bias=-8.0)
+    return pc, pf
+
+
+TEACHER_EPS = 3.0e-3
+
+
+def teacher_params(seed=0, dtype=torch.float32, device="cpu", eps=TEACHER_EPS):
+    """"Ground truth" scene for the PSNR gate: the (coarse, fine) pair of scene_params(seed) with every parameter
+    perturbed by a relative eps.  Images rendered from teacher_params() are the target; the networks under test are
+    scene_params() -- a model that has almost converged to the target, PSNR ~ 33-36 dB (trained-NeRF territory), which
+    is where the north-star criterion 'PSNR delta < 0.01 dB' is meaningful: at that operating point an rgb error of
+    1e-3 moves the PSNR by ~0.1 dB (against a random target, PSNR ~ 6 dB, it would move it by 1e-4 dB)."""
+    pc, pf = scene_params(seed, torch.float64, device)
+    rs = np.random.RandomState(900 + seed)
+    out = []
+    for P in (pc, pf):
+        out.append({k: (v * torch.tensor(1.0 + eps * rs.standard_normal(tuple(v.shape)), dtype=torch.float64,
+                                         device=device)).to(dtype) for k, v in P.items()})
+    return tuple(out)
+
+
+# --------------------------------------------------------------------------- rays
+def _ray_records(o, d, near, far):
+    """[N,11] = (o3, d3, near, far, viewdir3): the record render() assembles (run_nerf.py:100-123, use_viewdirs=True)."""
+    viewdirs = d / torch.norm(d, dim=-1, keepdim=True)
+    viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    o = torch.reshape(o, [-1, 3]).float()
+    d = torch.reshape(d, [-1, 3]).float()
+    nr = near * torch.ones_like(d[..., :1])
+    fr = far * torch.ones_like(d[..., :1])
+    return torch.cat([o, d, nr, fr, viewdirs], -1)
+
+
+def synthetic_rays(n, seed=0, near=2.0, far=6.0, dtype=torch.float32):
+    """lego-like: o ~ N((0,0,4), 0.1^2), d = normalize(N(0,I)) pointing roughly at the origin, |d| in [0.8, 1.25]
+    (non-unit like get_rays() output).  Returns the assembled [n,11] ray records."""
+    rs = np.random.RandomState(seed)
+    o = rs.normal(0.0, 0.1, size=(n, 3)) + np.array([0.0, 0.0, 4.0])
+    tgt = rs.normal(0.0, 0.6, size=(n, 3))
+    d = tgt - o
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    d = d * rs.uniform(0.8, 1.25, size=(n, 1))
+    o = torch.tensor(o, dtype=dtype)
+    d = torch.tensor(d, dtype=dtype)
+    return _ray_records(o, d, near, far).to(dtype)
+
+
+def lego_batch(n, seed=0):
+    """The same rays as synthetic_rays(n, seed) in the form train() hands to render(): batch_rays [2, n, 3]
+    = (rays_o, rays_d) (run_nerf.py:756), to be rendered with ndc=False, near=2, far=6."""
+    r = synthetic_rays(n, seed)
+    return torch.stack([r[:, 0:3], r[:, 3:6]], 0).contiguous()
+
+
+LEGO = dict(H=400, W=400, focal=555.5, near=2.0, far=6.0, ndc=False, white_bkgd=True, raw_noise_std=0.0)
+FERN = dict(H=378, W=504, focal=407.5, near=0.0, far=1.0, ndc=True, white_bkgd=False, raw_noise_std=1.0)
+
+
+def intrinsics(cfg):
+    H, W, f = cfg["H"], cfg["W"], cfg["focal"]
+    return np.array([[f, 0, 0.5 * W], [0, f, 0.5 * H], [0, 0, 1]], dtype=np.float64)
+
+
+def fern_poses(n_poses=8, seed=0):
+    """Forward-facing LLFF-like camera-to-world matrices [n,3,4]: cameras near the origin looking down -z, jittered
+    by a few degrees and a few tenths of a unit (load_llff.py recentres poses this way)."""
+    rs = np.random.RandomState(4000 + seed)
+    out = []
+    for _ in range(n_poses):
+        ax, ay, az = rs.uniform(-0.12, 0.12), rs.uniform(-0.12, 0.12), rs.uniform(-0.03, 0.03)
+        Rx = np.array([[1, 0, 0], [0, math.cos(ax), -math.sin(ax)], [0, math.sin(ax), math.cos(ax)]])
+        Ry = np.array([[math.cos(ay), 0, math.sin(ay)], [0, 1, 0], [-math.sin(ay), 0, math.cos(ay)]])
+        Rz = np.array([[math.cos(az), -math.sin(az), 0], [math.sin(az), math.cos(az), 0], [0, 0, 1]])
+        t = np.array([rs.uniform(-0.3, 0.3), rs.uniform(-0.2, 0.2), rs.uniform(-0.1, 0.1)])
+        out.append(np.concatenate([Rz @ Ry @ Rx, t[:, None]], 1))
+    return torch.tensor(np.stack(out), dtype=torch.float32)
+
+
+def fern_batch(n, seed=0, cfg=FERN):
+    """cfg3: n rays of random pixels of random forward-facing cameras, as the `use_batching` ray table of train()
+    yields them (run_nerf.py:680-698,716-722): batch_rays [2, n, 3] = (rays_o, rays_d) in WORLD space with d_z < 0;
+    render(..., ndc=True, near=0., far=1.) applies the NDC warp (run_nerf.py:110-112)."""
+    rs = np.random.RandomState(7000 + seed)
+    poses = fern_poses(8, 0).double().numpy()
+    H, W, f = cfg["H"], cfg["W"], cfg["focal"]
+    pid = rs.randint(0, poses.shape[0], size=n)
+    i = rs.randint(0, W, size=n).astype(np.float32)      # column
+    j = rs.randint(0, H, size=n).astype(np.float32)      # row
+    dirs = np.stack([(i - 0.5 * W) / f, -(j - 0.5 * H) / f, -np.ones_like(i)], -1).astype(np.float32)
+    R = poses[pid, :, :3].astype(np.float32)
+    d = np.sum(dirs[:, None, :] * R, -1)                 # get_rays: sum(dirs[..., None, :] * c2w[:3,:3], -1)
+    o = poses[pid, :, 3].astype(np.float32)
+    assert (d[:, 2] < 0).all()
+    return torch.tensor(np.stack([o, d], 0), dtype=torch.float32)
+
+
+def synthetic_randoms(n, n_coarse, n_fine, seed=0, dtype=torch.float32):
+    rs = np.random.RandomState(seed + 1000)
+    mk = lambda a: torch.tensor(a, dtype=dtype)
+    return dict(t_rand=mk(rs.rand(n, n_coarse)), u=mk(rs.rand(n, n_fine)),
+                noise_c=mk(rs.randn(n, n_coarse)), noise_f=mk(rs.randn(n, n_coarse + n_fine)))
+
+
+def psnr(mse):
+    return -10.0 * math.log10(max(float(mse), 1e-300))
+
+
+def precision_gate(rgb, rgb_ref, target):
+    """The north-star acceptance numbers of one rendered image (all [N,3], any device):
+      target_psnr_db   PSNR(reference image, target)           -- the operating point (must be trained-NeRF-like)
+      psnr_delta_db    |PSNR(our image, target) - that|        -- north_star: < 0.01 dB
+      psnr_vs_ref_db   PSNR(our image, reference image)        -- how far the two images are from each other"""
+    rgb, rgb_ref, target = (t.detach().double().cpu().reshape(-1, 3) for t in (rgb, rgb_ref, target))
+    p_ref = psnr(((rgb_ref - target) ** 2).mean())
+    p_hip = psnr(((rgb - target) ** 2).mean())
+    return {"target_psnr_db": p_ref, "psnr_delta_db": abs(p_hip - p_ref),
+            "psnr_vs_ref_db": psnr(((rgb - rgb_ref) ** 2).mean())}
+
+
+# --------------------------------------------------------------------------- synthetic blender-format scene
+def pose_spherical(theta, phi, radius):
+    """Camera-to-world [4,4] on a sphere looking at the origin: the convention of the blender scenes
+    (load_blender.py:10-34), theta / phi in degrees."""
+    th, ph = theta / 180.0 * math.pi, phi / 180.0 * math.pi
+    trans = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]], dtype=np.float64)
+    rot_phi = np.array([[1, 0, 0, 0], [0, math.cos(ph), -math.sin(ph), 0], [0, math.sin(ph), math.cos(ph), 0], [0, 0, 0, 1]])
+    rot_th = np.array([[math.cos(th), 0, -math.sin(th), 0], [0, 1, 0, 0], [math.sin(th), 0, math.cos(th), 0], [0, 0, 0, 1]])
+    flip = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=np.float64)
+    return torch.tensor(flip @ rot_th @ rot_phi @ trans, dtype=torch.float32)
+
+
+_BLOBS = [  # centre, radius, rgb, peak density: an analytic emission-absorption volume (no lego files in this image)
+    ((0.0, 0.0, 0.0), 0.55, (0.9, 0.2, 0.2), 25.0),
+    ((0.6, 0.3, 0.2), 0.30, (0.2, 0.8, 0.3), 40.0),
+    ((-0.5, -0.4, 0.3), 0.35, (0.2, 0.3, 0.9), 30.0),
+    ((0.1, 0.6, -0.5), 0.25, (0.9, 0.8, 0.2), 50.0),
+]
+
+
+def analytic_field(pts):
+    """pts [...,3] -> (rgb [...,3], sigma [...]): a sum of soft-edged coloured balls."""
+    sig = torch.zeros(pts.shape[:-1], dtype=pts.dtype)
+    col = torch.zeros(pts.shape, dtype=pts.dtype)
+    for c, r, rgb, peak in _BLOBS:
+        d2 = ((pts - torch.tensor(c, dtype=pts.dtype)) ** 2).sum(-1)
+        s = peak * torch.sigmoid((r * r - d2) * (12.0 / (r * r)))
+        sig = sig + s
+        col = col + s[..., None] * torch.tensor(rgb, dtype=pts.dtype)
+    return col / sig.clamp_min(1e-8)[..., None], sig
+
+
+def render_analytic(H, W, focal, c2w, near=2.0, far=6.0, n_quad=384, white_bkgd=True):
+    """Ground-truth image [H,W,3] of the analytic volume: emission-absorption quadrature (the volume-rendering
+    integral raw2outputs discretises, run_nerf.py:262-305) with n_quad uniform samples, float64."""
+    i, j = torch.meshgrid(torch.arange(W, dtype=torch.float64), torch.arange(H, dtype=torch.float64), indexing="xy")
+    dirs = torch.stack([(i - 0.5 * W) / focal, -(j - 0.5 * H) / focal, -torch.ones_like(i)], -1)
+    c2w = c2w.double()
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    z = torch.linspace(near, far, n_quad, dtype=torch.float64)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[:, None]
+    rgb, sigma = analytic_field(pts)
+    dist = (far - near) / (n_quad - 1) * rays_d.norm(dim=-1, keepdim=True)
+    alpha = 1.0 - torch.exp(-sigma * dist)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1.0 - alpha + 1e-10], -1), -1)[..., :-1]
+    w = alpha * T
+    img = (w[..., None] * rgb).sum(-2)
+    if white_bkgd:
+        img = img + (1.0 - w.sum(-1))[..., None]
+    return img.float()
+
+
+def blender_scene(H=48, W=48, n_train=12, n_test=3, camera_angle_x=0.6911112070083618, seed=0):
+    """What load_blender_data returns (load_blender.py:37-91) for a synthetic scene: images [V,H,W,3] (white
+    background already composited, run_nerf.py:583-586), poses [V,4,4], hwf, i_split = (train, val, test).
+    Cameras: radius 4, near 2 / far 6 (run_nerf.py:580-581); focal from camera_angle_x as in load_blender.py:71-72."""
+    rs = np.random.RandomState(1234 + seed)
+    focal = 0.5 * W / math.tan(0.5 * camera_angle_x)
+    poses = [pose_spherical(rs.uniform(-180, 180), rs.uniform(-60, -10), 4.0) for _ in range(n_train + 2 * n_test)]
+    imgs = torch.stack([render_analytic(H, W, focal, p) for p in poses], 0)
+    idx = np.arange(len(poses))
+    return {"images": imgs, "poses": torch.stack(poses, 0), "hwf": [H, W, focal],
+            "i_split": (idx[:n_train], idx[n_train:n_train + n_test], idx[n_train + n_test:]),
+            "camera_angle_x": camera_angle_x, "near": 2.0, "far": 6.0}
+
+
+def write_blender_scene(scene, basedir):
+    """Write `scene` in the on-disk format load_blender_data reads (transforms_{train,val,test}.json + RGBA PNGs),
+    so the reference's own run_nerf.py --dataset_type blender can be pointed at it."""
+    import json
+    import os
+    import struct
+    import zlib
+
+    def png(path, rgba):
+        h, w, _ = rgba.shape
+        rows = b"".join(b"\x00" + rgba[y].tobytes() for y in range(h))
+        chunk = lambda tag, data: struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+        with open(path, "wb") as f:
+            f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
+                    chunk(b"IDAT", zlib.compress(rows, 6)) + chunk(b"IEND", b""))
+    for name, ids in zip(("train", "val", "test"), scene["i_split"]):
+        os.makedirs(os.path.join(basedir, name), exist_ok=True)
+        frames = []
+        for k, i in enumerate(ids):
+            rgb = (255 * scene["images"][i].clamp(0, 1)).to(torch.uint8).numpy()
+            rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], -1)
+            png(os.path.join(basedir, name, f"r_{k}.png"), rgba)
+            frames.append({"file_path": f"./{name}/r_{k}", "transform_matrix": scene["poses"][i].tolist()})
+        with open(os.path.join(basedir, f"transforms_{name}.json"), "w") as fp:
+            json.dump({"camera_angle_x": scene["camera_angle_x"], "frames": frames}, fp)
