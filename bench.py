@@ -1,13 +1,29 @@
-"""Contract benchmark: rays/s of the volumetric-rendering training step on MI355X.
+"""Contract benchmark: rays/s of the volumetric-rendering hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched through torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config lego|fern] [--mode train|infer|render_only] [--strong]
 
-One "step" = one pass of the hot path over one batch of synthetic rays, exactly what train() does per
-iteration around render() (run_nerf.py:760-776): render (coarse 64 + fine 128 samples, perturb=1,
-white_bkgd, both networks) -> MSE(rgb)+MSE(rgb0) -> backward -> [RCCL all-reduce of the two flat
-gradient buckets] -> Adam.  Workload = BASELINE.json configs[1]: lego-like, N_rand = 4096 rays per GPU,
-64+128 samples (configs[3] = the same per-GPU work on 8 GPUs, global batch 32768 -> "weak" scaling).
-Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+N > 1: one process per GPU.  Launched by the driver through ``python -m torch.distributed.run ... bench.py --gpus N``
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) -- or directly: ``python bench.py --gpus N`` re-executes
+itself under torch.distributed.run (127.0.0.1 rendezvous) and fails loudly when the box has fewer than N GPUs.
+
+One "step" = one pass of the hot path over one batch of synthetic rays, written exactly as the reference's train() writes
+it around render() (run_nerf.py:760-784):
+
+    rgb, disp, acc, extras = render(H, W, K, chunk=args.chunk, rays=batch_rays, verbose=False, retraw=True, **render_kwargs_train)
+    optimizer.zero_grad(); loss = img2mse(rgb, target_s) + img2mse(extras['rgb0'], target_s); loss.backward()
+    [RCCL all-reduce of the two flat gradient buckets]; optimizer.step()
+
+Workloads (BASELINE.json `configs`; synthetic, seeded: workloads.py):
+    --config lego  (default; configs[1], and configs[3] = the same per-GPU work on 8 GPUs): 400x400, N_rand = 4096
+                   rays per GPU, 64 coarse + 128 fine samples, two 8x256 networks, perturb=1, white_bkgd, no NDC
+    --config fern  (configs[2]): 504x378, focal 407.5, forward-facing rays through the NDC warp, near=0 / far=1,
+                   raw_noise_std=1, perturb=1, no white_bkgd, N_rand = 4096, 64 + 128
+    --mode render_only (configs[4]): one step = one 800x800 frame (640,000 rays in chunks of 32,768, no_grad,
+                   perturb=0) of a pose_spherical spiral; frames are dealt round-robin over the ranks, no collective
+    --strong       (configs[3] as strong scaling): the GLOBAL batch is 32,768 rays, random draws made once for the
+                   full batch from a shared seed and sliced per rank
+Inputs are resident in HBM before the timed region.  `value` is timed with the per-kernel event timer OFF; the per-kernel
+table (`kernels`, `roofline`) comes from a separate pass over the same steps.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -16,36 +32,95 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (ROOT, os.path.join(ROOT, "oracle")):
-    if _p not in sys.path:
-        sys.path.insert(0, _p)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 N_RAND = 4096
 N_SAMPLES, N_IMPORTANCE = 64, 128
-FLOP_FWD_PER_RAY = 2 * 593408 * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)               # 303.82 MFLOP
-FLOP_TRAIN_PER_RAY = 2 * (593408 + 557696 + 593408) * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)  # 893.19 MFLOP
+POINTS_PER_RAY = N_SAMPLES + N_SAMPLES + N_IMPORTANCE
+FLOP_FWD_PER_RAY = 2 * 593408 * POINTS_PER_RAY                                   # 303.82 MFLOP
+FLOP_TRAIN_PER_RAY = 2 * (593408 + 557696 + 593408) * POINTS_PER_RAY             # 893.19 MFLOP
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = vector rate; exact-fp32 datapath
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA; the bf16x3 datapath issues 3 MFMA FLOPs per algorithmic FLOP
+PEAK_HBM_GBS = 8000.0               # HBM3E spec (~6.3 TB/s achievable, MI355X_MICROARCH.md)
+DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products, f32 accumulate/activations/gradients)",
+              "mixed": "bf16x3 forward + bf16 backward (mixed-precision training option)"}
 
 
-def cpu_baseline(n_rays=512):
-    """The oracle (bit-identical restatement of the reference, CPU, fp32) timed on this box's host cores on a
-    bounded sample of the same workload: one training step of n_rays rays x (64+128) samples."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=["lego", "fern"], default="lego")
+    ap.add_argument("--mode", choices=["train", "infer", "render_only"], default="train")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: global batch of 32768 rays split over the ranks")
+    ap.add_argument("--rays", type=int, default=N_RAND, help="rays per GPU per step (weak scaling)")
+    ap.add_argument("--frame", type=int, default=800, help="render_only: frame side in pixels")
+    ap.add_argument("--chunk", type=int, default=1024 * 32)
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "mixed"], default=os.environ.get("NERF_BENCH_PRECISION", "bf16x3"),
+                    help="headline field datapath.  bf16x3 = split-bf16 (3 bf16 MFMAs per product, fp32 accumulate, fp32 "
+                         "activations / gradients), admitted by the north-star PSNR criterion, which this run re-measures and "
+                         "prints (`precision_gate`); fp32 = exact fp32 MFMA (the parity anchor).  The other datapath is measured "
+                         "in the same run (`other_datapath`).")
+    ap.add_argument("--single-datapath", action="store_true", help="skip the secondary datapath measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true")
+    ap.add_argument("--no-gate", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group plumbing only (no GPU work): used by the CPU test of the N > 1 launch path")
+    return ap.parse_args(argv)
+
+
+def relaunch_if_needed(args):
+    """`python bench.py --gpus N` with no torchrun environment: become N ranks."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but this box exposes {have} GPU(s); refusing to report a "
+                             f"{args.gpus}-GPU number from fewer devices\n")
+            sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execve(sys.executable, cmd, env)
+
+
+# --------------------------------------------------------------------------------------------- baselines (reported beside)
+def cpu_baseline(cfg_name, n_rays=512):
+    """The oracle (bit-identical restatement of the reference, CPU, fp32) timed on this box's host cores on a bounded
+    sample of the same workload: training steps of n_rays rays x (64+128) samples."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as orc
-    Pc, Pf = orc.scene_params()
+    import workloads as wl
+    cfg = wl.LEGO if cfg_name == "lego" else wl.FERN
+    Pc, Pf = wl.scene_params()
     Pc = {k: v.requires_grad_(True) for k, v in Pc.items()}
     Pf = {k: v.requires_grad_(True) for k, v in Pf.items()}
     opt = torch.optim.Adam(list(Pc.values()) + list(Pf.values()), lr=5e-4, betas=(0.9, 0.999))
-    rays = orc.synthetic_rays(n_rays, seed=1)
+    batch = wl.lego_batch(n_rays, seed=1) if cfg_name == "lego" else wl.fern_batch(n_rays, seed=1)
+    rays = orc.assemble_render_rays(cfg["H"], cfg["W"], wl.intrinsics(cfg), batch[0], batch[1], cfg["ndc"], cfg["near"], cfg["far"])
     target = torch.rand(n_rays, 3)
+    std = cfg["raw_noise_std"]
 
     def step():
         opt.zero_grad()
-        t_rand, u = torch.rand(n_rays, N_SAMPLES), torch.rand(n_rays, N_IMPORTANCE)
-        out = orc.trace_rays(rays, Pc, Pf, N_SAMPLES, N_IMPORTANCE, perturb=1.0, white_bkgd=True, t_rand=t_rand, u=u)
+        rnd = dict(t_rand=torch.rand(n_rays, N_SAMPLES), u=torch.rand(n_rays, N_IMPORTANCE))
+        if std > 0:
+            rnd.update(noise_c=torch.randn(n_rays, N_SAMPLES), noise_f=torch.randn(n_rays, N_SAMPLES + N_IMPORTANCE))
+        out = orc.trace_rays(rays, Pc, Pf, N_SAMPLES, N_IMPORTANCE, perturb=1.0, white_bkgd=cfg["white_bkgd"],
+                             raw_noise_std=std, **rnd)
         loss = orc.mse(out["rgb_map"], target) + orc.mse(out["rgb0"], target)
         loss.backward()
         opt.step()
@@ -57,14 +132,63 @@ def cpu_baseline(n_rays=512):
         reps += 1
     dt = (time.perf_counter() - t0) / reps
     return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} training steps of {n_rays} rays x (64+128) samples (oracle = bit-identical "
+            "sample": f"{reps} training steps of {n_rays} rays x (64+128) samples, {cfg_name} workload (oracle = bit-identical "
                       f"restatement of the reference, torch CPU fp32, {torch.get_num_threads()} threads of "
                       f"{os.cpu_count()} host CPUs)"}
 
 
-PEAK_HBM_GBS = 8000.0               # HBM3E spec (≈6.3 TB/s achievable, MI355X_MICROARCH.md)
+def rocm_eager_baseline(cfg_name, dev, n_rays, steps=3):
+    """Baseline leg: the reference's own algorithm as eager PyTorch-ROCm ops on this GPU (the oracle's torch ops with CUDA
+    tensors = what run_nerf.py executes after set_default_tensor_type('torch.cuda.FloatTensor'), run_nerf.py:876), same
+    workload shape, training step and no_grad render.  It is the denominator of the north-star '>= 10x' target; like
+    cpu_baseline it is timed beside the product, never part of `value`."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nerf_oracle as orc
+    import workloads as wl
+    cfg = wl.LEGO if cfg_name == "lego" else wl.FERN
+    Pc, Pf = wl.scene_params()
+    Pc = {k: v.to(dev).requires_grad_(True) for k, v in Pc.items()}
+    Pf = {k: v.to(dev).requires_grad_(True) for k, v in Pf.items()}
+    opt = torch.optim.Adam(list(Pc.values()) + list(Pf.values()), lr=5e-4, betas=(0.9, 0.999))
+    batch = (wl.lego_batch(n_rays, seed=1) if cfg_name == "lego" else wl.fern_batch(n_rays, seed=1)).to(dev)
+    K = wl.intrinsics(cfg)
+    target = torch.rand(n_rays, 3, device=dev)
+    std = cfg["raw_noise_std"]
+
+    def train():
+        rays = orc.assemble_render_rays(cfg["H"], cfg["W"], K, batch[0], batch[1], cfg["ndc"], cfg["near"], cfg["far"])
+        rnd = dict(t_rand=torch.rand(n_rays, N_SAMPLES, device=dev), u=torch.rand(n_rays, N_IMPORTANCE, device=dev))
+        if std > 0:
+            rnd.update(noise_c=torch.randn(n_rays, N_SAMPLES, device=dev), noise_f=torch.randn(n_rays, N_SAMPLES + N_IMPORTANCE, device=dev))
+        out = orc.trace_rays(rays, Pc, Pf, N_SAMPLES, N_IMPORTANCE, perturb=1.0, white_bkgd=cfg["white_bkgd"], raw_noise_std=std,
+                             retraw=True, **rnd)
+        opt.zero_grad()
+        loss = orc.mse(out["rgb_map"], target) + orc.mse(out["rgb0"], target)
+        loss.backward()
+        opt.step()
+
+    def infer():
+        with torch.no_grad():
+            rays = orc.assemble_render_rays(cfg["H"], cfg["W"], K, batch[0], batch[1], cfg["ndc"], cfg["near"], cfg["far"])
+            orc.trace_rays(rays, Pc, Pf, N_SAMPLES, N_IMPORTANCE, perturb=0.0, white_bkgd=cfg["white_bkgd"], retraw=True)
+    res = {}
+    for name, fn in (("train", train), ("infer", infer)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        res[name] = n_rays * steps / (time.perf_counter() - t0)
+    del Pc, Pf, opt
+    torch.cuda.empty_cache()
+    return {"train_rays_per_s": res["train"], "infer_rays_per_s": res["infer"], "unit": "rays/s", "steps": steps,
+            "what": f"reference algorithm as eager PyTorch-ROCm ops on this GPU (oracle ops on cuda tensors), {n_rays} rays x (64+128), "
+                    f"{cfg_name} workload, torch {torch.__version__}"}
 
 
+# --------------------------------------------------------------------------------------------- per-kernel table / roofline
 def kernel_table(kern, precision):
     """per timed kernel: average launch time, algorithmic TFLOP/s and GB/s, and its fraction of both roofs"""
     issued = 1.0 if precision == "fp32" else 3.0        # bf16x3 issues every algorithmic FLOP three times on the bf16 pipe
@@ -86,31 +210,34 @@ def kernel_table(kern, precision):
 
 
 def pmc_traffic(kernel_name, precision):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary of this same command
-    (separate --pmc passes; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_bf16x3_pmc_summary.csv" if precision == "bf16x3" else "r01_pmc_summary.csv")
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary of this same command (separate --pmc
+    passes; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the
+    process, so this is the profile of the same command committed under profiles/ (None if absent)."""
+    tag = {"bf16x3": "bf16x3_", "mixed": "mixed_"}.get(precision, "")
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}pmc_summary.csv")
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
     key = kernel_name.split("<")[0].split("(")[0]
     fetch = write = None
-    try:
-        for line in open(path):
-            if line.startswith("#") or "," not in line:
-                continue
-            kn, cn, _, val = line.rstrip().rsplit(",", 3)
-            base = kn.replace("void ", "").replace("nerf::", "")
-            tmpl = base.split("<")[1].split(">")[0] if "<" in base else ""
-            if base.split("<")[0].split("(")[0] != key:
-                continue
-            if key in ("field_fwd3_kernel", "field_fwd16_kernel") and (tmpl in ("1", "true")) != ("<save>" in kernel_name):
-                continue
-            if key == "field_dgrad3_kernel" and (tmpl in ("1", "true")) != ("<mixed>" in kernel_name):
-                continue
-            if True:
-                if cn == "FETCH_SIZE":
-                    fetch = float(val)
-                elif cn == "WRITE_SIZE":
-                    write = float(val)
-    except OSError:
-        return None, None
+    for line in open(path):
+        if line.startswith("#") or "," not in line:
+            continue
+        kn, cn, _, val = line.rstrip().rsplit(",", 3)
+        base = kn.replace("void ", "").replace("nerf::", "").strip('"')
+        tmpl = base.split("<")[1].split(">")[0] if "<" in base else ""
+        if base.split("<")[0].split("(")[0] != key:
+            continue
+        if key in ("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd_kernel") and (tmpl not in ("0", "false", "")) != ("<save" in kernel_name):
+            continue
+        if key == "field_dgrad3_kernel" and (tmpl in ("1", "true")) != ("<mixed>" in kernel_name):
+            continue
+        if cn == "FETCH_SIZE":
+            fetch = float(val)
+        elif cn == "WRITE_SIZE":
+            write = float(val)
     if fetch is None or write is None:
         return None, None
     return (2.0 * fetch + write) * 1024.0, os.path.relpath(path, ROOT)
@@ -132,126 +259,235 @@ def roofline_of(table):
             "also": {"hbm_frac": k["hbm_frac"], "algorithmic_GBps": k["algorithmic_GBps"]}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["train", "infer"], default="train")
-    ap.add_argument("--rays", type=int, default=N_RAND, help="rays per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3", "mixed"], default=os.environ.get("NERF_BENCH_PRECISION", "bf16x3"),
-                    help="headline field datapath: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate; PSNR delta vs the "
-                         "reference 2e-5 dB, tests/test_gpu_parity.py) or exact fp32 MFMA (the parity anchor). The other "
-                         "datapath is measured too (fewer steps) and reported in the same JSON line, and so is the "
-                         "mixed-precision training option (bf16x3 forward + bf16 backward; 'mixed'), which is never the "
-                         "default headline because its gradients are bf16-rounded.")
-    ap.add_argument("--single-datapath", action="store_true", help="skip the secondary datapath measurement")
-    args = ap.parse_args()
+def rccl_version():
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:       # version query only; never fail the bench on it
+        return f"unknown ({type(e).__name__})"
 
-    import nerf_oracle as orc
-    import nerf_pytorch_amd as npa
+
+# --------------------------------------------------------------------------------------------- main
+def dry_run(args):
+    """Launcher / process-group plumbing without GPU work (CPU test of the N > 1 path): rendezvous, sharding arithmetic,
+    one all-reduce over a flat bucket of the gradient's size, max-over-ranks timing, rank-0 JSON line."""
+    import torch
+    import torch.distributed as dist
     from nerf_pytorch_amd import parallel
+    rank, world, dev = parallel.init_distributed(backend=args.backend or "gloo")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
+    n_global = 32768 if args.strong else args.rays * world
+    lo, hi = parallel.shard_slice(n_global, rank, world)
+    bucket = torch.full((595844,), float(rank + 1))
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(bucket)
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    assert float(bucket[0]) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher plumbing only)", "value": None, "unit": "rays/s", "n_gpus": world,
+                          "world_size": dist.get_world_size() if world > 1 else 1, "backend": args.backend or "gloo",
+                          "scaling": "strong" if args.strong else "weak", "rays_per_rank": hi - lo,
+                          "global_batch_rays": n_global, "dry_run": True}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def main():
+    args = parse_args()
+    relaunch_if_needed(args)
+    if args.dry_run:
+        return dry_run(args)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import nerf_pytorch_amd as npa
+    import workloads as wl
+    from nerf_pytorch_amd import parallel
+    hb = npa.hip_backend
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the render hot path has no CPU fallback)")
     npa.set_precision(args.precision)
-    rank, world, dev = parallel.init_distributed()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (the render hot path has no CPU fallback)"
-    n = args.rays
+    rank, world, dev = parallel.init_distributed(backend=args.backend)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run with "
+                         f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` without a torchrun environment)")
+    if torch.cuda.device_count() < (world if "LOCAL_RANK" in os.environ else 1):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
 
-    Pc, Pf = orc.scene_params()
+    cfg = wl.LEGO if args.config == "lego" else wl.FERN
+    H, W, K = cfg["H"], cfg["W"], wl.intrinsics(cfg)
+    if args.strong:
+        n_global = 32768
+        lo, hi = parallel.shard_slice(n_global, rank, world)
+        n = hi - lo
+    else:
+        n = args.rays
+        n_global = n * world
+        lo, hi = rank * n, (rank + 1) * n
+
+    Pc, Pf = wl.scene_params()
     kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
     net_c, net_f = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
     net_c.load_state_dict(Pc)
     net_f.load_state_dict(Pf)
     parallel.broadcast_parameters([net_c, net_f])
     # torch.optim.Adam semantics (run_nerf.py:207), fused over the two flat parameter vectors (state_dict compatible)
-    opt = npa.FlatAdam(list(net_c.parameters()) + list(net_f.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    optimizer = npa.FlatAdam(list(net_c.parameters()) + list(net_f.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    # the dict create_nerf builds (run_nerf.py:237-259) for this config
+    render_kwargs_train = dict(network_query_fn=None, perturb=1.0, N_importance=N_IMPORTANCE, network_fine=net_f,
+                               N_samples=N_SAMPLES, network_fn=net_c, use_viewdirs=True, white_bkgd=cfg["white_bkgd"],
+                               raw_noise_std=cfg["raw_noise_std"], ndc=cfg["ndc"], lindisp=False, near=cfg["near"], far=cfg["far"])
+    render_kwargs_test = dict(render_kwargs_train, perturb=False, raw_noise_std=0.)
 
-    # synthetic data, resident in HBM: a pool of ray batches (rank-dependent seeds) + targets
+    # synthetic data, resident in HBM: a pool of ray batches + targets.  weak: rank-dependent seeds; strong: one global
+    # batch per pool slot, every rank takes its slice (and the random draws are made once for the full batch, below)
     pool = 8
-    rays = [orc.synthetic_rays(n, seed=1000 * rank + i).to(dev) for i in range(pool)]
-    gen = torch.Generator().manual_seed(77 + rank)
-    targets = [torch.rand(n, 3, generator=gen).to(dev) for _ in range(pool)]
-    render_kw = dict(N_samples=N_SAMPLES, N_importance=N_IMPORTANCE, network_fine=net_f, white_bkgd=True,
-                     raw_noise_std=0., retraw=True)
+    make = wl.lego_batch if args.config == "lego" else wl.fern_batch
+    if args.strong:
+        batches = [make(n_global, seed=100 + i)[:, lo:hi].contiguous().to(dev) for i in range(pool)]
+        targets = [torch.rand(n_global, 3, generator=torch.Generator().manual_seed(77 + i))[lo:hi].to(dev) for i in range(pool)]
+    else:
+        batches = [make(n, seed=1000 * rank + i).to(dev) for i in range(pool)]
+        gen = torch.Generator().manual_seed(77 + rank)
+        targets = [torch.rand(n, 3, generator=gen).to(dev) for _ in range(pool)]
+    strong_gen = torch.Generator(device=dev).manual_seed(4242) if args.strong else None
+
+    def strong_randoms():
+        """random draws of the GLOBAL batch in the reference's order from a generator every rank seeds identically;
+        each rank keeps its slice, so the N-GPU step computes exactly the 1-GPU N_rand=32768 step"""
+        r = {"t_rand": torch.rand((n_global, N_SAMPLES), device=dev, generator=strong_gen)}
+        if cfg["raw_noise_std"] > 0:
+            r["noise_c"] = torch.randn((n_global, N_SAMPLES), device=dev, generator=strong_gen)
+        r["u"] = torch.rand((n_global, N_IMPORTANCE), device=dev, generator=strong_gen)
+        if cfg["raw_noise_std"] > 0:
+            r["noise_f"] = torch.randn((n_global, N_SAMPLES + N_IMPORTANCE), device=dev, generator=strong_gen)
+        return {k: v[lo:hi].contiguous() for k, v in r.items()}
 
     def train_step(i):
-        opt.zero_grad()
-        out = npa.render_rays(rays[i % pool], net_c, None, perturb=1.0, **render_kw)
-        t = targets[i % pool]
-        loss = npa.img2mse(out["rgb_map"], t) + npa.img2mse(out["rgb0"], t)
+        batch_rays, target_s = batches[i % pool], targets[i % pool]
+        extra = {"randoms": strong_randoms()} if args.strong else {}
+        rgb, disp, acc, extras = npa.render(H, W, K, chunk=args.chunk, rays=batch_rays, verbose=False, retraw=True,
+                                            **render_kwargs_train, **extra)
+        optimizer.zero_grad()
+        loss = npa.img2mse(rgb, target_s) + npa.img2mse(extras["rgb0"], target_s)
         loss.backward()
         parallel.allreduce_gradients([net_c, net_f])
-        opt.step()
+        optimizer.step()
 
     def infer_step(i):
         with torch.no_grad():
-            npa.render_rays(rays[i % pool], net_c, None, perturb=0., **render_kw)
+            npa.render(H, W, K, chunk=args.chunk, rays=batches[i % pool], retraw=True, **render_kwargs_test)
 
-    step = train_step if args.mode == "train" else infer_step
+    # render_only (configs[4]): frames of a pose_spherical spiral (load_blender.py:75), dealt round-robin
+    fr = args.frame
+    fr_focal = cfg["focal"] * fr / cfg["W"]
+    Kf = np.array([[fr_focal, 0, 0.5 * fr], [0, fr_focal, 0.5 * fr], [0, 0, 1]])
+    spiral = [wl.pose_spherical(a, -30.0, 4.0) for a in np.linspace(-180, 180, 40 + 1)[:-1]]
+
+    def frame_step(i):
+        frame_id = (rank + i * world) % len(spiral)          # parallel.frames_of_rank dealing: frame f -> rank f mod G
+        with torch.no_grad():
+            npa.render(fr, fr, Kf, chunk=args.chunk, c2w=spiral[frame_id][:3, :4], **render_kwargs_test)
+
+    if args.mode == "render_only" and args.config != "lego":
+        raise SystemExit("bench.py: --mode render_only is BASELINE configs[4] (lego spiral); use --config lego")
+    step = {"train": train_step, "infer": infer_step, "render_only": frame_step}[args.mode]
+    rays_per_step = fr * fr if args.mode == "render_only" else n
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(precision, steps, warmup):
+    def measure(precision, steps, warmup, fn, with_kernels):
+        """(seconds for `steps` steps with the per-kernel timer OFF, max over ranks; per-kernel summary of a SEPARATE pass)"""
         npa.set_precision(precision)
+        hb.TIMER = None
         for i in range(warmup):
-            step(i)
-        timer = npa.hip_backend.KernelTimer()
-        npa.hip_backend.TIMER = timer
+            fn(i)
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i)
+            fn(i)
         barrier()
         el = time.perf_counter() - t0
-        npa.hip_backend.TIMER = None
-        kern = timer.summary()
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+        kern = {}
+        if with_kernels:
+            timer = hb.KernelTimer()
+            hb.TIMER = timer
+            for i in range(max(2, min(steps, 6))):
+                fn(i)
+            torch.cuda.synchronize()
+            hb.TIMER = None
+            kern = timer.summary()
         return el, kern
 
-    elapsed, kern = measure(args.precision, args.steps, args.warmup)
+    elapsed, kern = measure(args.precision, args.steps, args.warmup, step, with_kernels=True)
 
-    # secondary numbers (not the headline): inference on the same batch shape, and the other datapath
-    other = None
+    # ---- secondary numbers of the same run (never the headline)
+    other_infer = second = second_mixed = None
     if args.mode == "train":
-        for i in range(2):
-            infer_step(i)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(max(5, args.steps // 2)):
-            infer_step(i)
-        barrier()
-        other = n * world * max(5, args.steps // 2) / (time.perf_counter() - t1)
-    second = second_mixed = None
-    if not args.single_datapath:
+        k_inf = max(5, args.steps // 2)
+        el_i, _ = measure(args.precision, k_inf, 2, infer_step, with_kernels=False)
+        other_infer = n * world * k_inf / el_i
+    if not args.single_datapath and args.mode != "render_only":
         p2 = "bf16x3" if args.precision == "fp32" else "fp32"
         k2 = max(4, args.steps // 4)
-        el2, kern2 = measure(p2, k2, 2)
+        el2, kern2 = measure(p2, k2, 2, step, with_kernels=True)
         tab2 = kernel_table(kern2, p2)
-        second = {"dtype": "f32" if p2 == "fp32" else "bf16x3", "value": n * world * k2 / el2, "unit": "rays/s",
+        second = {"dtype": DTYPE_NAME[p2].split(" ")[0], "value": n * world * k2 / el2, "unit": "rays/s",
                   "steps": k2, "ms_per_step": 1e3 * el2 / k2, "roofline": roofline_of(tab2),
                   "kernels": {k: {"avg_ms": v["avg_ms"], "mfma_frac": v["mfma_frac"], "hbm_frac": v["hbm_frac"]}
                               for k, v in tab2.items()}}
         if args.mode == "train" and args.precision != "mixed":
             k3 = max(4, args.steps // 2)
-            el3, kern3 = measure("mixed", k3, 2)
+            el3, kern3 = measure("mixed", k3, 2, step, with_kernels=True)
             tab3 = kernel_table(kern3, "mixed")
-            second_mixed = {"dtype": "bf16x3 forward (outputs identical to the headline datapath) + bf16 backward (saved activations / "
-                                     "deltas rounded to bf16, one bf16 MFMA per product, f32 accumulate)",
+            second_mixed = {"dtype": "bf16x3 forward (outputs identical to the bf16x3 datapath) + bf16 backward (saved activations / "
+                                     "deltas rounded to bf16, one bf16 MFMA per product, f32 accumulate); gradients are NOT fp32-class",
                             "value": n * world * k3 / el3, "unit": "rays/s", "steps": k3, "ms_per_step": 1e3 * el3 / k3,
                             "kernels": {k: {"avg_ms": v["avg_ms"], "mfma_frac": v["mfma_frac"], "hbm_frac": v["hbm_frac"]}
                                         for k, v in tab3.items()}}
-        npa.set_precision(args.precision)
+    npa.set_precision(args.precision)
+
+    # ---- the north-star acceptance gate of the headline datapath, measured in this run: our image vs the image the
+    # REAL reference rendered for the same rays / weights (committed fixture tests/golden/gate_<config>.npz,
+    # generated by tests/golden/make_golden.py --round2 from /root/reference), against a teacher-scene target
+    gate = None
+    if not args.no_gate and rank == 0:
+        gpath = os.path.join(ROOT, "tests", "golden", f"gate_{args.config}.npz")
+        if os.path.exists(gpath):
+            gold = np.load(gpath)
+            gbatch = (wl.lego_batch(1024, seed=31) if args.config == "lego" else wl.fern_batch(1024, seed=32)).to(dev)
+            # the timed steps have trained net_c / net_f: the gate is evaluated on the fixture's weights
+            gate_nets = (npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev))
+            gate_nets[0].load_state_dict(Pc)
+            gate_nets[1].load_state_dict(Pf)
+            with torch.no_grad():
+                rgb_g = npa.render(H, W, K, chunk=args.chunk, rays=gbatch,
+                                   **dict(render_kwargs_test, network_fn=gate_nets[0], network_fine=gate_nets[1]))[0]
+            gate = wl.precision_gate(rgb_g, torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"]))
+            gate.update(datapath=args.precision, rays=1024, bar_psnr_delta_db=0.01,
+                        passed=bool(gate["psnr_delta_db"] < 0.01 and gate["target_psnr_db"] >= 30.0),
+                        what="PSNR of our image vs the reference's image (real reference, CPU fp32, fixture gate_%s.npz) against a "
+                             "teacher-scene target at target_psnr_db; north_star: psnr_delta_db < 0.01" % args.config)
 
     if rank == 0:
-        total_rays = n * world * args.steps
+        total_rays = rays_per_step * world * args.steps
         value = total_rays / elapsed
         flop_per_ray = FLOP_TRAIN_PER_RAY if args.mode == "train" else FLOP_FWD_PER_RAY
         kernels = kernel_table(kern, args.precision)
@@ -261,36 +497,53 @@ def main():
             if tr is not None:
                 k = kernels[roofline["kernel"]]
                 roofline["traffic"] = tr
-                roofline["traffic_note"] = (f"bytes per launch (mean over coarse+fine launches) from {src}: 2*FETCH_SIZE + WRITE_SIZE; "
-                                            f"algorithmic bytes per launch here: {k['algorithmic_GBps'] * 1e9 * k['avg_ms'] * 1e-3:.4g}")
+                roofline["traffic_note"] = (f"bytes per launch (mean over coarse+fine launches) from {src} (rocprofv3 --pmc passes of this "
+                                            f"command): 2*FETCH_SIZE + WRITE_SIZE; algorithmic bytes per launch here: "
+                                            f"{k['algorithmic_GBps'] * 1e9 * k['avg_ms'] * 1e-3:.4g}")
             issued = 1.0 if args.precision == "fp32" else 3.0
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
             roofline["whole_step_mfma_frac"] = value * flop_per_ray * issued / world / 1e12 / peak
+        workload = {
+            "train": f"{args.config}-like {W}x{H}, N_rand={n} rays/GPU x (64 coarse + 128 fine) samples, two 8x256 networks, perturb=1, "
+                     + ("white_bkgd" if cfg["white_bkgd"] else f"NDC rays near=0 far=1, raw_noise_std={cfg['raw_noise_std']}")
+                     + "; step = render() + MSE(rgb)+MSE(rgb0) + backward" + (" + RCCL grad all-reduce" if world > 1 else "") + " + fused Adam",
+            "infer": f"{args.config}-like, {n} rays/GPU x (64+128) samples, no_grad render()",
+            "render_only": f"lego render_only: {fr}x{fr} frames of a pose_spherical spiral, {fr * fr} rays/frame in chunks of {args.chunk}, "
+                           f"no_grad render(c2w=...), one frame per GPU per step, frames dealt round-robin, no collective",
+        }[args.mode]
         line = {
-            "metric": "rays/sec (coarse+fine, 64+128 samples), training step" if args.mode == "train"
-                      else "rays/sec (coarse+fine, 64+128 samples), inference",
+            "metric": {"train": "rays/sec (coarse+fine, 64+128 samples), training step",
+                       "infer": "rays/sec (coarse+fine, 64+128 samples), inference",
+                       "render_only": "rays/sec (coarse+fine, 64+128 samples), render_only frames"}[args.mode],
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products, f32 accumulate/activations/gradients)",
-                      "mixed": "bf16x3 forward + bf16 backward (mixed-precision training option)"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": f"lego-like 400x400, N_rand={n} rays/GPU x (64 coarse + 128 fine) samples, "
-                                   "two 8x256 networks, perturb=1, white_bkgd; step = render + MSE + backward"
-                                   + (" + RCCL grad all-reduce" if world > 1 else "") + " + Adam"
-                                   if args.mode == "train" else
-                                   f"lego-like, {n} rays/GPU x (64+128) samples, no_grad render",
-                       "global_batch_rays": n * world, "parallelism": f"ray-shard dp{world}"},
-            "roofline": roofline, "kernels": kernels,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
+            "config": {"workload": workload, "global_batch_rays": rays_per_step * world if args.mode == "render_only" else n_global,
+                       "parallelism": f"ray-shard dp{world}" if args.mode != "render_only" else f"frame-parallel x{world}",
+                       "boundary": "nerf_pytorch_amd.render(H, W, K, chunk, rays=batch_rays, **render_kwargs) as run_nerf.py:760"},
+            "world_size": dist.get_world_size() if world > 1 else 1,
+            "collective": (f"RCCL {rccl_version()} all-reduce (torch.distributed backend nccl), 2 x 2.38 MB fp32 per step"
+                           if world > 1 and args.mode == "train" else None),
+            "precision_gate": gate, "roofline": roofline, "kernels": kernels,
         }
-        if other is not None:
-            line["inference_rays_per_s"] = other
+        if other_infer is not None:
+            line["inference_rays_per_s"] = other_infer
         if second is not None:
             line["other_datapath"] = second
         if second_mixed is not None:
             line["mixed_precision_training"] = second_mixed
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_eager_baseline and args.mode != "render_only":
+            eb = rocm_eager_baseline(args.config, dev, n)
+            line["rocm_eager_baseline"] = eb
+            ref = eb["train_rays_per_s"] if args.mode == "train" else eb["infer_rays_per_s"]
+            line["speedup_vs_rocm_eager"] = {"headline": value / ref}
+            if second is not None:
+                line["speedup_vs_rocm_eager"][second["dtype"]] = second["value"] / ref
+            if other_infer is not None:
+                line["speedup_vs_rocm_eager"]["inference"] = other_infer / eb["infer_rays_per_s"]
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

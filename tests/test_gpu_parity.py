@@ -276,40 +276,195 @@ def test_field_backward(npa, dev, nets, n_rays, S):
     assert maxdiff(grad_dev, 2 * grad) <= 1e-3 * float(grad.abs().max())
 
 
-# ---------------------------------------------------------------- end to end vs golden (reference-produced)
-def _check_golden(npa, dev, nets, name, kw, seed):
-    """HIP render_rays + loss + backward vs numbers produced by the real reference (fp32, CPU).
-    Tolerance per quantity = max(floor, 10 x the reference's own fp32-vs-fp64 rounding noise on the same
-    inputs, stored in the fixture): the fine pass inherits sample_pdf's conditioning (denominators ~1e-5,
-    helpers:234-236), so its noise floor is 1e-5..5e-4 where the coarse pass sits at 1e-6."""
+@pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192)])
+def test_field_backward_no_exclusion(npa, dev, nets, n_rays, S):
+    """The same comparison with NO point excluded: ReLU units within rounding of zero may take the other side of the
+    kink (about one unit per million in fp32), so the bound is on each tensor's direction and norm, not on every entry."""
     nc, nf, Pc, Pf = nets
+    g = torch.Generator().manual_seed(7 * n_rays + S)
+    rays = orc.synthetic_rays(n_rays, seed=S + 1)
+    z = torch.sort(torch.rand(n_rays, S, generator=g) * 4.0 + 2.0, -1)[0]
+    d_raw = torch.randn(n_rays, S, 4, generator=g)
+    raw, act = npa.hip_backend.field_fwd(nf.packed_params(), rays.to(dev), z.to(dev), save_act=True)
+    grad = torch.full((595844,), float("nan"), device=dev)
+    npa.hip_backend.field_bwd(nf.packed_params(), act, d_raw.to(dev), grad, accumulate=False)
+    P64 = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]
+    (orc.query_field(P64, pts.double(), rays[:, 8:11].double()) * d_raw.double()).sum().backward()
+    grad = grad.cpu().double()
+    rel, cosdef = {}, {}
+    for nm, off, shape in npa.hip_backend.param_table():
+        gg, r = grad[off:off + int(np.prod(shape))].view(shape), P64[nm].grad
+        rel[nm] = float((gg - r).norm() / r.norm())
+        cosdef[nm] = 1.0 - float((gg * r).sum() / (gg.norm() * r.norm()))
+    print("no exclusion: worst relative L2 error", max(rel.values()), "worst cosine deficit", max(cosdef.values()))
+    assert max(rel.values()) <= 1e-4, rel
+    assert max(cosdef.values()) <= 1e-8, cosdef
+
+
+def test_raw2outputs_weight_and_depth_gradients(npa, dev):
+    """All five outputs of raw2outputs carry gradients to raw in the reference (a depth / weight-sparsity loss term):
+    d_weights and d_depth through the HIP adjoint vs fp64 autograd of the oracle."""
+    n, S = 70, 96
+    g = torch.Generator().manual_seed(4)
+    raw = torch.randn(n, S, 4, generator=g) * 3.0
+    z = torch.sort(torch.rand(n, S, generator=g) * 4.0 + 2.0, -1)[0]
+    rays_d = torch.randn(n, 3, generator=g)
+    cw, cd, crgb = torch.randn(n, S, generator=g), torch.randn(n, generator=g), torch.randn(n, 3, generator=g)
+    raw64 = raw.double().requires_grad_(True)
+    rgb, disp, acc, w, depth = orc.composite(raw64, z.double(), rays_d.double(), None, True)
+    ((w * cw.double()).sum() + (depth * cd.double()).sum() + (rgb * crgb.double()).sum()).backward()
+    rawg = raw.to(dev).requires_grad_(True)
+    o = npa.raw2outputs(rawg, z.to(dev), rays_d.to(dev), 0.0, True)
+    ((o[3] * cw.to(dev)).sum() + (o[4] * cd.to(dev)).sum() + (o[0] * crgb.to(dev)).sum()).backward()
+    scale = float(raw64.grad.abs().max())
+    assert maxdiff(rawg.grad, raw64.grad) <= 2e-5 * max(1.0, scale), (maxdiff(rawg.grad, raw64.grad), scale)
+    # weights-only loss (no rgb term at all)
+    rawg2 = raw.to(dev).requires_grad_(True)
+    (npa.raw2outputs(rawg2, z.to(dev), rays_d.to(dev), 0.0, True)[3] * cw.to(dev)).sum().backward()
+    raw64b = raw.double().requires_grad_(True)
+    (orc.composite(raw64b, z.double(), rays_d.double(), None, True)[3] * cw.double()).sum().backward()
+    assert maxdiff(rawg2.grad, raw64b.grad) <= 2e-5 * max(1.0, float(raw64b.grad.abs().max()))
+
+
+def test_render_rays_raw_output_carries_gradients(npa, dev):
+    """extras['raw'] is differentiable in the reference (a sigma regulariser on raw[..., 3] trains the networks)."""
+    Pc, Pf = orc.scene_params(seed=3)
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    nc, nf = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
+    nc.load_state_dict(Pc); nf.load_state_dict(Pf)
+    rays = orc.synthetic_rays(40, seed=8)
+    target = torch.rand(40, 3, generator=torch.Generator().manual_seed(1))
+    out = npa.render_rays(rays.to(dev), nc, None, 64, N_importance=128, network_fine=nf, white_bkgd=True, retraw=True)
+    loss = npa.img2mse(out["rgb_map"], target.to(dev)) + 1e-3 * torch.relu(out["raw"][..., 3]).mean()
+    loss.backward()
+    Pc_g = {k: v.clone().double().requires_grad_(True) for k, v in Pc.items()}
+    Pf_g = {k: v.clone().double().requires_grad_(True) for k, v in Pf.items()}
+    ref = orc.trace_rays(rays.double(), Pc_g, Pf_g, 64, 128, white_bkgd=True, retraw=True)
+    (orc.mse(ref["rgb_map"], target.double()) + 1e-3 * torch.relu(ref["raw"][..., 3]).mean()).backward()
+    stable = ~orc.endpoint_unstable(ref["_weights0"])
+    assert stable.all(), "pick another seed: this test wants no endpoint-unstable ray"
+    for k, p in nf.named_parameters():
+        r = Pf_g[k].grad
+        assert maxdiff(p.grad, r) <= 2e-3 * float(r.abs().max()) + 1e-9, (k, maxdiff(p.grad, r), float(r.abs().max()))
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in nc.parameters())   # coarse net: rgb0 not in this loss
+
+
+def test_second_backward_fails_loudly(npa, dev, nets):
+    nc, nf, Pc, Pf = nets
+    rays = orc.synthetic_rays(8, seed=1).to(dev)
+    out = npa.render_rays(rays, nc, None, 64, N_importance=128, network_fine=nf, white_bkgd=True)
+    loss = out["rgb_map"].sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already consumed"):
+        loss.backward()
+    pts = torch.randn(5, 3, device=dev)
+    vd = torch.nn.functional.normalize(torch.randn(5, 3, device=dev), dim=-1)
+    y = npa.query_points(nf, pts, vd).sum()
+    y.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already consumed"):
+        y.backward()
+    for m in (nc, nf):
+        m.zero_grad()
+
+
+def test_packed_cache_invalidation_after_raw_writes(npa, dev):
+    """Writers that do not advance tensor version counters (c10d broadcast / all_reduce, `.data`, raw pointers) must be
+    followed by NeRF.invalidate_packed() (parallel.broadcast_parameters does it): otherwise the kernels keep evaluating
+    the previous fragment repack."""
+    Pc, _ = orc.scene_params(seed=7)
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    net = npa.NeRF(**kw).to(dev)
+    net.load_state_dict(Pc)
+    pts = torch.randn(32, 3, device=dev)
+    vd = torch.nn.functional.normalize(torch.randn(32, 3, device=dev), dim=-1)
+    with torch.no_grad():
+        before = npa.query_points(net, pts, vd).clone()
+        flat = net.flat_params()
+        versions = (flat._version, tuple(p._version for p in net.parameters()))
+        flat.data.mul_(1.01)                                  # `.data` write: no version counter moves
+        assert versions == (flat._version, tuple(p._version for p in net.parameters()))
+        stale = npa.query_points(net, pts, vd)
+        assert torch.equal(stale, before), "expected the cached repack to be (wrongly) reused without invalidation"
+        net.invalidate_packed()
+        fresh = npa.query_points(net, pts, vd)
+        net2 = npa.NeRF(**kw).to(dev)
+        net2.load_state_dict(net.state_dict())
+        assert float((fresh - before).abs().max()) > 1e-4 and torch.equal(fresh, npa.query_points(net2, pts, vd))
+
+
+# ---------------------------------------------------------------- end to end vs golden (reference-produced)
+# Stated tolerances of the two parity datapaths against numbers produced by the REAL reference (fp32, CPU).
+#   fp32   : every per-ray quantity within max(floor, 10 x the reference's own fp32-vs-fp64 rounding noise on the same
+#            inputs, stored per quantity in the fixture).
+#   bf16x3 : products carry ~1e-5 relative error (16-17 significand bits per operand).  Coarse-pass quantities (no
+#            hierarchical sampling upstream) are held to absolute per-ray bounds 100x the fp32 ones.  The fine pass
+#            inherits sample_pdf's conditioning (helpers:234-236 divides by ~1e-5 in bins the coarse pass found empty; the
+#            reference's own fp32-vs-fp64 runs differ by 1e-4..1e-2 there), so the few samples drawn in such bins move
+#            by a fraction of a bin under ANY perturbation of the coarse weights: fine quantities are held to a bound on
+#            95 % of the rays plus an image-level bound (PSNR between our image and the reference's), which is the
+#            north-star's form of the criterion (SURVEY 8c: "reduced-precision variants are judged on PSNR").
+GOLD_TOL = {
+    "fp32": dict(coarse=1e-5, fine_floor=1e-5, fine_stat="max", disp_rel=2e-5, zstd_floor=1e-4, raw_floor=5e-4, loss_floor=2e-6,
+                 grad=2e-4, grad_max=1e-3, img_psnr_db=70.0),
+    "bf16x3": dict(coarse=1e-3, fine_floor=3e-3, fine_stat="p95", disp_rel=2e-3, zstd_floor=2e-3, raw_floor=5e-2, loss_floor=2e-4,
+                   grad=5e-2, grad_max=5e-2, img_psnr_db=50.0),
+}
+
+
+def _golden_randoms(seed, n, args):
+    """replay the CPU generator stream the reference consumed (run_nerf.py:371, :285, helpers:208, :285)"""
+    if seed is None:
+        return None
+    torch.manual_seed(seed)
+    n_f = args["N_importance"]
+    randoms = {}
+    if args["perturb"] > 0:
+        randoms["t_rand"] = torch.rand(n, 64)
+    if args["raw_noise_std"] > 0:
+        randoms["noise_c"] = torch.randn(n, 64)
+    if n_f > 0 and args["perturb"] > 0:
+        randoms["u"] = torch.rand(n, n_f)
+    if n_f > 0 and args["raw_noise_std"] > 0:
+        randoms["noise_f"] = torch.randn(n, 64 + n_f)
+    return randoms
+
+
+def _check_golden(npa, dev, nets, name, kw, seed, precision="fp32", render=None):
+    """HIP render_rays (or, with `render`, the whole render() boundary incl. view directions and the NDC warp) + loss +
+    backward vs numbers produced by the real reference (fp32, CPU); tolerances: GOLD_TOL[precision]."""
+    nc, nf, Pc, Pf = nets
+    T = GOLD_TOL[precision]
     gold = np.load(f"{GOLD}/{name}.npz")
-    rays = orc.synthetic_rays(256, seed=7)
     target = torch.tensor(np.random.RandomState(99).rand(256, 3), dtype=torch.float32)
-    assert abs(float(rays.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-6
     args = dict(N_samples=64, retraw=True, N_importance=128, network_fine=nf, perturb=0., white_bkgd=True,
                 raw_noise_std=0., lindisp=False)
     args.update(kw)
     n_f = args["N_importance"]
-    randoms = None
-    if seed is not None:          # replay the CPU generator stream the reference consumed
-        torch.manual_seed(seed)
-        randoms = {}
-        if args["perturb"] > 0:
-            randoms["t_rand"] = torch.rand(256, 64)
-        if args["raw_noise_std"] > 0:
-            randoms["noise_c"] = torch.randn(256, 64)
-        if n_f > 0 and args["perturb"] > 0:
-            randoms["u"] = torch.rand(256, n_f)
-        if n_f > 0 and args["raw_noise_std"] > 0:
-            randoms["noise_f"] = torch.randn(256, 64 + n_f)
+    randoms = _golden_randoms(seed, 256, args)
     for m in (nc, nf):
         m.zero_grad()
-    out = npa.render_rays(rays.to(dev), nc, None, randoms=randoms, **args)
-    loss = npa.img2mse(out["rgb_map"], target.to(dev))
-    if "rgb0" in out:
-        loss = loss + npa.img2mse(out["rgb0"], target.to(dev))
-    loss.backward()
+    npa.set_precision(precision)
+    try:
+        if render is None:
+            rays = orc.synthetic_rays(256, seed=7)
+            assert abs(float(rays.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-6
+            out = npa.render_rays(rays.to(dev), nc, None, randoms=randoms, **args)
+        else:
+            cfg, batch = render
+            assert abs(float(batch.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-6
+            rgb, disp, acc, extras = npa.render(cfg["H"], cfg["W"], orc.intrinsics(cfg), chunk=1024 * 32, rays=batch.to(dev),
+                                                ndc=cfg["ndc"], near=cfg["near"], far=cfg["far"], use_viewdirs=True,
+                                                network_fn=nc, network_query_fn=None, randoms=randoms, **args)
+            out = dict(extras, rgb_map=rgb, disp_map=disp, acc_map=acc)
+            rays = orc.assemble_render_rays(cfg["H"], cfg["W"], orc.intrinsics(cfg), batch[0], batch[1], cfg["ndc"],
+                                            cfg["near"], cfg["far"])
+        loss = npa.img2mse(out["rgb_map"], target.to(dev))
+        if "rgb0" in out:
+            loss = loss + npa.img2mse(out["rgb0"], target.to(dev))
+        loss.backward()
+    finally:
+        npa.set_precision("fp32")
     out = {k: v.detach().cpu() for k, v in out.items()}
     # rays whose deterministic u == 1.0 sample is rounding-dependent in the reference itself
     stable = torch.ones(256, dtype=torch.bool)
@@ -324,30 +479,48 @@ def _check_golden(npa, dev, nets, name, kw, seed):
         report[key] = (float(err), float(tol))
         if not float(err) <= tol:
             fails.append(key)
+
+    def per_ray(a, b):      # worst component of each ray, NaN == NaN
+        d = (a.double() - b.double()).abs()
+        d = d.masked_fill(torch.isnan(a) & torch.isnan(b), 0.0).nan_to_num(nan=float("inf"))
+        return d.reshape(d.shape[0], -1).max(-1)[0]
+
+    def stat(err, fine):
+        if err.numel() == 0:
+            return 0.0
+        if fine and T["fine_stat"] == "p95":
+            return float(torch.quantile(err, 0.95))
+        return float(err.max())
     everything = torch.ones(256, dtype=torch.bool)
     fine_keys = ("rgb_map", "acc_map", "disp_map", "z_std", "raw") if n_f > 0 else ()
     for k in ("rgb0", "acc0", "rgb_map", "acc_map"):
         if k in gold.files:
-            sel = stable if k in fine_keys else everything
-            check(k, maxdiff(out[k][sel], torch.tensor(gold[k])[sel]), max(1e-5, 10 * noise(k)))
+            fine = k in fine_keys
+            sel = stable if fine else everything
+            err = per_ray(out[k][sel], torch.tensor(gold[k])[sel])
+            check(k, stat(err, fine), max(T["fine_floor"], 10 * noise(k)) if fine else T["coarse"])
+            report[k + " max"] = float(err.max()) if err.numel() else 0.0
     for k in ("disp_map", "disp0"):
         if k in gold.files:
-            sel = stable if k in fine_keys else everything
-            a, b = out[k].double()[sel], torch.tensor(gold[k]).double()[sel]
+            fine = k in fine_keys
+            sel = stable if fine else everything
+            a, b = out[k][sel], torch.tensor(gold[k])[sel]
             ok = ~(torch.isnan(a) & torch.isnan(b))
-            check(k, (a - b).abs()[ok].max(), max(2e-5 * float(b[ok].abs().max()), 10 * noise(k)))
+            check(k, stat(per_ray(a[ok], b[ok]), fine), max(T["disp_rel"] * float(b[ok].abs().max()), 10 * noise(k)))
     if "z_std" in gold.files:
-        check("z_std", maxdiff(out["z_std"][stable], torch.tensor(gold["z_std"])[stable]), max(1e-4, 10 * noise("z_std")))
+        check("z_std", stat(per_ray(out["z_std"][stable], torch.tensor(gold["z_std"])[stable]), True), max(T["zstd_floor"], 10 * noise("z_std")))
     graw = torch.tensor(gold["raw"])
     sel = stable if n_f > 0 else everything
-    check("raw", maxdiff(out["raw"][:, ::8][sel], graw[sel]), max(5e-4 * max(1.0, float(graw.abs().max()) / 10), 10 * noise("raw")))
-    # north_star criterion over ALL rays (unstable ones included): PSNR delta < 0.01 dB
-    mse_ref = float(((torch.tensor(gold["rgb_map"]) - target) ** 2).mean())
-    mse_hip = float(((out["rgb_map"] - target) ** 2).mean())
-    check("psnr_delta_dB", abs(10 * np.log10(mse_hip / mse_ref)), 0.01)
-    check("loss", abs(loss.item() - float(gold["loss"])), max(2e-6, 10 * noise("rgb_map") * 0.05))
+    check("raw", stat(per_ray(out["raw"][:, ::8][sel], graw[sel]), n_f > 0),
+          max(T["raw_floor"] * max(1.0, float(graw.abs().max()) / 10), 10 * noise("raw")))
+    # image-level criterion over ALL rays (unstable ones included): PSNR between our image and the reference's
+    mse_img = float(((out["rgb_map"].double() - torch.tensor(gold["rgb_map"]).double()) ** 2).mean())
+    report["psnr_vs_ref_dB"] = (orc.psnr(max(mse_img, 1e-30)), T["img_psnr_db"])
+    if report["psnr_vs_ref_dB"][0] < T["img_psnr_db"]:
+        fails.append("psnr_vs_ref_dB")
+    check("loss", abs(loss.item() - float(gold["loss"])), max(T["loss_floor"], 10 * noise("rgb_map") * 0.05))
     unstable_slack = 50.0 if (~stable).any() else 1.0
-    worst = 0.0
+    worst, dots = 0.0, [0.0, 0.0, 0.0]
     for tag, net in (("c", nc), ("f", nf)):
         for nm, p in net.named_parameters():
             key = f"{tag}/{nm}/max"
@@ -357,30 +530,139 @@ def _check_golden(npa, dev, nets, name, kw, seed):
             g = p.grad.detach().cpu().reshape(-1)
             idx, val = gold[f"{tag}/{nm}/idx"], gold[f"{tag}/{nm}/val"]
             gmax, gnoise = float(gold[key]), float(gold[f"{tag}/{nm}/noise"])
-            err = float(np.abs(g[idx].numpy() - val).max())
-            tol = max(2e-4 * gmax, 10 * gnoise) * (unstable_slack if tag == "f" else 1.0)
+            got = g[idx].numpy().astype(np.float64)
+            err = float(np.abs(got - val).max())
+            tol = max(T["grad"] * gmax, 10 * gnoise) * (unstable_slack if tag == "f" else 1.0)
             worst = max(worst, err / max(gmax, 1e-30))
             check(f"grad {tag}/{nm}", err, tol)
-            check(f"grad {tag}/{nm} max", abs(float(g.abs().max()) - gmax), max(1e-3 * gmax, 10 * gnoise) * unstable_slack)
+            check(f"grad {tag}/{nm} max", abs(float(g.abs().max()) - gmax), max(T["grad_max"] * gmax, 10 * gnoise) * unstable_slack)
+            dots[0] += float((got * val).sum()) / gmax ** 2
+            dots[1] += float((got * got).sum()) / gmax ** 2
+            dots[2] += float((val.astype(np.float64) ** 2).sum()) / gmax ** 2
     report["worst grad err/max"] = worst
-    print(name, {k: v for k, v in report.items() if not k.startswith("grad") or k in fails})
+    cos = dots[0] / max(np.sqrt(dots[1] * dots[2]), 1e-300)
+    check("grad cosine deficit (sampled entries, per-tensor normalised)", 1.0 - cos, 1e-6 if precision == "fp32" else 1e-3)
+    print(name, precision, {k: v for k, v in report.items() if not k.startswith("grad ") or k in fails})
     assert not fails, {k: report[k] for k in fails}
 
 
-def test_golden_lego_det(npa, dev, nets):
-    _check_golden(npa, dev, nets, "lego_det", {}, None)
+PARITY_DATAPATHS = ["fp32", "bf16x3"]
 
 
-def test_golden_lego_train(npa, dev, nets):
-    _check_golden(npa, dev, nets, "lego_train", dict(perturb=1.0), 123)
+@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+def test_golden_lego_det(npa, dev, nets, precision):
+    _check_golden(npa, dev, nets, "lego_det", {}, None, precision)
 
 
-def test_golden_fern_train(npa, dev, nets):
-    _check_golden(npa, dev, nets, "fern_train", dict(perturb=1.0, raw_noise_std=1.0, white_bkgd=False, N_importance=64, lindisp=True), 321)
+@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+def test_golden_lego_train(npa, dev, nets, precision):
+    _check_golden(npa, dev, nets, "lego_train", dict(perturb=1.0), 123, precision)
 
 
-def test_golden_coarse_only(npa, dev, nets):
-    _check_golden(npa, dev, nets, "lego_coarse_only", dict(perturb=1.0, N_importance=0, network_fine=None), 11)
+@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+def test_golden_fern_train(npa, dev, nets, precision):
+    _check_golden(npa, dev, nets, "fern_train", dict(perturb=1.0, raw_noise_std=1.0, white_bkgd=False, N_importance=64, lindisp=True), 321, precision)
+
+
+@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+def test_golden_coarse_only(npa, dev, nets, precision):
+    _check_golden(npa, dev, nets, "lego_coarse_only", dict(perturb=1.0, N_importance=0, network_fine=None), 11, precision)
+
+
+@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+def test_golden_fern_ndc_through_render(npa, dev, nets, precision):
+    """BASELINE.json configs[2]: the reference's render(H=378, W=504, K(focal 407.5), rays=..., ndc=True, near=0, far=1,
+    use_viewdirs=True, perturb=1, raw_noise_std=1, white_bkgd=False, N_importance=128) on forward-facing rays (d_z < 0)
+    -- run_nerf.py:110-123, run_nerf_helpers.py:175-192, configs/fern.txt -- vs npa.render() with the same arguments."""
+    _check_golden(npa, dev, nets, "fern_ndc_train", dict(perturb=1.0, raw_noise_std=1.0, white_bkgd=False, N_importance=128), 77,
+                  precision, render=(orc.FERN, orc.fern_batch(256, seed=3)))
+
+
+@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+def test_golden_lego_through_render(npa, dev, nets, precision):
+    """BASELINE.json configs[1] through the rays=... branch of render() (run_nerf.py:95-134), as train() calls it (:760)."""
+    _check_golden(npa, dev, nets, "lego_render_train", dict(perturb=1.0), 123, precision,
+                  render=(orc.LEGO, orc.lego_batch(256, seed=7)))
+
+
+# ---------------------------------------------------------------- the north-star acceptance gate
+GATE_FLOOR_DB = {"fp32": 70.0, "bf16x3": 55.0, "mixed": 55.0}      # PSNR(our image, reference image)
+
+
+def _gate(npa, dev, nets, which, precision):
+    nc, nf, Pc, Pf = nets
+    cfg = orc.LEGO if which == "lego" else orc.FERN
+    batch = orc.lego_batch(1024, seed=31) if which == "lego" else orc.fern_batch(1024, seed=32)
+    gold = np.load(f"{GOLD}/gate_{which}.npz")
+    assert abs(float(batch.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-5
+    npa.set_precision(precision)
+    try:
+        with torch.no_grad():
+            rgb, _, _, _ = npa.render(cfg["H"], cfg["W"], orc.intrinsics(cfg), chunk=1024 * 32, rays=batch.to(dev), ndc=cfg["ndc"],
+                                      near=cfg["near"], far=cfg["far"], use_viewdirs=True, network_fn=nc, network_query_fn=None,
+                                      N_samples=64, N_importance=128, network_fine=nf, perturb=0., raw_noise_std=0.,
+                                      white_bkgd=cfg["white_bkgd"])
+    finally:
+        npa.set_precision("fp32")
+    return orc.precision_gate(rgb, torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"]))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mixed"])
+@pytest.mark.parametrize("which", ["lego", "fern"])
+def test_precision_gate_psnr_on_a_teacher_target(npa, dev, nets, which, precision):
+    """north_star: 'PSNR delta < 0.01 dB'.  Target = the image of a teacher scene (workloads.teacher_params) rendered by
+    the REAL reference; the networks under test sit at 31 dB (lego-like) / 37 dB (fern-like, NDC) from it -- trained-NeRF
+    territory, where an rgb error of 1e-3 moves the PSNR by ~0.1 dB (a uniform-random target at ~6 dB would hide it).
+    Both images of the fixture come from the reference's render() (tests/golden/make_golden.py --round2)."""
+    g = _gate(npa, dev, nets, which, precision)
+    print(which, precision, g)
+    assert g["target_psnr_db"] >= 30.0, g
+    assert g["psnr_delta_db"] < 0.01, g
+    assert g["psnr_vs_ref_db"] >= GATE_FLOOR_DB[precision], g
+
+
+def test_precision_gate_can_fail(npa, dev, nets):
+    """The gate is not vacuous: an image off by a uniform 2e-3 (a plain-bf16-sized error) violates the 0.01 dB bar."""
+    gold = np.load(f"{GOLD}/gate_lego.npz")
+    ref, tgt = torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"])
+    bad = orc.precision_gate(ref + 2e-3 * torch.sign(ref - tgt), ref, tgt)
+    assert bad["psnr_delta_db"] > 0.01 and bad["psnr_vs_ref_db"] < GATE_FLOOR_DB["bf16x3"], bad
+    ok = orc.precision_gate(ref, ref, tgt)
+    assert ok["psnr_delta_db"] == 0.0 and abs(ok["target_psnr_db"] - float(gold["target_psnr_db"])) < 1e-6
+
+
+@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+def test_render_c2w_ndc_matches_rays_branch_and_oracle(npa, dev, nets, precision):
+    """render(c2w=..., ndc=True) (one HIP launch builds the NDC ray records) == render(rays=get_rays(...), ndc=True)
+    == the oracle on the same image (run_nerf.py:95-123)."""
+    nc, nf, Pc, Pf = nets
+    H, W, focal = 10, 14, 11.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    c2w = orc.fern_poses(3)[1]
+    kw = dict(network_fn=nc, network_query_fn=None, N_samples=64, N_importance=128, network_fine=nf, perturb=0.,
+              white_bkgd=False, raw_noise_std=0., retraw=True, ndc=True, near=0., far=1., use_viewdirs=True)
+    npa.set_precision(precision)
+    try:
+        with torch.no_grad():
+            a = npa.render(H, W, K, chunk=64, c2w=c2w.to(dev), **kw)
+            ro, rd = npa.get_rays(H, W, K, c2w.to(dev))
+            b = npa.render(H, W, K, chunk=1 << 15, rays=torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0), **kw)
+    finally:
+        npa.set_precision("fp32")
+    assert a[0].shape == (H, W, 3) and b[0].shape == (H * W, 3)
+    o, d = orc.pinhole_rays(H, W, K, c2w)
+    flat = orc.assemble_render_rays(H, W, K, o.reshape(-1, 3), d.reshape(-1, 3), True, 0., 1.)
+    ref = orc.trace_rays(flat, Pc, Pf, 64, 128, perturb=0., white_bkgd=False)
+    stable = ~orc.endpoint_unstable(ref["_weights0"])
+    tol0 = 1e-5 if precision == "fp32" else 1e-3
+    assert maxdiff(a[3]["rgb0"].reshape(-1, 3), ref["rgb0"]) <= tol0
+    assert maxdiff(b[3]["rgb0"], ref["rgb0"]) <= tol0
+    assert maxdiff(a[3]["rgb0"].reshape(-1, 3), b[3]["rgb0"]) <= 2e-6 + (0 if precision == "fp32" else 1e-4)
+    ref64 = orc.trace_rays(flat.double(), {k: v.double() for k, v in Pc.items()}, {k: v.double() for k, v in Pf.items()},
+                           64, 128, perturb=0., white_bkgd=False)
+    floor = maxdiff(ref["rgb_map"][stable], ref64["rgb_map"][stable])
+    lim = max(1e-5, 10 * floor) if precision == "fp32" else max(3e-3, 10 * floor)
+    assert float(torch.quantile((a[0].reshape(-1, 3).cpu()[stable] - ref["rgb_map"][stable]).abs().max(-1)[0], 0.95)) <= lim
 
 
 # ---------------------------------------------------------------- split-bf16 datapath (precision "bf16x3")
@@ -595,11 +877,10 @@ def test_mixed_training_tracks_fp32(npa, dev):
         assert abs(a - b) <= 5e-3 * abs(a), losses
 
 
-def test_bf16x3_render_psnr_delta(npa, dev, nets):
-    """north_star bar for a reduced-precision datapath: PSNR delta vs the reference < 0.01 dB (here: measured ~1e-4)."""
+def test_bf16x3_render_close_to_oracle_per_ray(npa, dev, nets):
+    """bf16x3 inference vs the oracle ray by ray (the image-level PSNR criterion is test_precision_gate_*)."""
     nc, nf, Pc, Pf = nets
     rays = orc.synthetic_rays(512, seed=31)
-    target = torch.rand(512, 3, generator=torch.Generator().manual_seed(5))
     npa.set_precision("bf16x3")
     try:
         with torch.no_grad():
@@ -608,12 +889,10 @@ def test_bf16x3_render_psnr_delta(npa, dev, nets):
         npa.set_precision("fp32")
     ref = orc.trace_rays(rays, Pc, Pf, 64, 128, white_bkgd=True)
     d0 = maxdiff(out["rgb0"], ref["rgb0"])
-    mse_h = float(((out["rgb_map"].cpu() - target) ** 2).mean())
-    mse_r = float(((ref["rgb_map"] - target) ** 2).mean())
-    dpsnr = abs(10 * np.log10(mse_h / mse_r))
-    print(f"bf16x3: max|rgb0 - ref| = {d0:.2e}, max|rgb - ref| = {maxdiff(out['rgb_map'], ref['rgb_map']):.2e}, PSNR delta = {dpsnr:.2e} dB")
-    assert d0 <= 2e-4
-    assert dpsnr < 0.01
+    err = (out["rgb_map"].cpu() - ref["rgb_map"]).abs().max(-1)[0]
+    print(f"bf16x3: max|rgb0 - ref| = {d0:.2e}, rgb_map err median {float(err.median()):.2e} p95 {float(torch.quantile(err, 0.95)):.2e} max {float(err.max()):.2e}")
+    assert d0 <= 5e-4
+    assert float(torch.quantile(err, 0.95)) <= 3e-3
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mixed"])
@@ -747,22 +1026,30 @@ def test_training_reaches_the_same_psnr_in_every_datapath(npa, dev):
 
 
 def test_adversarial_scene_psnr_delta(npa, dev):
-    """Unrelated coarse/fine networks with full-strength 2^9-frequency columns: per-ray agreement is not
-    defined (the reference's own fp32-vs-fp64 runs disagree at 1e-2 here), the image-level criterion is."""
+    """Unrelated coarse/fine networks with full-strength 2^9-frequency columns: per-ray agreement is not defined (the
+    reference's own fp32-vs-fp64 runs disagree at 1e-2 here), the image-level criterion is.  Target = the oracle's
+    image of the same networks perturbed by 0.3 % (a teacher scene; a random target would make the criterion vacuous)."""
     Pc, Pf = orc.scene_params_adversarial()
+    rs = np.random.RandomState(5)
+    Tc, Tf = ({k: v * torch.tensor(1.0 + 3e-3 * rs.standard_normal(tuple(v.shape)), dtype=torch.float32) for k, v in P.items()}
+              for P in (Pc, Pf))
     kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
     nc, nf = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
     nc.load_state_dict(Pc); nf.load_state_dict(Pf)
     rays = orc.synthetic_rays(512, seed=13)
-    target = torch.rand(512, 3)
-    with torch.no_grad():
-        out = npa.render_rays(rays.to(dev), nc, None, 64, N_importance=128, network_fine=nf, white_bkgd=True)
     ref = orc.trace_rays(rays, Pc, Pf, 64, 128, white_bkgd=True)
-    assert maxdiff(out["rgb0"], ref["rgb0"]) <= 1e-5
-    mse_h = float(((out["rgb_map"].cpu() - target) ** 2).mean())
-    mse_r = float(((ref["rgb_map"] - target) ** 2).mean())
-    assert abs(10 * np.log10(mse_h / mse_r)) < 0.01
-    assert float(((out["rgb_map"].cpu() - ref["rgb_map"]) ** 2).mean()) < 1e-5
+    target = orc.trace_rays(rays, Tc, Tf, 64, 128, white_bkgd=True)["rgb_map"]
+    for prec, floor in (("fp32", 50.0), ("bf16x3", 40.0)):
+        npa.set_precision(prec)
+        try:
+            with torch.no_grad():
+                out = npa.render_rays(rays.to(dev), nc, None, 64, N_importance=128, network_fine=nf, white_bkgd=True)
+        finally:
+            npa.set_precision("fp32")
+        g = orc.precision_gate(out["rgb_map"], ref["rgb_map"], target)
+        print("adversarial", prec, g, "max|rgb0 - ref|", maxdiff(out["rgb0"], ref["rgb0"]))
+        assert maxdiff(out["rgb0"], ref["rgb0"]) <= (1e-5 if prec == "fp32" else 1e-3)
+        assert g["psnr_delta_db"] < 0.01 and g["psnr_vs_ref_db"] >= floor, g
 
 
 # ---------------------------------------------------------------- boundary: render() / run_network / NeRF.forward

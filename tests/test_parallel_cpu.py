@@ -42,7 +42,10 @@ def _worker(rank, world, port, q):
     kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
     torch.manual_seed(100 + rank)                      # ranks start from DIFFERENT weights ...
     net = npa.NeRF(**kw)
+    net._packed, net._packed_key = {"fp32": "stale repack"}, ("stale",)
     parallel.broadcast_parameters([net])               # ... and are made identical by one broadcast
+    # c10d writes do not advance tensor versions: the broadcast must drop the cached fragment repack itself
+    assert net._packed is None and net._packed_key is None
     P0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
     n = 32
     rays_all = orc.synthetic_rays(n, seed=4)

@@ -1,0 +1,161 @@
+"""GPU (-m gpu): the callers either side of the hot path, driven the way the reference's train() drives them
+(run_nerf.py:711-784): create_nerf -> device-side ray-batch sampling -> render() -> img2mse -> backward ->
+fused Adam -> lr decay, on a synthetic blender-format scene (workloads.blender_scene: there are no lego files here),
+against the same loop executed by the oracle (eager PyTorch ops on the same GPU = the reference's own ROCm path)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import nerf_oracle as orc
+import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def npa():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import nerf_pytorch_amd
+    return nerf_pytorch_amd
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("precrop", [None, 0.5])
+def test_sample_ray_batch_on_the_gpu(npa, dev, precrop):
+    """f-1: rays generated only for the selected pixels == get_rays (oracle.pinhole_rays, pinned to the reference) at
+    those pixels; colours are the image's at those pixels; selection is without replacement and respects precrop
+    (run_nerf.py:730-757)."""
+    H, W, focal = 40, 56, 47.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    pose = wl.pose_spherical(37.0, -25.0, 4.0)
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(0))
+    g = torch.Generator(device=dev).manual_seed(5)
+    N = 300
+    rays, tgt = npa.sample_ray_batch(H, W, K, pose[:3, :4].to(dev), img.to(dev), N, precrop_frac=precrop, generator=g)
+    assert rays.shape == (2, N, 3) and tgt.shape == (N, 3) and rays.is_cuda
+    ro, rd = orc.pinhole_rays(H, W, K, pose)
+    rd_flat = rd.reshape(-1, 3)
+    # identify each sampled ray's pixel by its direction (directions of distinct pixels differ by ~1/focal)
+    dist = torch.cdist(rays[1].cpu().double(), rd_flat.double())
+    err, pix = dist.min(-1)
+    assert float(err.max()) <= 2e-6, float(err.max())
+    assert len(set(pix.tolist())) == N, "a pixel was drawn twice"
+    assert torch.equal(tgt.cpu(), img.reshape(-1, 3)[pix])
+    assert float((rays[0].cpu() - ro.reshape(-1, 3)[pix]).abs().max()) == 0.0
+    if precrop is not None:
+        dH, dW = int(H // 2 * precrop), int(W // 2 * precrop)
+        jj, ii = pix // W, pix % W
+        assert bool(((jj >= H // 2 - dH) & (jj < H // 2 + dH) & (ii >= W // 2 - dW) & (ii < W // 2 + dW)).all())
+    with pytest.raises(ValueError):
+        npa.sample_ray_batch(H, W, K, pose[:3, :4].to(dev), img.to(dev), H * W + 1)
+
+
+def _oracle_params_from(model):
+    return {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_train_shaped_loop_matches_the_oracle_loop(npa, dev, precision):
+    """200 iterations of the reference's training loop shape through the drop-in surface, and the same 200 iterations
+    (same initial weights, same ray batches, same random draws, torch.optim.Adam, same lr schedule) by the oracle:
+    the held-out PSNR of the two runs agree within 0.1 dB and both have learned the scene."""
+    scene = wl.blender_scene(H=48, W=48, n_train=12, n_test=3)
+    H, W, focal = scene["hwf"]
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    images, poses = scene["images"].to(dev), scene["poses"].to(dev)
+    i_train, i_val, i_test = scene["i_split"]
+    N_rand, n_iters, precrop_iters, precrop_frac = 1024, 200, 20, 0.5
+    args = npa.config_parser().parse_args(["--expname", "t", "--basedir", "/nonexistent", "--dataset_type", "blender",
+                                          "--use_viewdirs", "--white_bkgd", "--N_samples", "64", "--N_importance", "128",
+                                          "--N_rand", str(N_rand), "--lrate_decay", "500", "--no_reload"])
+    torch.manual_seed(0)
+    tr, te, start, grad_vars, optimizer = npa.create_nerf(args, device=dev, fused_adam=True)
+    assert isinstance(optimizer, npa.FlatAdam) and start == 0
+    Pc = _oracle_params_from(tr["network_fn"])
+    Pf = _oracle_params_from(tr["network_fine"])
+    opt_o = torch.optim.Adam(list(Pc.values()) + list(Pf.values()), lr=args.lrate, betas=(0.9, 0.999))
+    bds = dict(near=scene["near"], far=scene["far"])
+    tr.update(bds)
+    te.update(bds)
+
+    # the batches of train() (one random training view per step, N_rand pixels without replacement, central precrop at
+    # the start), drawn once on the device so that both loops consume the same ones
+    g = torch.Generator(device=dev).manual_seed(11)
+    rs = np.random.RandomState(3)
+    batches = []
+    for i in range(n_iters):
+        img_i = int(rs.choice(i_train))
+        batches.append(npa.sample_ray_batch(H, W, K, poses[img_i, :3, :4], images[img_i], N_rand,
+                                            precrop_frac=precrop_frac if i < precrop_iters else None, generator=g))
+
+    def lr_at(step):
+        return args.lrate * (0.1 ** (step / (args.lrate_decay * 1000)))
+
+    def held_out_psnr(render_image):
+        mse = []
+        for i in i_test:
+            mse.append(float(((render_image(poses[i, :3, :4]) - images[i]) ** 2).mean()))
+        return -10.0 * math.log10(float(np.mean(mse)))
+
+    # ---- loop A: the product, through render() exactly as run_nerf.py:760-784
+    npa.set_precision(precision)
+    try:
+        torch.manual_seed(1234)
+        first = last = None
+        for i, (batch_rays, target_s) in enumerate(batches):
+            rgb, disp, acc, extras = npa.render(H, W, K, chunk=args.chunk, rays=batch_rays, verbose=i < 10, retraw=True, **tr)
+            optimizer.zero_grad()
+            loss = npa.img2mse(rgb, target_s) + npa.img2mse(extras["rgb0"], target_s)
+            loss.backward()
+            optimizer.step()
+            for group in optimizer.param_groups:
+                group["lr"] = lr_at(i + 1)
+            if i == 0:
+                first = loss.item()
+            last = loss.item()
+        with torch.no_grad():
+            psnr_hip = held_out_psnr(lambda c2w: npa.render(H, W, K, chunk=args.chunk, c2w=c2w, **te)[0])
+    finally:
+        npa.set_precision("fp32")
+
+    # ---- loop B: the oracle (eager torch ops on the GPU), same batches, same draws in the same order
+    torch.manual_seed(1234)
+    first_o = last_o = None
+    for i, (batch_rays, target_s) in enumerate(batches):
+        flat = orc.assemble_rays(batch_rays[0], batch_rays[1], bds["near"], bds["far"])
+        t_rand = torch.rand((N_rand, 64), device=dev)
+        u = torch.rand((N_rand, 128), device=dev)
+        out = orc.trace_rays(flat, Pc, Pf, 64, 128, perturb=1.0, white_bkgd=True, t_rand=t_rand, u=u)
+        opt_o.zero_grad()
+        loss_o = orc.mse(out["rgb_map"], target_s) + orc.mse(out["rgb0"], target_s)
+        loss_o.backward()
+        opt_o.step()
+        for group in opt_o.param_groups:
+            group["lr"] = lr_at(i + 1)
+        if i == 0:
+            first_o = loss_o.item()
+        last_o = loss_o.item()
+
+    def oracle_image(c2w):
+        o, d = orc.pinhole_rays(H, W, K, c2w.cpu())
+        flat = orc.assemble_rays(o.reshape(-1, 3).to(dev), d.reshape(-1, 3).to(dev), bds["near"], bds["far"])
+        with torch.no_grad():
+            return orc.trace_rays(flat, Pc, Pf, 64, 128, perturb=0.0, white_bkgd=True)["rgb_map"].reshape(H, W, 3)
+    psnr_orc = held_out_psnr(oracle_image)
+    print(f"{precision}: first-step loss {first:.6f} (oracle {first_o:.6f}); last {last:.6f} (oracle {last_o:.6f}); "
+          f"held-out PSNR {psnr_hip:.3f} dB (oracle loop {psnr_orc:.3f} dB)")
+    assert abs(first - first_o) <= (2e-5 if precision == "fp32" else 2e-3) * first_o
+    psnr_blank = held_out_psnr(lambda c2w: torch.ones(H, W, 3, device=dev))        # an untrained field renders white
+    print(f"held-out PSNR of a blank (white) image: {psnr_blank:.3f} dB")
+    assert last < first and psnr_hip > psnr_blank + 3.0, "the loop did not learn the scene"
+    assert abs(psnr_hip - psnr_orc) <= 0.1, (psnr_hip, psnr_orc)
+    # the optimizer state is the reference's checkpoint format (run_nerf.py:792-800)
+    sd = optimizer.state_dict()
+    assert len(sd["state"]) == 48 and float(sd["state"][0]["step"]) == n_iters
