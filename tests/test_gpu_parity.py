@@ -297,9 +297,12 @@ def test_field_backward_no_exclusion(npa, dev, nets, n_rays, S):
         gg, r = grad[off:off + int(np.prod(shape))].view(shape), P64[nm].grad
         rel[nm] = float((gg - r).norm() / r.norm())
         cosdef[nm] = 1.0 - float((gg * r).sum() / (gg.norm() * r.norm()))
-    print("no exclusion: worst relative L2 error", max(rel.values()), "worst cosine deficit", max(cosdef.values()))
-    assert max(rel.values()) <= 1e-4, rel
-    assert max(cosdef.values()) <= 1e-8, cosdef
+    wk = max(rel, key=rel.get)
+    print("no exclusion: worst relative L2 error", rel[wk], "on", wk, "worst cosine deficit", max(cosdef.values()))
+    # one unit taking the other side of its kink at one of ~3000 points moves a small tensor by ~1e-3 of its norm
+    # (measured: 1.1e-3 / 8e-7 on the two cases); the direction is unaffected to 6e-7
+    assert max(rel.values()) <= 5e-3, rel
+    assert max(cosdef.values()) <= 1e-5, cosdef
 
 
 def test_raw2outputs_weight_and_depth_gradients(npa, dev):
@@ -405,10 +408,12 @@ def test_packed_cache_invalidation_after_raw_writes(npa, dev):
 #            95 % of the rays plus an image-level bound (PSNR between our image and the reference's), which is the
 #            north-star's form of the criterion ("reduced-precision variants are judged on PSNR").
 GOLD_TOL = {
-    "fp32": dict(coarse=1e-5, fine_floor=1e-5, fine_stat="max", disp_rel=2e-5, zstd_floor=1e-4, raw_floor=5e-4, loss_floor=2e-6,
-                 grad=2e-4, grad_max=1e-3, img_psnr_db=70.0),
-    "bf16x3": dict(coarse=1e-3, fine_floor=3e-3, fine_stat="p95", disp_rel=2e-3, zstd_floor=2e-3, raw_floor=5e-2, loss_floor=2e-4,
-                   grad=5e-2, grad_max=5e-2, img_psnr_db=50.0),
+    "fp32": dict(coarse=1e-5, fine_floor=1e-5, fine_stat="max", fine_max=None, disp_rel=2e-5, zstd_floor=1e-4, raw_floor=5e-4,
+                 loss_floor=2e-6, grad=2e-4, grad_max=1e-3, img_psnr_db=85.0),
+    # measured on MI355X (round 2): coarse 4e-5..1.1e-4; fine p95 2e-5..6e-5, fine max 6e-4..1.4e-3; image PSNR vs the
+    # reference 84.5..102 dB; gradients 3e-4..4.8e-3 of max|g|
+    "bf16x3": dict(coarse=3e-4, fine_floor=3e-4, fine_stat="p95", fine_max=5e-3, disp_rel=1e-3, zstd_floor=1e-3, raw_floor=2e-2,
+                   loss_floor=2e-5, grad=2e-2, grad_max=2e-2, img_psnr_db=75.0),
 }
 
 
@@ -500,12 +505,21 @@ def _check_golden(npa, dev, nets, name, kw, seed, precision="fp32", render=None)
             err = per_ray(out[k][sel], torch.tensor(gold[k])[sel])
             check(k, stat(err, fine), max(T["fine_floor"], 10 * noise(k)) if fine else T["coarse"])
             report[k + " max"] = float(err.max()) if err.numel() else 0.0
+            if fine and T["fine_max"] is not None:
+                check(k + " worst ray", report[k + " max"], max(T["fine_max"], 10 * noise(k)))
     for k in ("disp_map", "disp0"):
         if k in gold.files:
             fine = k in fine_keys
             sel = stable if fine else everything
             a, b = out[k][sel], torch.tensor(gold[k])[sel]
-            ok = ~(torch.isnan(a) & torch.isnan(b))
+            acc_k = torch.tensor(gold["acc_map" if k == "disp_map" else ("acc0" if "acc0" in gold.files else "acc_map")])[sel]
+            if precision == "fp32":
+                ok = ~(torch.isnan(a) & torch.isnan(b))      # exact datapath: same empty rays (disp = NaN there, reference quirk)
+            else:
+                # disp = 1 / max(1e-10, depth / acc) is discontinuous at acc -> 0 (NaN on an empty ray, ~1e10 on a ray whose
+                # only opacity is one sample with sigma ~ 0+): a reduced-precision datapath is compared where it is defined
+                ok = acc_k > 1e-3
+                report[k + " rays compared"] = int(ok.sum())
             check(k, stat(per_ray(a[ok], b[ok]), fine), max(T["disp_rel"] * float(b[ok].abs().max()), 10 * noise(k)))
     if "z_std" in gold.files:
         check("z_std", stat(per_ray(out["z_std"][stable], torch.tensor(gold["z_std"])[stable]), True), max(T["zstd_floor"], 10 * noise("z_std")))
@@ -586,7 +600,7 @@ def test_golden_lego_through_render(npa, dev, nets, precision):
 
 
 # ---------------------------------------------------------------- the north-star acceptance gate
-GATE_FLOOR_DB = {"fp32": 70.0, "bf16x3": 55.0, "mixed": 55.0}      # PSNR(our image, reference image)
+GATE_FLOOR_DB = {"fp32": 110.0, "bf16x3": 90.0, "mixed": 90.0}     # PSNR(our image, reference image); measured 120..134 / 96.6..104 dB
 
 
 def _gate(npa, dev, nets, which, precision):
@@ -627,6 +641,9 @@ def test_precision_gate_can_fail(npa, dev, nets):
     ref, tgt = torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"])
     bad = orc.precision_gate(ref + 2e-3 * torch.sign(ref - tgt), ref, tgt)
     assert bad["psnr_delta_db"] > 0.01 and bad["psnr_vs_ref_db"] < GATE_FLOOR_DB["bf16x3"], bad
+    # an error well inside the 0.01 dB bar but larger than the split-bf16 datapath's is still caught by the image floor
+    mild = orc.precision_gate(ref + 1e-4 * torch.sign(ref - tgt), ref, tgt)
+    assert mild["psnr_delta_db"] < 0.01 and mild["psnr_vs_ref_db"] < GATE_FLOOR_DB["bf16x3"], mild
     ok = orc.precision_gate(ref, ref, tgt)
     assert ok["psnr_delta_db"] == 0.0 and abs(ok["target_psnr_db"] - float(gold["target_psnr_db"])) < 1e-6
 
@@ -891,8 +908,9 @@ def test_bf16x3_render_close_to_oracle_per_ray(npa, dev, nets):
     d0 = maxdiff(out["rgb0"], ref["rgb0"])
     err = (out["rgb_map"].cpu() - ref["rgb_map"]).abs().max(-1)[0]
     print(f"bf16x3: max|rgb0 - ref| = {d0:.2e}, rgb_map err median {float(err.median()):.2e} p95 {float(torch.quantile(err, 0.95)):.2e} max {float(err.max()):.2e}")
-    assert d0 <= 5e-4
-    assert float(torch.quantile(err, 0.95)) <= 3e-3
+    assert d0 <= 3e-4                                       # measured 4.6e-5
+    assert float(torch.quantile(err, 0.95)) <= 3e-4         # measured 2.4e-5 (worst ray 1.6e-3)
+    assert float(err.max()) <= 1e-2
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mixed"])
@@ -1039,7 +1057,7 @@ def test_adversarial_scene_psnr_delta(npa, dev):
     rays = orc.synthetic_rays(512, seed=13)
     ref = orc.trace_rays(rays, Pc, Pf, 64, 128, white_bkgd=True)
     target = orc.trace_rays(rays, Tc, Tf, 64, 128, white_bkgd=True)["rgb_map"]
-    for prec, floor in (("fp32", 50.0), ("bf16x3", 40.0)):
+    for prec, floor in (("fp32", 65.0), ("bf16x3", 60.0)):        # measured 77.0 / 71.8 dB
         npa.set_precision(prec)
         try:
             with torch.no_grad():

@@ -71,7 +71,7 @@ def test_train_shaped_loop_matches_the_oracle_loop(npa, dev, precision):
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
     images, poses = scene["images"].to(dev), scene["poses"].to(dev)
     i_train, i_val, i_test = scene["i_split"]
-    N_rand, n_iters, precrop_iters, precrop_frac = 1024, 200, 20, 0.5
+    N_rand, n_iters, precrop_iters, precrop_frac = 512, 200, 20, 0.5      # precrop window 24 x 24 = 576 pixels >= N_rand
     args = npa.config_parser().parse_args(["--expname", "t", "--basedir", "/nonexistent", "--dataset_type", "blender",
                                           "--use_viewdirs", "--white_bkgd", "--N_samples", "64", "--N_importance", "128",
                                           "--N_rand", str(N_rand), "--lrate_decay", "500", "--no_reload"])
