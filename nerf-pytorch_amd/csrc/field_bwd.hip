@@ -420,13 +420,21 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
     // staging role: waves 0-3 stage delta (A), waves 4-7 the input (B)
     const int sop = __builtin_amdgcn_readfirstlane(tid >> 8);
     const int st_t = tid & 255;
-    const int sg = st_t & 7;                                       // 4-point group inside the tile
+    // lane -> (feature of the round, 4-point group): a wave stages 8 features x 8 groups.  The LDS image has a pitch of
+    // 36 dwords per feature (conflict-free ds_read_b128 of the fragments); a ds_write_b64 is serviced in groups of 16
+    // contiguous lanes over 32 banks, so a group must hold 8 consecutive features (bank offsets 4k) x 2 adjacent point
+    // groups (the two dword pairs of one 16-byte piece): lane = 16*g + 2*k + b -> feature k, point group 2*g + b.
+    // (feature = lane >> 3, group = lane & 7 put two features with 12 overlapping banks in every group: 2-way conflicts
+    // on a third of all LDS cycles, profiles/r01_bf16x3_pmc_summary.csv.)  The global loads stay one contiguous KiB per wave.
+    const int sk = (st_t >> 1) & 7;
+    const int sg = ((st_t >> 4) & 3) * 2 + (st_t & 1);            // 4-point group inside the tile
+    const int sfeat = (st_t >> 6) * 8 + sk;                        // the thread's feature in round 0 (0..31)
     const int swidth = sop == 0 ? jb.nA : jb.nB;
     const int sld = sop == 0 ? jb.lda : jb.ldb;                    // features per tile of the operand's region
     // scalar base of this workgroup's first tile + 32-bit per-lane byte offsets (a chunk spans < 4 GiB)
     const char* cbase = reinterpret_cast<const char*>((sop == 0 ? jb.A : jb.B) + (p_begin >> 5) * (long)sld * 32);
     const unsigned tile_bytes = 128u * (unsigned)sld;
-    const int sf0 = st_t >> 3;                                     // the thread's feature in round 0
+    const int sf0 = sfeat;
     const int sflast = swidth - 1;
     float colsum[WG3_ROUNDS];
 #pragma unroll
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
             dst[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(cbase + (off0 + 128u * (unsigned)min(32 * r + sf0, sflast))));
     };
     auto swrite_from = [&](const f32x4 (&src)[WG3_ROUNDS], int buf, int st) {
-        unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + (st_t >> 3) * WG3_FEAT_BYTES + 8 * sg;
+        unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + sfeat * WG3_FEAT_BYTES + 8 * sg;
         const int left = nrows - st * WG_STAGE - 4 * sg;           // points of this thread's group that exist
 #pragma unroll
         for (int r = 0; r < WG3_ROUNDS; ++r) {
@@ -535,11 +543,11 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
     if (jb.bias_off >= 0 && sop == 0) {
 #pragma unroll
         for (int r = 0; r < WG3_ROUNDS; ++r) {
-                float s = colsum[r];
+                float s = colsum[r];                // sum over the 8 point groups: lane bits 0, 4, 5
                 s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
-                const int f = 32 * r + (st_t >> 3);
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                const int f = 32 * r + sfeat;
                 if (sg == 0 && f < swidth) out[jb.bias_off + f] = s;
             }
     }
