@@ -164,7 +164,9 @@ int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_
  * only), bit 2 = reduction of the per-chunk partial gradients into grad.  Calling it with phases 1, 2, 4 in that order
  * equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                           float* partial, float* grad, int accumulate, int bf16x3 /* 0 fp32, 1 bf16x3, 2 mixed */,
+                           float* partial, float* grad, int accumulate,
+                           int datapath /* 0 fp32; 1 bf16x3, act saved by nerf_field_fwd_bf16x3 (32-point tiles); 2 mixed;
+                                           3 bf16x3, act saved by nerf_field_fwd16_bf16x3 (rows in 16-point tiles) */,
                            int phases, void* stream);
 /* ---- optimizer.step() of run_nerf.py:776 for torch.optim.Adam(lr, betas=(beta1, beta2), eps) (run_nerf.py:207), fused over
  * a flat vector: params / grads / exp_avg / exp_avg_sq [n]; step = 1-based step count (bias correction). */

@@ -184,9 +184,10 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
 }
 
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                           float* partial, float* grad, int accumulate, int bf16x3, int phases, void* stream) {
+                           float* partial, float* grad, int accumulate, int datapath, int phases, void* stream) {
+    const int bf16x3 = datapath;
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && bf16x3 >= 0 && bf16x3 <= 2, "bad size");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && bf16x3 >= 0 && bf16x3 <= 3, "bad size");
     return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate,
                                                    bf16x3, phases, (hipStream_t)stream));
 }

@@ -160,6 +160,7 @@ struct WgradJob {
     int c_off, ldc, bias_off;       // offsets into the canonical gradient vector; bias_off < 0: none
     int tiles_k, tile_base;         // tiles of this job: [tile_base, tile_base + tiles_n*tiles_k)
     int vecA, vecB;                 // 16-byte aligned full-row loads allowed
+    int b_tile16;                   // bf16x3: B is stored in 16-point tiles with the row16 row order (field_fwd16_kernel<1>)
 };
 struct WgradArgs {
     WgradJob job[WG_MAX_JOBS];
@@ -442,11 +443,17 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
     // 8 independent, unconditional 16-byte loads per stage (rounds beyond a narrow operand's width re-read its last
     // feature: cache hits, no HBM bytes); zeros (features beyond the width; points >= P in the last stage of the last
     // chunk) are selected when the values are consumed, so the loads stay in flight across a whole compute phase
+    // 16-point tiles (B operands written by field_fwd16_kernel<1>): the stage's 32 points are two consecutive tiles of
+    // sld rows x 64 B, rows in row16 order; the staged LDS row index is then a ROW of the tile, not a feature -- the
+    // contraction does not care, the output columns are mapped back through row16_feature() when they are written
+    const bool t16 = sop == 1 && jb.b_tile16 != 0;
+    const unsigned row_bytes = t16 ? 64u : 128u;
+    const unsigned sg_off = t16 ? (unsigned)(sg >> 2) * 64u * (unsigned)sld + 16u * (unsigned)(sg & 3) : 16u * (unsigned)sg;
     auto gload_into = [&](f32x4 (&dst)[WG3_ROUNDS], int st) {
-        const unsigned off0 = (unsigned)st * tile_bytes + 16u * (unsigned)sg;
+        const unsigned off0 = (unsigned)st * tile_bytes + sg_off;
 #pragma unroll
-        for (int r = 0; r < WG3_ROUNDS; ++r)        // feature clamped into the operand: always inside the tile
-            dst[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(cbase + (off0 + 128u * (unsigned)min(32 * r + sf0, sflast))));
+        for (int r = 0; r < WG3_ROUNDS; ++r)        // row clamped into the operand: always inside the tile
+            dst[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(cbase + (off0 + row_bytes * (unsigned)min(32 * r + sf0, sflast))));
     };
     auto swrite_from = [&](const f32x4 (&src)[WG3_ROUNDS], int buf, int st) {
         unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + sfeat * WG3_FEAT_BYTES + 8 * sg;
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int k = wave_k * 64 + 32 * j + row;
-                    if (k < jb.nB) orow[k] = acc[i][j][r];
+                    if (k < jb.nB) orow[jb.b_tile16 ? row16_feature(k) : k] = acc[i][j][r];
                 }
             }
         }
@@ -794,8 +801,12 @@ __global__ void expand_dir_tiles_bf16_kernel(const float* __restrict__ dir_ray, 
 // phases: bit 0 = full-width jobs, bit 1 = narrow jobs, bit 2 = chunk reduction (7 = everything)
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
                               float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream) {
-    // bf16x3: 0 = fp32 datapath, 1 = split-bf16 datapath, 2 = mixed-precision backward (bf16 operands, one MFMA per product)
+    // bf16x3 (datapath): 0 = fp32, 1 = split-bf16 with act saved by the 32-point forward (32-point tiles), 2 = mixed-precision
+    // backward (bf16 operands, one MFMA per product), 3 = split-bf16 with act saved by the 16-point forward (rows in
+    // 16-point tiles, nerf_common.h row16)
     const bool mixed = bf16x3 == 2;
+    const bool x_tile16 = bf16x3 == 3;
+    if (x_tile16) bf16x3 = 1;
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     hipError_t e;
@@ -847,6 +858,8 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         if (nj >= WG_MAX_JOBS) { ++nj; return; }
         WgradJob& j = wa.job[nj++];
         j.A = A; j.B = B; j.lda = lda; j.nA = nA; j.ldb = ldb; j.nB = nB; j.b_rowdiv = rowdiv;
+        // rows saved by the 16-point forward (256- / 128-wide regions) are in 16-point tiles; encodings are not
+        j.b_tile16 = (x_tile16 && (ldb == W || ldb == WV)) ? 1 : 0;
         j.c_off = c_off; j.ldc = ldc; j.bias_off = bias_off;
         const int tn = (nA + WG_TILE - 1) / WG_TILE;
         j.tiles_k = (nB + WG_TILE - 1) / WG_TILE;

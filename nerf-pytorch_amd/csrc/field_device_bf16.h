@@ -1,5 +1,6 @@
 // Device helpers of the split-bf16 ("bf16x3") field kernels (forward and dgrad).
 #pragma once
+#include <type_traits>
 #include "field_device.h"
 
 namespace nerf {
@@ -102,6 +103,33 @@ __device__ inline void mma16_kstep(f32x4 (&acc)[NB], const u32x4 bhi, const u32x
         for (int i = 0; i < G; ++i) acc[g + i] = mfma16_bf16(alo[i], bhi, acc[g + i]);
     }
 }
+// one k-step whose four MFMA groups (4 blocks = 12 MFMAs each) are separated by `between(integral_constant<int, group>)`:
+// the saving forward issues its row stores there, so that they leave as a steady stream (2 stores per 12 MFMAs)
+// instead of a burst.  Everything is indexed at compile time (register arrays must never be indexed dynamically).
+template <int GI, int NB>
+__device__ __forceinline__ void mma16_group(f32x4 (&acc)[NB], const u32x4 bhi, const u32x4 blo, const u32x4* kbase) {
+    constexpr int g = 4 * GI;
+    u32x4 ahi[4], alo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ahi[i] = kbase[((g + i) * 2) * 64]; alo[i] = kbase[((g + i) * 2 + 1) * 64]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[g + i] = mfma16_bf16(ahi[i], bhi, acc[g + i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[g + i] = mfma16_bf16(ahi[i], blo, acc[g + i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[g + i] = mfma16_bf16(alo[i], bhi, acc[g + i]);
+}
+template <int VOFF, int NV, typename F>
+__device__ __forceinline__ void mma16_kstep_with(f32x4 (&acc)[16], const float (&v)[NV], const float* kstep_base, int lane, F between) {
+    const u32x4* kbase = reinterpret_cast<const u32x4*>(kstep_base) + lane;
+    u32x4 bhi, blo;
+    split8(&v[VOFF], bhi, blo);
+    mma16_group<0>(acc, bhi, blo, kbase); between(std::integral_constant<int, 0>{});
+    mma16_group<1>(acc, bhi, blo, kbase); between(std::integral_constant<int, 1>{});
+    mma16_group<2>(acc, bhi, blo, kbase); between(std::integral_constant<int, 2>{});
+    mma16_group<3>(acc, bhi, blo, kbase); between(std::integral_constant<int, 3>{});
+}
+
 template <int NB, int KS, int VOFF, int NV>
 __device__ inline void mma16_chunk(f32x4 (&acc)[NB], const float (&v)[NV], const float* lbuf, int lane) {
     const u32x4* a = reinterpret_cast<const u32x4*>(lbuf) + lane;

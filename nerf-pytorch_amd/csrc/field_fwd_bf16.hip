@@ -246,9 +246,11 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
 // every A fragment serves 16 instead of 32 points (2x the ds_read_b128 traffic per MAC).  The contraction-slot maps
 // are the fp32 datapath's (hcol / encslot / dirslot with value index 8*s + j); the products are summed in a different
 // order than in the 32-point kernel, so the two agree to rounding (~1e-5 of |raw|), not bit for bit.
-// SAVE (0 none / 1 fp32 tiles / 2 bf16 tiles) writes EXACTLY the act buffer of field_fwd3_kernel<SAVE>: the same
-// 32-point tiles (a wave fills its 16-point half of every row) and the same ReLU bitmask words (lane (pt, q) owns
-// nibbles 8*nb + 4*(q>>1) of the 128-bit half q&1; lanes q and q^2 are OR-ed), so the backward kernels are shared.
+// SAVE (0 none / 1 fp32 / 2 bf16) writes the act buffer of field_fwd3_kernel<SAVE> -- the same regions, the same
+// ReLU bitmask words (lane (pt, q) owns nibbles 8*nb + 4*(q>>1) of the 128-bit half q&1; lanes q and q^2 are OR-ed), the
+// same encoding tiles -- so the backward kernels are shared, with ONE difference for SAVE == 1: the rows of the 256- /
+// 128-wide regions go to 16-point tiles (nerf_common.h, row16) so that every non-temporal store instruction writes
+// full 128-byte lines; the weight-gradient GEMM is told which of the two tilings its B operands have.
 template <int SAVE>
 __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -264,9 +266,6 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     WeightStreamT<2, FIELD_WAVES> ws;                  // same chunk sizes as the 32-point forward stream
     ws.start(a.packed3 + P16F, lds, wave, lane, SAVE && valid);
     stage_small_from(a.packed3 + P3_SMALL, lds, FIELD_WAVES * 64);
-    // After a save_rows() (>= 64 store instructions, all issued after the DMA of the next chunk) the next acquire
-    // waits with a counted vmcnt: the DMA has landed, the newest 63 stores keep draining under that chunk's MFMAs
-    constexpr int NSAVED = SAVE ? 63 : 0;
 
     const float* rp = a.rays + (long)ray * a.ray_stride;
     const float z = a.z_vals[p];
@@ -286,6 +285,19 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
         const size_t idx = tile * (size_t)(F * 32) + (size_t)f * 32 + pp;
         if (SAVE == 2) nt_store(reinterpret_cast<__bf16*>(a.act + region) + idx, (__bf16)v);
         else nt_store(a.act + region + idx, v);
+    };
+    // rows of the 256- / 128-wide regions: 16-point tiles whose row order turns the four 64-byte runs of one store
+    // instruction into two full 128-byte lines (nerf_common.h, row16); bf16 saves (SAVE == 2) keep the 32-point tiles
+    // The wave's 16 points are one tile: the tile base is wave-uniform (SGPR pair), the lane contributes a 32-bit offset
+    // (its row inside a 16-feature block and its point), the (block, register) part is an immediate -- no 64-bit VALU
+    // address arithmetic per store, no address registers held across the MFMA loop.
+    const unsigned tile16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * FIELD_WAVES + wave)));
+    const unsigned lane_row_off = (unsigned)((8 * (q >> 1) + (q & 1)) * 16 + (lane & 15));      // floats
+    auto store_row = [&](size_t region, int F, int nb, int r, float v) __attribute__((always_inline)) {
+        if (SAVE == 2) { store_val(region, F, 16 * nb + 4 * q + r, v); return; }
+        // feature f = 16*nb + 4*q + r: row16(f) * 16 = nb*256 + (8*(q>>1) + (q&1))*16 + r*32
+        float* tile_base = a.act + region + (size_t)tile16 * (size_t)(F * 16);                 // uniform
+        nt_store(tile_base + (nb * 256 + r * 32) + lane_row_off, v);
     };
     if (SAVE) {
         al = act_layout3((size_t)P, (size_t)a.n_rays);
@@ -307,47 +319,82 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[4 * nb + r] = relu ? fmaxf(acc[nb][r], 0.0f) : acc[nb][r];
     };
-    // rows of h (value 4*nb + r = feature 16*nb + 4*q + r) -> region; optionally the ReLU bitmask of `layer`
-    auto save_rows = [&](size_t region, bool with_mask, int layer) {
+    // ---- saving.  HBM absorbs a workgroup's rows (128 points x 256 x 4 B = 128 KiB per layer) at about the rate the
+    // layer computes (~10 B/clk/CU fair share of 6 TB/s vs ~13k clk of MFMA issue per layer), so the rows must leave as a
+    // STEADY stream: 64 store instructions issued back to back after a layer stall the wave on the full store queue
+    // (measured: saving cost 0.70 ms of a 2.9 ms launch, all of it issue stalls, SQ_WAIT_INST_ANY).  The rows of layer L
+    // (they stay live in h[] as the B operand of layer L+1) are therefore written DURING layer L+1, one group of 8
+    // stores per k-step, i.e. 16 per weight chunk; every acquire<> of that layer waits with a counted vmcnt so that the
+    // 16 newest stores keep draining under the next chunk's MFMAs (WeightStreamT::acquire).
+    constexpr int ST_K = SAVE ? 8 : 0;                   // row stores per k-step
+    constexpr int ST_C = 2 * ST_K;                       // per 2-k-step chunk
+    // value 4*nb + r of h = feature 16*nb + 4*q + r; k-step k writes blocks 2k, 2k+1: two stores after each of its four
+    // MFMA groups (group g: block 2k + (g >> 1), registers 2*(g & 1), 2*(g & 1) + 1)
+    auto save_pair = [&](auto kk, auto gg, size_t region) __attribute__((always_inline)) {
+        if (!SAVE || !valid) return;
+        constexpr int nb = 2 * decltype(kk)::value + (decltype(gg)::value >> 1);
+        constexpr int r0 = 2 * (decltype(gg)::value & 1);
+        store_row(region, W, nb, r0, h[4 * nb + r0]);
+        store_row(region, W, nb, r0 + 1, h[4 * nb + r0 + 1]);
+    };
+    auto save_part = [&](auto part, size_t region) __attribute__((always_inline)) {      // the 8 stores of one k-step at once
+        save_pair(part, std::integral_constant<int, 0>{}, region);
+        save_pair(part, std::integral_constant<int, 1>{}, region);
+        save_pair(part, std::integral_constant<int, 2>{}, region);
+        save_pair(part, std::integral_constant<int, 3>{}, region);
+    };
+    auto save_mask16 = [&](int layer) __attribute__((always_inline)) {                   // ReLU bitmask of the rows in h[] (one 16-byte store, lanes q < 2)
         if (!SAVE) return;
-        if (valid) {
+        unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int nb = 0; nb < 16; ++nb)
+        for (int nb = 0; nb < 16; ++nb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) store_val(region, W, 16 * nb + 4 * q + r, h[4 * nb + r]);
-        }
-        if (with_mask) {
-            unsigned w[4] = {0u, 0u, 0u, 0u};
+            for (int r = 0; r < 4; ++r) w[nb >> 2] |= (h[4 * nb + r] > 0.0f ? 1u : 0u) << (8 * (nb & 3) + 4 * (q >> 1) + r);
 #pragma unroll
-            for (int nb = 0; nb < 16; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[nb >> 2] |= (h[4 * nb + r] > 0.0f ? 1u : 0u) << (8 * (nb & 3) + 4 * (q >> 1) + r);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] |= __shfl_xor(w[i], 32);            // the other nibbles: lane q ^ 2
-            if (valid && q < 2)
-                nt_store(reinterpret_cast<u32x4*>(a.act + al.mask) + ((size_t)layer * P + p) * 2 + q, u32x4{w[0], w[1], w[2], w[3]});
-        }
+        for (int i = 0; i < 4; ++i) w[i] |= __shfl_xor(w[i], 32);            // the other nibbles: lane q ^ 2
+        if (valid && q < 2)
+            nt_store(reinterpret_cast<u32x4*>(a.act + al.mask) + ((size_t)layer * P + p) * 2 + q, u32x4{w[0], w[1], w[2], w[3]});
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>;
+    using K6 = std::integral_constant<int, 6>; using K7 = std::integral_constant<int, 7>;
+    // one 256-wide contraction (4 chunks x 2 k-steps) of h into acc while the rows in h go to `region`.  `first` is the
+    // already acquired first chunk.
+    auto kstep_h = [&](auto part, const float* kstep_base, size_t region, bool store_rows) __attribute__((always_inline)) {
+        mma16_kstep_with<8 * decltype(part)::value, 64>(acc, h, kstep_base, lane,
+                                                         [&](auto gg) __attribute__((always_inline)) { if (store_rows) save_pair(part, gg, region); });
+    };
+    auto contract_h = [&](const float* first, size_t region, bool store_rows) __attribute__((always_inline)) {
+        const float* cur = first;
+        kstep_h(K0{}, cur, region, store_rows);
+        kstep_h(K1{}, cur + KSTEP16_W16, region, store_rows);
+        cur = store_rows ? ws.template acquire<ST_C>() : ws.acquire();
+        kstep_h(K2{}, cur, region, store_rows);
+        kstep_h(K3{}, cur + KSTEP16_W16, region, store_rows);
+        cur = store_rows ? ws.template acquire<ST_C>() : ws.acquire();
+        kstep_h(K4{}, cur, region, store_rows);
+        kstep_h(K5{}, cur + KSTEP16_W16, region, store_rows);
+        cur = store_rows ? ws.template acquire<ST_C>() : ws.acquire();
+        kstep_h(K6{}, cur, region, store_rows);
+        kstep_h(K7{}, cur + KSTEP16_W16, region, store_rows);
     };
 
     // ---- layer 0: 63 -> 256 (2 k-steps = one chunk)
     load_bias<16>(acc, bias, q);
     mma16_chunk<16, 2, 0, 16>(acc, e, ws.acquire(), lane);
     take(true);
-    // rows are written right after take(), while the accumulators are dead (the registers the store addressing needs
-    // are free then); the wave's next acquire() drains them, the SIMD's other wave computes meanwhile
-    save_rows(0, true, 0);
-    // ---- layers 1..7 (layer 5 also contracts the xyz encoding: skip connection); 8 k-steps = 4 chunks
+    save_mask16(0);
+    // ---- layers 1..7 (layer 5 also contracts the xyz encoding: skip connection); 8 k-steps = 4 chunks.  Layer l writes
+    // the rows of layer l-1.  Pending stores at the first acquire of a layer: the last chunk's 16 (+ the mask store)
 #pragma unroll 1
     for (int l = 1; l < D; ++l) {
         load_bias<16>(acc, bias + l * W, q);
-        const float* cur = ws.template acquire<NSAVED>();
+        const float* cur = (l == 1) ? ws.template acquire<SAVE ? 1 : 0>() : ws.template acquire<SAVE ? ST_C + 1 : 0>();
         if (l == SKIP + 1) { mma16_chunk<16, 2, 0, 16>(acc, e, cur, lane); cur = ws.acquire(); }
-        mma16_chunk<16, 2, 0, 64>(acc, h, cur, lane);
-        mma16_chunk<16, 2, 16, 64>(acc, h, ws.acquire(), lane);
-        mma16_chunk<16, 2, 32, 64>(acc, h, ws.acquire(), lane);
-        mma16_chunk<16, 2, 48, 64>(acc, h, ws.acquire(), lane);
+        contract_h(cur, (size_t)(l - 1) * layer_floats, SAVE != 0);
         take(true);
-        save_rows((size_t)l * layer_floats, true, l);
+        save_mask16(l);
     }
     // ---- density head: alpha_linear 256 -> 1 (VALU dot + quarter reduction)
     float sigma = 0.0f;
@@ -361,14 +408,10 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
         }
         sigma = quarter_sum(sigma) + small_ptr(lds, SM_BALPHA)[0];
     }
-    // ---- feature_linear 256 -> 256 (no activation)
+    // ---- feature_linear 256 -> 256 (no activation); layer 7's rows are written meanwhile
     load_bias<16>(acc, small_ptr(lds, SM_BFEAT), q);
-    mma16_chunk<16, 2, 0, 64>(acc, h, ws.template acquire<NSAVED>(), lane);
-    mma16_chunk<16, 2, 16, 64>(acc, h, ws.acquire(), lane);
-    mma16_chunk<16, 2, 32, 64>(acc, h, ws.acquire(), lane);
-    mma16_chunk<16, 2, 48, 64>(acc, h, ws.acquire(), lane);
+    contract_h(ws.template acquire<SAVE ? ST_C + 1 : 0>(), (size_t)(D - 1) * layer_floats, SAVE != 0);
     take(false);
-    save_rows(al.feat, false, 0);
     // ---- view branch: [feature, enc(dir)] 283 -> 128, ReLU: 4 + 4 k-steps of 128 outputs, then the dir k-step
     float dv[8];
     {
@@ -388,9 +431,15 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     }
     f32x4 av[8];
     load_bias<8>(av, small_ptr(lds, SM_BVIEWS), q);
-    mma16_chunk<8, 4, 0, 64>(av, h, ws.template acquire<NSAVED>(), lane);
-    mma16_chunk<8, 4, 32, 64>(av, h, ws.acquire(), lane);
-    mma16_chunk<8, 1, 0, 8>(av, dv, ws.acquire(), lane);
+    {   // the feature rows (h[]) are written under the two feature chunks of the view branch (4 k-steps of 128 outputs each)
+        const float* cur = ws.template acquire<ST_C>();
+        save_part(K0{}, al.feat); save_part(K1{}, al.feat); save_part(K2{}, al.feat); save_part(K3{}, al.feat);
+        mma16_chunk<8, 4, 0, 64>(av, h, cur, lane);
+        cur = ws.template acquire<4 * ST_K>();
+        save_part(K4{}, al.feat); save_part(K5{}, al.feat); save_part(K6{}, al.feat); save_part(K7{}, al.feat);
+        mma16_chunk<8, 4, 32, 64>(av, h, cur, lane);
+        mma16_chunk<8, 1, 0, 8>(av, dv, ws.template acquire<4 * ST_K>(), lane);
+    }
     float hv[32];
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
@@ -401,7 +450,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) store_val(al.hv, WV, 16 * nb + 4 * q + r, hv[4 * nb + r]);
+                for (int r = 0; r < 4; ++r) store_row(al.hv, WV, nb, r, hv[4 * nb + r]);
         }
         // view-branch mask: 128 features = 64 bits per half; value 4*nb + r -> bit 8*nb + 4*(q>>1) + r of half q&1
         unsigned w[4] = {0u, 0u, 0u, 0u};

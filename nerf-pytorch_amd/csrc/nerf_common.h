@@ -235,6 +235,21 @@ constexpr int PTS_PER_WG3 = PTS_PER_WAVE3 * FIELD3_WAVES;
 // Regions are sized for P rounded up to a tile; the pad points of the last tile are never written and never used.
 __host__ __device__ constexpr size_t pad32(size_t P) { return (P + 31) & ~(size_t)31; }
 __host__ __device__ inline size_t tile_index(size_t p, int F, int f) { return (p >> 5) * (size_t)(F * 32) + (size_t)f * 32 + (p & 31); }
+// ---- 16-POINT TILES of the rows saved by the 16-point forward (field_fwd16_kernel<1>; regions h[0..7], feat, hv).
+// A wave of that kernel owns 16 points; lane (pt, q) holds features 16*nb + 4*q + j, so one store instruction (j fixed)
+// carries features {j, 4+j, 8+j, 12+j} of its 16 points = four runs of 64 B.  Non-temporal stores of HALF lines reach
+// only 3.2-3.6 TB/s on MI355X against 5.6-6.0 TB/s for full lines (tools/probe/wr_probe.hip: the 32-point tile layout,
+// where the other half of every line belongs to the partner wave, capped the saving forward at 2.9 TB/s), so the rows
+// are laid out so that each instruction's runs pair up into full 128-byte lines: inside a 16-feature block the feature
+// 4*q + j sits at row 8*(q>>1) + 2*j + (q&1), i.e. element (p, f) of an F-wide region lives at
+//     (p >> 4) * F * 16 + row16(f) * 16 + (p & 15).
+// Two consecutive 16-point tiles cover the same 32 points (and the same bytes) as one 32-point tile, so the
+// weight-gradient GEMM stages them as one contiguous block; it contracts over points and only has to know which
+// feature a staged row is (row16_feature).
+__host__ __device__ constexpr int row16(int f) { return (f & ~15) + 8 * ((f >> 3) & 1) + 2 * (f & 3) + ((f >> 2) & 1); }
+__host__ __device__ constexpr int row16_feature(int r) { return (r & ~15) + 8 * ((r >> 3) & 1) + 4 * (r & 1) + ((r >> 1) & 3); }
+__host__ __device__ inline size_t tile16_index(size_t p, int F, int f) { return (p >> 4) * (size_t)(F * 16) + (size_t)row16(f) * 16 + (p & 15); }
+
 struct ActLayout3 {
     size_t h[D], feat;  // tiles of 256 features
     size_t hv;          // tiles of 128

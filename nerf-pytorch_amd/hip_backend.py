@@ -280,11 +280,20 @@ def act_floats(n_rays, n_samples):
     return lib().nerf_act_floats(n_rays, n_samples)
 
 
-def saved_rows(buf, P, region, precision="fp32"):
+def _row16(f):
+    """csrc/nerf_common.h row16(): row of feature f inside a 16-point tile (numpy / torch integer arrays or ints)."""
+    return (f & ~15) + 8 * ((f >> 3) & 1) + 2 * (f & 3) + ((f >> 2) & 1)
+
+
+def saved_rows(buf, P, region, precision="fp32", tile16=None):
     """Debug/test view of one saved region (activations or deltas) as a point-major [P, F] tensor.
     region: "h0".."h7", "feat", "hv", "enc".  The fp32 datapath stores point-major rows (act_layout); the bf16x3
-    datapath stores 32-point feature-major tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32."""
+    datapath stores 32-point feature-major tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32 -- except
+    the 256- / 128-wide activation rows saved by the 16-point forward (precision "bf16x3" with FWD_16PT), which are in
+    16-point tiles with the row16 row order (tile16=True; default: what field_fwd recorded on the buffer)."""
     tiled = precision in ("bf16x3", "mixed")
+    if tile16 is None:
+        tile16 = getattr(buf, "nerf_tile16", False)
     Pa = (P + 31) // 32 * 32 if tiled else P
     widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
     off = 0
@@ -295,6 +304,9 @@ def saved_rows(buf, P, region, precision="fp32"):
                 return flat.view(P, F)
             if precision == "mixed":        # 2-byte elements in the first half of the region
                 flat = flat.view(torch.bfloat16)[:Pa * F].float()
+            if tile16 and precision == "bf16x3" and F in (256, 128):
+                rows = flat.view(Pa // 16, F, 16).permute(0, 2, 1).reshape(Pa, F)[:P]      # [P, row]
+                return rows[:, _row16(torch.arange(F, device=rows.device))]              # feature f sits at row16(f)
             return flat.view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
         off += Pa * F
     raise KeyError(region)
@@ -313,6 +325,8 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
             _check(lib().nerf_field_fwd16_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                                  n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
                    "nerf_field_fwd16_bf16x3")
+        if act is not None and not bf16_save:
+            act.nerf_tile16 = True      # rows in 16-point tiles (csrc/nerf_common.h row16): the weight-gradient GEMM must know
         return raw, act
     if precision == "mixed" and save_act:
         with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD_PER_POINT * n * S, 0.5 * nbytes):
@@ -403,8 +417,9 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32"):
             else:
                 _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
                                           _stream()), "nerf_field_dgrad")
+    datapath = 2 if mx else ((3 if getattr(act, "nerf_tile16", False) else 1) if b3 else 0)
     args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),
-            int(bool(accumulate)), 2 if mx else int(b3))
+            int(bool(accumulate)), datapath)
     if TIMER is None:
         _check(L.nerf_field_wgrad_phase(*args, 7, _stream()), "nerf_field_wgrad_phase")
         return grad

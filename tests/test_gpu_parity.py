@@ -712,7 +712,8 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     feats = torch.cat([orc.posenc(pts.reshape(-1, 3), 10), orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3), 4)], -1)
     _, hidden, feat, hv = orc.field_mlp(Pf, feats, return_hidden=True)
     act = act.cpu()
-    rows = lambda region: npa.hip_backend.saved_rows(act, P, region, "bf16x3")    # 32-point feature-major tiles
+    # the 16-point forward writes its 256- / 128-wide rows to 16-point tiles (row16 order), the encoding to 32-point tiles
+    rows = lambda region: npa.hip_backend.saved_rows(act, P, region, "bf16x3", tile16=True)
     for l in range(8):
         assert maxdiff(rows(f"h{l}"), hidden[l]) <= 3e-4 * max(1.0, float(hidden[l].abs().max())), l
     assert maxdiff(rows("feat"), feat) <= 3e-4 * max(1.0, float(feat.abs().max()))
@@ -725,31 +726,34 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     i = torch.arange(128)
     feat_of = lambda half: 32 * (i >> 4) + ((i & 15) & 3) + 8 * ((i & 15) >> 2) + 4 * half
 
-    def check_masks(buf):
+    def check_masks(buf, tile16):
         words = buf[mask_off:mask_off + 9 * P * 8].view(torch.int32).view(9, P, 2, 4)
         for layer, region, width in [(l, f"h{l}", 256) for l in range(8)] + [(8, "hv", 128)]:
-            pos = npa.hip_backend.saved_rows(buf, P, region, "bf16x3") > 0
+            pos = npa.hip_backend.saved_rows(buf, P, region, "bf16x3", tile16=tile16) > 0
             for half in range(2):
                 bits = ((words[layer, :, half, :, None] >> torch.arange(32)) & 1).reshape(P, 128).bool()
                 n = width // 2
                 assert torch.equal(bits[:, :n], pos[:, feat_of(half)[:n]]), (layer, half)
-    check_masks(act)
+    check_masks(act, True)
     npa.hip_backend.FWD_16PT = False
     try:
         _, act32 = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
     finally:
         npa.hip_backend.FWD_16PT = True
+    assert not getattr(act32, "nerf_tile16", False)
     act32 = act32.cpu()
-    check_masks(act32)
+    check_masks(act32, False)
     for region in [f"h{l}" for l in range(8)] + ["feat", "hv", "enc"]:
-        a16, a32 = npa.hip_backend.saved_rows(act, P, region, "bf16x3"), npa.hip_backend.saved_rows(act32, P, region, "bf16x3")
+        a16 = npa.hip_backend.saved_rows(act, P, region, "bf16x3", tile16=True)
+        a32 = npa.hip_backend.saved_rows(act32, P, region, "bf16x3", tile16=False)
         if region == "enc":
             a16, a32 = a16[:, :63], a32[:, :63]
         assert maxdiff(a16, a32) <= 1e-4 * max(1.0, float(a32.abs().max())), region
 
 
+@pytest.mark.parametrize("fwd16", [True, False])
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192)])
-def test_field_backward_bf16x3(npa, dev, nets, n_rays, S):
+def test_field_backward_bf16x3(npa, dev, nets, n_rays, S, fwd16, monkeypatch):
     """Split-bf16 forward + dgrad + wgrad vs fp64 autograd.  Besides the ~1e-5 product error, ReLU units whose
     pre-activation lies within the forward's ~1e-4 error of zero pick the other side of the kink (a few units per
     point out of 2176), which moves a gradient by up to ~1e-2 of its max while its direction is unchanged
@@ -760,7 +764,11 @@ def test_field_backward_bf16x3(npa, dev, nets, n_rays, S):
     z = torch.sort(torch.rand(n_rays, S, generator=g) * 4.0 + 2.0, -1)[0]
     d_raw = torch.randn(n_rays, S, 4, generator=g)
     packed3 = nf.packed_params("bf16x3")
+    # both forwards: the 16-point kernel saves its rows in 16-point tiles, the 32-point kernel in 32-point tiles; the
+    # weight-gradient GEMM stages either (datapath 3 / 1 of nerf_field_wgrad_phase)
+    monkeypatch.setattr(npa.hip_backend, "FWD_16PT", fwd16)
     raw, act = npa.hip_backend.field_fwd(packed3, rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
+    assert bool(getattr(act, "nerf_tile16", False)) == fwd16
     grad = torch.full((595844,), float("nan"), device=dev)
     npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), grad, accumulate=False, precision="bf16x3")
     P64 = {k: v.double().requires_grad_(True) for k, v in Pf.items()}

@@ -240,6 +240,27 @@ def test_precision_selection_and_saved_row_views():
         assert torch.equal(npa.hip_backend.saved_rows(buf16.view(torch.float32), P, name, "mixed"), want[name])
     flat = torch.arange(P * 2688, dtype=torch.float32)
     assert torch.equal(npa.hip_backend.saved_rows(flat, P, "h1", "fp32"), flat[P * 256:2 * P * 256].view(P, 256))
+    # rows saved by the 16-point forward: 16-point tiles, feature 4*q + j of a 16-block at row 8*(q>>1) + 2*j + (q&1)
+    buf16t = torch.zeros(total)
+    off = 0
+    for name, F in widths:
+        p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
+        if F in (256, 128):
+            q, j = (f % 16) // 4, f % 4
+            row = (f // 16) * 16 + 8 * (q >> 1) + 2 * j + (q & 1)
+            idx = (p // 16) * F * 16 + row * 16 + p % 16
+        else:
+            idx = (p // 32) * F * 32 + f * 32 + p % 32
+        buf16t[off + idx] = want[name]
+        off += Pp * F
+    for name, F in widths:
+        assert torch.equal(npa.hip_backend.saved_rows(buf16t, P, name, "bf16x3", tile16=True), want[name]), name
+    # one store instruction of that kernel (j fixed, q = 0..3) covers rows {2j, 2j+1} and {8+2j, 8+2j+1}: two full lines
+    r16 = npa.hip_backend._row16
+    for j in range(4):
+        rows = sorted(r16(4 * q + j) for q in range(4))
+        assert rows == [2 * j, 2 * j + 1, 8 + 2 * j, 9 + 2 * j]
+    assert sorted(r16(f) for f in range(256)) == list(range(256))
 
 
 def test_flat_adam_rejects_options_the_fused_kernel_ignores():

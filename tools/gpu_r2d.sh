@@ -1,0 +1,12 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 300 python tools/exp_fwd3.py libnerf_hip.so --bwd 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r2d_exp.log
+timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider > gpurun_out/r2d_tests.log 2>&1; echo "pytest rc=$?"
+tail -4 gpurun_out/r2d_tests.log
+timeout 600 python bench.py --no-cpu-baseline > gpurun_out/r2d_bench_lego.json 2> gpurun_out/r2d_bench_lego.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r2d_bench_lego.json').read())
+print(d['value'], d['ms_per_step'], d['inference_rays_per_s'], d['speedup_vs_rocm_eager'])
+print({k:(round(v['avg_ms'],3), round(v['mfma_frac'],3), round(v['hbm_frac'],3)) for k,v in d['kernels'].items()})
+PY
