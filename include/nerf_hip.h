@@ -74,6 +74,12 @@ int nerf_make_rays(int H, int W, const float* K_host, const float* c2w_host, con
  * raw[n_rays][n_samples][4] = (rgb pre-sigmoid, sigma pre-relu).
  * act: NULL for inference; otherwise nerf_act_floats() floats that receive what the backward needs. */
 size_t nerf_act_floats(int n_rays, int n_samples);
+/* Scratch of one training call of render_rays (run_nerf.py:308-418) on n_rays rays, in floats: the saved activations of
+ * the coarse pass (n_coarse samples) and of the fine pass (n_coarse + n_fine samples; none if n_fine == 0), plus the
+ * deltas and the per-chunk partial weight gradients of the larger pass (reused by both backward calls).  The caller
+ * owns this memory (persistent across steps; any datapath); 0 when training == 0 -- inference needs no scratch.
+ * = nerf_act_floats(coarse) + nerf_act_floats(fine) + nerf_delta_floats(larger) + nerf_wgrad_partial_floats(larger). */
+size_t nerf_workspace_floats(int n_rays, int n_coarse, int n_fine, int training);
 int nerf_field_fwd(const float* packed, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                    int n_samples, float* raw, float* act, void* stream);
 

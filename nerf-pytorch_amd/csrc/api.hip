@@ -100,6 +100,13 @@ size_t nerf_wgrad_partial_floats(int n_rays, int n_samples) {
     return nerf::wgrad_partial_floats((long)n_rays * n_samples);
 }
 
+size_t nerf_workspace_floats(int n_rays, int n_coarse, int n_fine, int training) {
+    if (!training || n_rays <= 0 || n_coarse <= 0 || n_fine < 0) return 0;
+    const int s_big = n_coarse + n_fine;
+    return nerf_act_floats(n_rays, n_coarse) + (n_fine > 0 ? nerf_act_floats(n_rays, s_big) : 0) +
+           nerf_delta_floats(n_rays, s_big) + nerf_wgrad_partial_floats(n_rays, s_big);
+}
+
 int nerf_field_fwd(const float* packed, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                    int n_samples, float* raw, float* act, void* stream) {
     REQUIRE(packed && rays && z_vals && raw, "null pointer");

@@ -36,6 +36,7 @@ def _declare(lib):
         "nerf_sample_coarse": (i, [p, i, i, p, i, i, p, p, p]),
         "nerf_make_rays": (i, [i, i, p, p, p, i, f, f, p, i, p]),
         "nerf_act_floats": (sz, [i, i]),
+        "nerf_workspace_floats": (sz, [i, i, i, i]),
         "nerf_field_fwd": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_raw2outputs": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p, p]),
         "nerf_raw2outputs_bwd": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p, p, p]),
@@ -68,7 +69,7 @@ def _declare(lib):
 
 
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
-           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_sample_coarse", "nerf_act_floats", "nerf_field_fwd",
+           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_sample_coarse", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
@@ -280,6 +281,59 @@ def act_floats(n_rays, n_samples):
     return lib().nerf_act_floats(n_rays, n_samples)
 
 
+class Workspace:
+    """Caller-owned, persistent scratch of the backward path (the library allocates nothing and keeps no
+    pointer).  The saved activations of a forward live from the forward to its backward; the deltas and the per-chunk
+    partial gradients live inside one field_bwd call.  Buffers are LEASED from this pool (take) and handed back (give):
+    a training loop of fixed shape re-uses the same device buffers every step -- same pointers, no allocation -- and a
+    forward whose backward is still pending simply keeps its lease (a second forward leases another buffer).  A lease
+    that is never returned (graph dropped without backward) is an ordinary tensor and is freed with its owner."""
+    MAX_FREE = 6
+
+    def __init__(self):
+        self._free = {}
+
+    def take(self, n_floats, device):
+        free = self._free.setdefault(str(device), [])
+        best = None
+        for i, t in enumerate(free):
+            if t.numel() >= n_floats and (best is None or t.numel() < free[best].numel()):
+                best = i
+        if best is not None and free[best].numel() <= 2 * n_floats + (1 << 20):
+            return free.pop(best)
+        return torch.empty(max(int(n_floats), 1), dtype=torch.float32, device=device)
+
+    def give(self, t):
+        if t is None:
+            return
+        free = self._free.setdefault(str(t.device), [])
+        if any(f.data_ptr() == t.data_ptr() for f in free):
+            return
+        free.append(t)
+        if len(free) > self.MAX_FREE:       # (list.remove would compare tensors elementwise)
+            free.pop(min(range(len(free)), key=lambda i: free[i].numel()))
+
+    def clear(self):
+        self._free.clear()
+
+
+WORKSPACE = Workspace()
+SAVE_BUDGET_BYTES = int(float(os.environ.get("NERF_SAVE_BUDGET_GB", "48")) * (1 << 30))
+
+
+def workspace_floats(n_rays, n_coarse, n_fine, training=True):
+    """nerf_workspace_floats(): floats of scratch one training render_rays call needs (saved activations of both
+    passes + deltas + partial gradients of the larger pass); 0 for inference."""
+    return lib().nerf_workspace_floats(int(n_rays), int(n_coarse), int(n_fine), int(bool(training)))
+
+
+def max_saved_rays(n_coarse, n_fine):
+    """Largest ray count whose backward scratch fits SAVE_BUDGET_BYTES (multiple of 1024, at least 1024): larger ray
+    chunks are back-propagated in sub-chunks of this size with the forward recomputed (render._RenderRays)."""
+    per_1024 = 4 * workspace_floats(1024, n_coarse, n_fine, True)
+    return max(1, SAVE_BUDGET_BYTES // max(per_1024, 1)) * 1024
+
+
 def _row16(f):
     """csrc/nerf_common.h row16(): row of feature f inside a 16-point tile (numpy / torch integer arrays or ints)."""
     return (f & ~15) + 8 * ((f >> 3) & 1) + 2 * (f & 3) + ((f >> 2) & 1)
@@ -316,7 +370,9 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     n, stride = rays.shape
     S = z_vals.shape[1]
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
-    act = torch.empty(act_floats(n, S), dtype=torch.float32, device=rays.device) if save_act else None
+    act = WORKSPACE.take(act_floats(n, S), rays.device) if save_act else None
+    if act is not None:
+        act.nerf_tile16 = False
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in ("bf16x3", "mixed") and FWD_16PT:
         bf16_save = int(precision == "mixed")
@@ -400,8 +456,16 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32"):
     n, S, _ = d_raw.shape
     L = lib()
     dev = d_raw.device
-    delta = torch.empty(L.nerf_delta_floats(n, S), dtype=torch.float32, device=dev)
-    partial = torch.empty(L.nerf_wgrad_partial_floats(n, S), dtype=torch.float32, device=dev)
+    delta = WORKSPACE.take(L.nerf_delta_floats(n, S), dev)
+    partial = WORKSPACE.take(L.nerf_wgrad_partial_floats(n, S), dev)
+    try:
+        return _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S)
+    finally:        # stream-ordered: the next lease is written by kernels enqueued after these
+        WORKSPACE.give(delta)
+        WORKSPACE.give(partial)
+
+
+def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S):
     b3 = precision == "bf16x3"
     mx = precision == "mixed"
     P = n * S

@@ -72,7 +72,8 @@ class _FieldQuery(torch.autograd.Function):
             raise RuntimeError(_FREED_MSG)
         grad = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=d_raw.device)
         hb.field_bwd(ctx.packed, ctx.act, d_raw.contiguous(), grad, accumulate=False, precision=ctx.prec)
-        ctx.act = None      # ~10 KB per point: released as soon as the gradient exists (like autograd frees its buffers)
+        hb.WORKSPACE.give(ctx.act)
+        ctx.act = None      # ~10 KB per point: back to the workspace pool as soon as the gradient exists
         model.last_flat_grad = grad
         return (None, None, None, None) + _grad_views(model, grad)
 
@@ -86,112 +87,149 @@ def _grad_views(model, flat_grad):
     return tuple(flat_grad[off:off + int(np.prod(shape))].view(shape) for _, off, shape in _param_slices(model))
 
 
+def _field_pass(cfg, rays, rnd, model_c, model_f, save):
+    """One evaluation of render_rays' pipeline (run_nerf.py:351-412) on `rays`: coarse depths -> field -> composite
+    [-> hierarchical depths -> field -> composite].  save=True leases workspace buffers for the saved activations
+    (hb.Workspace) and returns them in the dict; everything else is small ([N,S]-sized)."""
+    n_c, n_f = cfg["N_samples"], cfg["N_importance"]
+    dev = rays.device
+    std, wb, prec = cfg["raw_noise_std"], cfg["white_bkgd"], cfg.get("precision", "fp32")
+    r = {}
+    r["packed_c"] = model_c.packed_params(prec)
+    r["z_c"] = hb.sample_coarse(rays, _linspace01(n_c, dev), cfg["lindisp"], rnd.get("t_rand"))
+    r["raw_c"], r["act_c"] = hb.field_fwd(r["packed_c"], rays, r["z_c"], save_act=save, precision=prec)
+    r["rgb_c"], r["disp_c"], r["acc_c"], w_c, _ = hb.raw2outputs(r["raw_c"], r["z_c"], rays, rays.shape[1], rnd.get("noise_c"), std, wb,
+                                                              want_weights=n_f > 0, want_depth=False, rays_d_offset=3)
+    if n_f <= 0:
+        return r
+    u = rnd.get("u")
+    r["z_f"], r["z_std"], _ = hb.sample_fine(r["z_c"], w_c, n_f, u, None if u is not None else _linspace01(n_f, dev))
+    mf = model_c if (model_f is None or model_f is model_c) else model_f
+    r["packed_f"] = mf.packed_params(prec)
+    r["raw_f"], r["act_f"] = hb.field_fwd(r["packed_f"], rays, r["z_f"], save_act=save, precision=prec)
+    r["rgb_f"], r["disp_f"], r["acc_f"], _, _ = hb.raw2outputs(r["raw_f"], r["z_f"], rays, rays.shape[1], rnd.get("noise_f"), std, wb,
+                                                             want_weights=False, want_depth=False, rays_d_offset=3)
+    return r
+
+
+def _release(r):
+    for k in ("act_c", "act_f"):
+        hb.WORKSPACE.give(r.get(k))
+        r[k] = None
+
+
 class _RenderRays(torch.autograd.Function):
-    """The whole of render_rays (run_nerf.py:308-418) as one autograd node."""
+    """The whole of render_rays (run_nerf.py:308-418) as one autograd node.
+
+    Memory: the backward needs ~10.7 KB of saved activations per sample point (plus as much for the deltas).  Up to
+    hb.max_saved_rays(...) rays per call (default budget 48 GiB: ~10k rays at 64+128 samples, i.e. every N_rand of the
+    BASELINE configs) they are saved by the forward into buffers leased from hb.WORKSPACE (persistent across steps, no
+    per-step allocation).  Larger ray chunks (the reference's default chunk is 32768 rays = ~150 GB of activations) run
+    the forward WITHOUT saving and the backward re-runs it, with saving, one sub-chunk at a time (the kernels are
+    deterministic, so the recomputed pass is bit-identical to the first): bounded memory for +1 inference-speed forward."""
 
     @staticmethod
     def forward(ctx, cfg, rays, rnd, model_c, model_f, *params):
-        n_c, n_f = cfg["N_samples"], cfg["N_importance"]
-        same_net = model_f is None or model_f is model_c
+        n_f = cfg["N_importance"]
         need = cfg["need_grad"]
-        dev = rays.device
-        std = cfg["raw_noise_std"]
-        wb = cfg["white_bkgd"]
-        prec = cfg.get("precision", "fp32")
-        packed_c = model_c.packed_params(prec)
-        z_c = hb.sample_coarse(rays, _linspace01(n_c, dev), cfg["lindisp"], rnd.get("t_rand"))
-        raw_c, act_c = hb.field_fwd(packed_c, rays, z_c, save_act=need, precision=prec)
-        rgb_c, disp_c, acc_c, w_c, _ = hb.raw2outputs(raw_c, z_c, rays, rays.shape[1], rnd.get("noise_c"), std, wb,
-                                                      want_weights=n_f > 0, want_depth=False, rays_d_offset=3)
-        ctx.cfg, ctx.model_c, ctx.model_f, ctx.same_net = cfg, model_c, model_f, same_net
+        n = rays.shape[0]
+        sub = hb.max_saved_rays(cfg["N_samples"], n_f) if need else n
+        ctx.checkpoint = bool(need and n > sub)
+        ctx.sub_rays = sub
+        r = _field_pass(cfg, rays, rnd, model_c, model_f, save=need and not ctx.checkpoint)
+        ctx.cfg, ctx.model_c, ctx.model_f = cfg, model_c, model_f
+        ctx.same_net = model_f is None or model_f is model_c
         ctx.n_params_c = len(_param_slices(model_c))
+        ctx.need = need
         ctx.set_materialize_grads(False)
+        ctx.rays, ctx.rnd = rays, rnd
+        ctx.saved = None if ctx.checkpoint else r
+        ctx.consumed = False
         if n_f <= 0:
-            ctx.save_for_backward(rays, z_c, raw_c)
-            ctx.saved = dict(act_c=act_c, packed_c=packed_c, rnd=rnd)
-            return rgb_c, disp_c, acc_c, raw_c
-        u = rnd.get("u")
-        z_f, z_std, _ = hb.sample_fine(z_c, w_c, n_f, u, None if u is not None else _linspace01(n_f, dev))
-        mf = model_c if same_net else model_f
-        packed_f = mf.packed_params(prec)
-        raw_f, act_f = hb.field_fwd(packed_f, rays, z_f, save_act=need, precision=prec)
-        rgb_f, disp_f, acc_f, _, _ = hb.raw2outputs(raw_f, z_f, rays, rays.shape[1], rnd.get("noise_f"), std, wb,
-                                                    want_weights=False, want_depth=False, rays_d_offset=3)
-        ctx.save_for_backward(rays, z_c, raw_c, z_f, raw_f)
-        ctx.saved = dict(act_c=act_c, packed_c=packed_c, rnd=rnd, act_f=act_f, packed_f=packed_f)
-        ctx.mark_non_differentiable(z_std)     # the reference detaches z_samples (run_nerf.py:394)
-        return rgb_f, disp_f, acc_f, raw_f, rgb_c, disp_c, acc_c, z_std
+            return r["rgb_c"], r["disp_c"], r["acc_c"], r["raw_c"]
+        ctx.mark_non_differentiable(r["z_std"])     # the reference detaches z_samples (run_nerf.py:394)
+        return r["rgb_f"], r["disp_f"], r["acc_f"], r["raw_f"], r["rgb_c"], r["disp_c"], r["acc_c"], r["z_std"]
 
     @staticmethod
     def backward(ctx, *gouts):
-        if ctx.saved is None:
+        if ctx.consumed:
             raise RuntimeError(_FREED_MSG)
-        s, cfg = dict(ctx.saved), ctx.cfg
-        tens = ctx.saved_tensors
-        s.update(rays=tens[0], z_c=tens[1], raw_c=tens[2])
-        if len(tens) > 3:
-            s.update(z_f=tens[3], raw_f=tens[4])
-        rays, rnd = s["rays"], s["rnd"]
-        std, wb = cfg["raw_noise_std"], cfg["white_bkgd"]
+        cfg = ctx.cfg
         n_lead = 5
         none_c = (None,) * ctx.n_params_c
-        if s["act_c"] is None:
-            return (None,) * n_lead + none_c + (() if ctx.same_net else (None,) * ctx.n_params_c)
-        dev = rays.device
-        n = rays.shape[0]
+        none_all = (None,) * n_lead + none_c + (() if ctx.same_net else none_c)
+        if not ctx.need:
+            return none_all
+        rays_all, rnd_all = ctx.rays, ctx.rnd
+        std, wb, prec = cfg["raw_noise_std"], cfg["white_bkgd"], cfg.get("precision", "fp32")
+        dev = rays_all.device
+        n_all = rays_all.shape[0]
+        n_f = cfg["N_importance"]
+        fine = n_f > 0
+        # upstream gradients of (rgb, disp, acc, raw) of the fine (or only) pass and of the coarse pass
+        up_f = (gouts[0], gouts[1], gouts[2], gouts[3])
+        up_c = (gouts[4], gouts[5], gouts[6], None) if fine else None
+        if not fine:
+            up_c, up_f = up_f, None
+        has = lambda up: up is not None and any(g is not None for g in up)
+        if not has(up_c) and not has(up_f):
+            ctx.consumed = True
+            if ctx.saved is not None:
+                _release(ctx.saved)
+            return none_all
+        grad_c = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
+        grad_f = None if (ctx.same_net or not fine) else torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
+        wrote = {"c": False, "f": False}
 
-        def cgrads(d_rgb, d_disp, d_acc, d_raw_up=None):
-            zero = lambda t, shape: t.contiguous() if t is not None else None
-            if d_rgb is None and d_disp is None and d_acc is None and d_raw_up is None:
-                return None
-            if d_rgb is None and not (d_disp is None and d_acc is None):
-                d_rgb = torch.zeros((n, 3), dtype=torch.float32, device=dev)
-            return (d_rgb.contiguous() if d_rgb is not None else None), zero(d_acc, n), zero(d_disp, n), d_raw_up
-
-        def field_grad(model, packed, act, raw, z, noise, g, grad, accumulate):
-            d_rgb, d_acc, d_disp, d_raw_up = g
+        def field_grad(rays, packed, act, raw, z, noise, up, lo, hi, grad, key):
+            d_rgb, d_disp, d_acc, d_raw_up = (None if g is None else g[lo:hi] for g in up)
+            m = hi - lo
+            if d_rgb is None and (d_disp is not None or d_acc is not None):
+                d_rgb = torch.zeros((m, 3), dtype=torch.float32, device=dev)
+            c = lambda t: t.to(torch.float32).contiguous() if t is not None else None
             if d_rgb is None:       # only `raw` itself (extras['raw'], e.g. a sigma regulariser) carries a gradient
-                d_raw = d_raw_up.to(torch.float32).contiguous()
+                d_raw = c(d_raw_up)
             else:
-                d_raw = hb.raw2outputs_bwd(raw, z, rays, rays.shape[1], noise, std, wb, d_rgb, d_acc, d_disp,
+                d_raw = hb.raw2outputs_bwd(raw, z, rays, rays.shape[1], noise, std, wb, c(d_rgb), c(d_acc), c(d_disp),
                                            rays_d_offset=3)
                 if d_raw_up is not None:
                     d_raw += d_raw_up
-            hb.field_bwd(packed, act, d_raw, grad, accumulate, precision=cfg.get("precision", "fp32"))
+            hb.field_bwd(packed, act, d_raw, grad, wrote[key], precision=prec)
+            wrote[key] = True
 
-        if cfg["N_importance"] <= 0:
-            g = cgrads(gouts[0], gouts[1], gouts[2], gouts[3])
-            if g is None:
-                return (None,) * n_lead + none_c
-            grad_c = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
-            field_grad(ctx.model_c, s["packed_c"], s["act_c"], s["raw_c"], s["z_c"], rnd.get("noise_c"), g, grad_c, False)
-            ctx.model_c.last_flat_grad = grad_c
-            ctx.saved = None
-            return (None,) * n_lead + _grad_views(ctx.model_c, grad_c)
+        def backprop(r, rays, rnd, lo, hi):
+            if has(up_c):
+                field_grad(rays, r["packed_c"], r["act_c"], r["raw_c"], r["z_c"], rnd.get("noise_c"), up_c, lo, hi, grad_c, "c")
+            hb.WORKSPACE.give(r["act_c"])
+            r["act_c"] = None
+            if fine and has(up_f):
+                if ctx.same_net:
+                    field_grad(rays, r["packed_f"], r["act_f"], r["raw_f"], r["z_f"], rnd.get("noise_f"), up_f, lo, hi, grad_c, "c")
+                else:
+                    field_grad(rays, r["packed_f"], r["act_f"], r["raw_f"], r["z_f"], rnd.get("noise_f"), up_f, lo, hi, grad_f, "f")
+            _release(r)
 
-        g_f = cgrads(gouts[0], gouts[1], gouts[2], gouts[3])
-        g_c = cgrads(gouts[4], gouts[5], gouts[6])
-        grad_c = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
-        wrote_c = False
-        if g_c is not None:
-            field_grad(ctx.model_c, s["packed_c"], s["act_c"], s["raw_c"], s["z_c"], rnd.get("noise_c"), g_c, grad_c, False)
-            wrote_c = True
-        grad_f = None
-        if ctx.same_net:
-            if g_f is not None:
-                field_grad(ctx.model_c, s["packed_f"], s["act_f"], s["raw_f"], s["z_f"], rnd.get("noise_f"), g_f, grad_c, wrote_c)
-                wrote_c = True
-        elif g_f is not None:
-            grad_f = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
-            field_grad(ctx.model_f, s["packed_f"], s["act_f"], s["raw_f"], s["z_f"], rnd.get("noise_f"), g_f, grad_f, False)
-            ctx.model_f.last_flat_grad = grad_f
+        if not ctx.checkpoint:
+            backprop(ctx.saved, rays_all, rnd_all, 0, n_all)
+        else:
+            step = ctx.sub_rays
+            for lo in range(0, n_all, step):
+                hi = min(lo + step, n_all)
+                rays = rays_all[lo:hi]
+                rnd = {k: v[lo:hi] for k, v in rnd_all.items()}
+                backprop(_field_pass(cfg, rays, rnd, ctx.model_c, ctx.model_f, save=True), rays, rnd, lo, hi)
         ctx.saved = None
-        out_c = _grad_views(ctx.model_c, grad_c) if wrote_c else none_c
-        if wrote_c:
+        ctx.consumed = True
+        out_c = none_c
+        if wrote["c"]:
             ctx.model_c.last_flat_grad = grad_c
+            out_c = _grad_views(ctx.model_c, grad_c)
         if ctx.same_net:
             return (None,) * n_lead + out_c
-        out_f = _grad_views(ctx.model_f, grad_f) if grad_f is not None else (None,) * ctx.n_params_c
+        out_f = none_c
+        if wrote["f"]:
+            ctx.model_f.last_flat_grad = grad_f
+            out_f = _grad_views(ctx.model_f, grad_f)
         return (None,) * n_lead + out_c + out_f
 
 

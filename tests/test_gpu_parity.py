@@ -1078,6 +1078,68 @@ def test_adversarial_scene_psnr_delta(npa, dev):
         assert g["psnr_delta_db"] < 0.01 and g["psnr_vs_ref_db"] >= floor, g
 
 
+# ---------------------------------------------------------------- workspace leases / recomputing backward
+@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+def test_large_chunks_backpropagate_in_subchunks_with_recompute(npa, dev, nets, precision, monkeypatch):
+    """Ray chunks whose saved activations exceed the workspace budget run the forward without saving and the backward
+    re-runs it sub-chunk by sub-chunk: outputs identical, gradients equal to the one-shot backward up to the fp32
+    summation order of the per-sub-chunk partial sums."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    n = 2500
+    rays = orc.synthetic_rays(n, seed=77).to(dev)
+    target = torch.rand(n, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    rnd = {k: v.to(dev) for k, v in orc.synthetic_randoms(n, 64, 128, seed=5).items()}
+    kw = dict(N_samples=64, N_importance=128, network_fine=nf, white_bkgd=True, perturb=1.0, raw_noise_std=0.5, retraw=True)
+
+    def run():
+        for m in (nc, nf):
+            m.zero_grad()
+        out = npa.render_rays(rays, nc, None, randoms=rnd, **kw)
+        loss = npa.img2mse(out["rgb_map"], target) + npa.img2mse(out["rgb0"], target) + 1e-4 * out["raw"][..., 3].abs().mean()
+        loss.backward()
+        return {k: v.detach().clone() for k, v in out.items()}, nc.last_flat_grad.clone(), nf.last_flat_grad.clone()
+    npa.set_precision(precision)
+    try:
+        assert hb.max_saved_rays(64, 128) >= n
+        out_a, gc_a, gf_a = run()
+        monkeypatch.setattr(hb, "SAVE_BUDGET_BYTES", 4 * hb.workspace_floats(1024, 64, 128) + 1)      # -> 1024-ray sub-chunks
+        assert hb.max_saved_rays(64, 128) == 1024
+        out_b, gc_b, gf_b = run()
+    finally:
+        npa.set_precision("fp32")
+    for k in out_a:
+        assert torch.equal(out_a[k], out_b[k]) or bool((torch.isnan(out_a[k]) == torch.isnan(out_b[k])).all()), k
+    for ga, gb in ((gc_a, gc_b), (gf_a, gf_b)):
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(ga.abs().max()), float((ga - gb).abs().max()) / float(ga.abs().max())
+
+
+def test_training_steps_reuse_the_same_workspace_buffers(npa, dev, nets):
+    """No per-step allocation of the backward scratch: consecutive steps lease the same device buffers (hb.WORKSPACE)."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    rays = orc.synthetic_rays(256, seed=9).to(dev)
+    target = torch.rand(256, 3, device=dev)
+    seen = []
+    real_take = hb.WORKSPACE.take
+
+    def spy(n_floats, device):
+        t = real_take(n_floats, device)
+        seen[-1].append(t.data_ptr())
+        return t
+    hb.WORKSPACE.take = spy
+    try:
+        for step in range(3):
+            seen.append([])
+            for m in (nc, nf):
+                m.zero_grad()
+            out = npa.render_rays(rays, nc, None, 64, N_importance=128, network_fine=nf, white_bkgd=True, perturb=1.0)
+            (npa.img2mse(out["rgb_map"], target) + npa.img2mse(out["rgb0"], target)).backward()
+    finally:
+        hb.WORKSPACE.take = real_take
+    assert len(seen[1]) == 6 and seen[1] == seen[2], seen        # 2 act + 2 x (delta, partial) leases per step, same pointers
+
+
 # ---------------------------------------------------------------- boundary: render() / run_network / NeRF.forward
 def test_render_boundary_and_chunking(npa, dev, nets):
     nc, nf, Pc, Pf = nets

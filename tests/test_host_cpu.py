@@ -316,3 +316,31 @@ def test_blender_scene_round_trips_through_the_on_disk_format(tmp_path):
     assert len(meta["frames"]) == 2 and abs(meta["camera_angle_x"] - sc["camera_angle_x"]) < 1e-12
     assert np.allclose(np.array(meta["frames"][1]["transform_matrix"]), sc["poses"][1].numpy())
     assert open(tmp_path / "train" / "r_0.png", "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+
+
+def test_workspace_size_query_and_lease_pool():
+    """nerf_workspace_floats = act(coarse) + act(fine) + delta(larger) + partial(larger); 0 for inference; the Python
+    pool re-issues a returned buffer (same pointer) and never hands out one that is still leased."""
+    L = npa.hip_backend.lib()
+    for n, sc, nf in ((4096, 64, 128), (1024, 64, 0), (7, 5, 3)):
+        big = sc + nf
+        want = L.nerf_act_floats(n, sc) + (L.nerf_act_floats(n, big) if nf else 0) + L.nerf_delta_floats(n, big) + \
+            L.nerf_wgrad_partial_floats(n, big)
+        assert L.nerf_workspace_floats(n, sc, nf, 1) == want == npa.hip_backend.workspace_floats(n, sc, nf)
+        assert L.nerf_workspace_floats(n, sc, nf, 0) == 0
+    assert L.nerf_workspace_floats(0, 64, 128, 1) == 0
+    # the default budget (48 GiB) covers every N_rand of the BASELINE configs without recomputation
+    assert npa.hip_backend.max_saved_rays(64, 128) >= 8192 and npa.hip_backend.max_saved_rays(64, 128) % 1024 == 0
+    w = npa.hip_backend.Workspace()
+    a = w.take(1000, "cpu")
+    b = w.take(1000, "cpu")
+    assert a.data_ptr() != b.data_ptr()
+    w.give(a)
+    c = w.take(900, "cpu")
+    assert c.data_ptr() == a.data_ptr()          # re-issued; b is still leased and was not touched
+    w.give(c); w.give(c); w.give(None)
+    assert len(w._free["cpu"]) == 1
+    big = w.take(10_000_000, "cpu")              # a much larger request does not squat in a small buffer, nor vice versa
+    assert big.numel() == 10_000_000
+    w.give(big)
+    assert w.take(1000, "cpu").data_ptr() == a.data_ptr()
