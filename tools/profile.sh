@@ -1,32 +1,44 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py: kernel stats (timing) + separate PMC passes (HBM bytes, MFMA busy, LDS).
-# Writes under gpurun_out/prof_*; summaries are copied into profiles/ by hand afterwards.
+# rocprofv3 evidence for bench.py (one datapath per call): kernel stats (timing) + separate PMC passes (HBM bytes, MFMA
+# busy, LDS, waits).  usage: tools/profile.sh <fp32|bf16x3|mixed> [extra bench flags]
+# Writes gpurun_out/prof_<prec>/ and the two summaries profiles/ expects:
+#   gpurun_out/prof_<prec>/kernel_stats.csv, gpurun_out/prof_<prec>/pmc_summary.csv
+PREC=${1:-bf16x3}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-mkdir -p $R/gpurun_out
+OUT=$R/gpurun_out/prof_$PREC
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --single-datapath"
-{
-echo "== kernel stats"
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_stats -o bench -- $CMD 2>&1 | grep -E '^\{|rror' | cut -c1-600
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32" "TCC_HIT_sum TCC_MISS_sum"; do
+CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eager-baseline --no-gate --single-datapath --precision $PREC $@"
+echo "# $CMD" > $OUT/command.txt
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1; echo "stats rc=$?"
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  echo "== pmc $pass"
-  timeout 600 rocprofv3 --kernel-trace --pmc $pass -f csv -d $R/gpurun_out/prof_pmc_$tag -o bench -- $CMD 2>&1 | grep -E 'rror|nvalid' | head -5
+  timeout 600 rocprofv3 --kernel-trace --pmc $pass -f csv -d $OUT/pmc_$tag -o bench -- $CMD > $OUT/pmc_$tag.log 2>&1; echo "pmc $tag rc=$?"
 done
 cd $R
-python - <<'PY'
-import csv, glob, collections, os
-for f in sorted(glob.glob("gpurun_out/prof_stats/**/*kernel_stats.csv", recursive=True)):
-    print("##", f); print(open(f).read()[:3000])
-for f in sorted(glob.glob("gpurun_out/prof_pmc_*/**/*counter_collection.csv", recursive=True)):
-    agg = collections.defaultdict(lambda: [0, 0.0])
+python - "$PREC" "$CMD" <<'PY'
+import csv, glob, collections, sys, os
+prec, cmd = sys.argv[1], sys.argv[2]
+out = f"gpurun_out/prof_{prec}"
+for f in glob.glob(f"{out}/stats/**/*kernel_stats.csv", recursive=True):
+    rows = open(f).read().splitlines()
+    keep = [rows[0]] + [r for r in rows[1:] if "nerf::" in r][:24]
+    open(f"{out}/kernel_stats.csv", "w").write("\n".join(keep) + "\n")
+    print("\n".join(keep[:12]))
+agg = collections.defaultdict(lambda: [0, 0.0])
+for f in sorted(glob.glob(f"{out}/pmc_*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        k = (row["Kernel_Name"].split("(")[0][:60], row["Counter_Name"])
+        kn = row["Kernel_Name"]
+        if "nerf::" not in kn:
+            continue
+        k = (kn.replace("void ", "").split("(")[0], row["Counter_Name"])
         agg[k][0] += 1; agg[k][1] += float(row["Counter_Value"])
-    print("##", f)
+with open(f"{out}/pmc_summary.csv", "w") as fo:
+    fo.write(f"# rocprofv3 --kernel-trace --pmc <one group per pass> -- {cmd.replace(os.getcwd() + '/', '')}\n")
+    fo.write("# mean per dispatch over the coarse (262,144 pts) and fine (786,432 pts) launches of every step; FETCH_SIZE / WRITE_SIZE in KiB;\n")
+    fo.write("# gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); TCC_EA0_WRREQ = 64-byte write requests\n")
+    fo.write("kernel,counter,dispatches,mean_per_dispatch\n")
     for (kn, cn), (n, v) in sorted(agg.items()):
-        if any(s in kn for s in ("field_", "wgrad", "expand")):
-            print(f"{kn:62s} {cn:28s} dispatches={n:4d} mean={v/n:.6g}")
+        fo.write(f"{kn},{cn},{n},{v / n:.6g}\n")
+print(open(f"{out}/pmc_summary.csv").read()[:200])
 PY
-} > $R/gpurun_out/profile.log 2>&1
-tail -150 $R/gpurun_out/profile.log
