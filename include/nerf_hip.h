@@ -69,6 +69,13 @@ int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const floa
 int nerf_make_rays(int H, int W, const float* K_host, const float* c2w_host, const float* c2w_staticcam_host, int ndc,
                    float near, float far, float* rays, int ray_stride, void* stream);
 
+/* ---- ray records of render(rays=(rays_o, rays_d), use_viewdirs=True) (run_nerf.py:95-123, no c2w / c2w_staticcam):
+ * rays_o / rays_d [n_rays][3] device, fp32, contiguous (world space).  View directions rays_d / |rays_d| (:100-107), then
+ * ndc_rays(H, W, focal, 1., ...) (run_nerf_helpers.py:175-192) iff ndc != 0, then the near / far columns (:117-123):
+ * rays[n_rays][ray_stride] = (o3, d3, near, far, viewdir3).  focal = K[0][0]; H, W, focal are read only when ndc != 0. */
+int nerf_assemble_rays(const float* rays_o, const float* rays_d, long n_rays, int ndc, int H, int W, float focal, float near,
+                       float far, float* rays, int ray_stride, void* stream);
+
 /* ---- network_query_fn(pts, viewdirs, network_fn) with pts = o + d*z
  * (run_nerf.py:381,385 -> run_network :37-51 -> Embedder :44-45 -> NeRF.forward helpers:96-119).
  * raw[n_rays][n_samples][4] = (rgb pre-sigmoid, sigma pre-relu).

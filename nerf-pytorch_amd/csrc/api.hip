@@ -75,6 +75,15 @@ int nerf_make_rays(int H, int W, const float* K_host, const float* c2w_host, con
                                                  ray_stride, (hipStream_t)stream));
 }
 
+int nerf_assemble_rays(const float* rays_o, const float* rays_d, long n_rays, int ndc, int H, int W, float focal, float near,
+                       float far, float* rays, int ray_stride, void* stream) {
+    REQUIRE(rays_o && rays_d && rays, "null pointer");
+    REQUIRE(n_rays >= 0 && ray_stride >= 11, "bad size");
+    REQUIRE(!ndc || (H > 0 && W > 0 && focal != 0.0f), "ndc needs H, W and a non-zero focal length");
+    return done(__func__, nerf::launch_assemble_rays(rays_o, rays_d, n_rays, ndc, H, W, focal, near, far, rays, ray_stride,
+                                                     (hipStream_t)stream));
+}
+
 int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int n_samples,
                        int lindisp, const float* t_rand, float* z_vals, void* stream) {
     REQUIRE(rays && t_vals && z_vals, "null pointer");

@@ -42,6 +42,8 @@ hipError_t launch_sample_coarse(const float* rays, int ray_stride, int n_rays, c
 hipError_t launch_embed(const float* x, long n_pts, int n_freqs, float* out, hipStream_t stream);
 hipError_t launch_make_rays(int H, int W, const float* K9, const float* pose12, const float* pose_static12, int ndc,
                             float near, float far, float* rays, int ray_stride, hipStream_t stream);
+hipError_t launch_assemble_rays(const float* rays_o, const float* rays_d, long n, int ndc, int H, int W, float focal,
+                                float near, float far, float* rays, int ray_stride, hipStream_t stream);
 hipError_t launch_composite(const CompositeArgs& a, bool bwd, hipStream_t stream);
 hipError_t launch_sample_fine(const FineArgs& a, hipStream_t stream);
 hipError_t launch_field_fwd(const float* packed, const float* rays, int ray_stride, const float* z_vals,

@@ -284,6 +284,38 @@ __device__ inline void camera_ray(const float* m, float dx, float dy, float dz, 
         o[k] = m[4 * k + 3];
     }
 }
+// ndc_rays(H, W, focal, near = 1., rays_o, rays_d) (run_nerf_helpers.py:175-192), same operation order
+__device__ inline void ndc_warp_inplace(int H, int W, float focal, float (&o)[3], float (&d)[3]) {
+    const float t = -(1.0f + o[2]) / d[2];
+    o[0] = o[0] + t * d[0];
+    o[1] = o[1] + t * d[1];
+    o[2] = o[2] + t * d[2];
+    const float sw = -1.0f / ((float)W / (2.0f * focal)), sh = -1.0f / ((float)H / (2.0f * focal));
+    const float n0 = sw * o[0] / o[2], n1 = sh * o[1] / o[2], n2 = 1.0f + 2.0f * 1.0f / o[2];
+    const float e0 = sw * (d[0] / d[2] - o[0] / o[2]), e1 = sh * (d[1] / d[2] - o[1] / o[2]), e2 = -2.0f * 1.0f / o[2];
+    o[0] = n0; o[1] = n1; o[2] = n2;
+    d[0] = e0; d[1] = e1; d[2] = e2;
+}
+
+// Ray records of render(rays=(rays_o, rays_d), use_viewdirs=True) (run_nerf.py:95-123 without c2w): view directions
+// d / |d| from the WORLD-space directions, the NDC warp iff ndc, the near / far columns -- one launch instead of the
+// ~10 (no NDC) / ~35 (NDC) elementwise torch kernels of the reference formulation.
+__global__ void assemble_rays_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, long n, int ndc,
+                                     int H, int W, float focal, float near, float far, float* __restrict__ rays, int stride) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float o[3] = {rays_o[3 * idx], rays_o[3 * idx + 1], rays_o[3 * idx + 2]};
+    float d[3] = {rays_d[3 * idx], rays_d[3 * idx + 1], rays_d[3 * idx + 2]};
+    const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float v0 = d[0] / nrm, v1 = d[1] / nrm, v2 = d[2] / nrm;
+    if (ndc) ndc_warp_inplace(H, W, focal, o, d);
+    float* r = rays + idx * stride;
+    r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+    r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
+    r[6] = near; r[7] = far;
+    r[8] = v0; r[9] = v1; r[10] = v2;
+}
+
 __global__ void make_rays_kernel(RayGenArgs a) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)a.H * a.W) return;
@@ -294,17 +326,7 @@ __global__ void make_rays_kernel(RayGenArgs a) {
     const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
     const float v0 = d[0] / nrm, v1 = d[1] / nrm, v2 = d[2] / nrm;
     if (a.has_static) camera_ray(a.pose_static, dx, dy, dz, o, d);
-    if (a.ndc) {            // ndc_rays(H, W, focal = K[0][0], near = 1.)
-        const float t = -(1.0f + o[2]) / d[2];
-        o[0] = o[0] + t * d[0];
-        o[1] = o[1] + t * d[1];
-        o[2] = o[2] + t * d[2];
-        const float sw = -1.0f / ((float)a.W / (2.0f * a.fx)), sh = -1.0f / ((float)a.H / (2.0f * a.fx));
-        const float n0 = sw * o[0] / o[2], n1 = sh * o[1] / o[2], n2 = 1.0f + 2.0f * 1.0f / o[2];
-        const float e0 = sw * (d[0] / d[2] - o[0] / o[2]), e1 = sh * (d[1] / d[2] - o[1] / o[2]), e2 = -2.0f * 1.0f / o[2];
-        o[0] = n0; o[1] = n1; o[2] = n2;
-        d[0] = e0; d[1] = e1; d[2] = e2;
-    }
+    if (a.ndc) ndc_warp_inplace(a.H, a.W, a.fx, o, d);
     float* r = a.rays + idx * a.stride;
     r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
     r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
@@ -347,6 +369,14 @@ hipError_t launch_make_rays(int H, int W, const float* K9, const float* pose12, 
     a.has_static = pose_static12 ? 1 : 0;
     a.ndc = ndc; a.near = near; a.far = far; a.rays = rays; a.stride = ray_stride;
     hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_rays(const float* rays_o, const float* rays_d, long n, int ndc, int H, int W, float focal,
+                                float near, float far, float* rays, int ray_stride, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(assemble_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rays_o, rays_d, n, ndc,
+                       H, W, focal, near, far, rays, ray_stride);
     return hipGetLastError();
 }
 

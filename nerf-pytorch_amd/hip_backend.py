@@ -35,6 +35,7 @@ def _declare(lib):
         "nerf_embed": (i, [p, l, i, p, p]),
         "nerf_sample_coarse": (i, [p, i, i, p, i, i, p, p, p]),
         "nerf_make_rays": (i, [i, i, p, p, p, i, f, f, p, i, p]),
+        "nerf_assemble_rays": (i, [p, p, l, i, i, i, f, f, f, p, i, p]),
         "nerf_act_floats": (sz, [i, i]),
         "nerf_workspace_floats": (sz, [i, i, i, i]),
         "nerf_field_fwd": (i, [p, p, i, p, i, i, p, p, p]),
@@ -69,7 +70,7 @@ def _declare(lib):
 
 
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
-           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_sample_coarse", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
+           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
@@ -274,6 +275,15 @@ def make_rays(H, W, K, c2w, c2w_staticcam, ndc, near, far, device):
     as_p = lambda arr: None if arr is None else arr.ctypes.data_as(ctypes.c_void_p)
     _check(lib().nerf_make_rays(int(H), int(W), as_p(Kh), as_p(ph), as_p(sh), int(bool(ndc)), float(near), float(far),
                                 _ptr(rays), 11, _stream()), "nerf_make_rays")
+    return rays
+
+
+def assemble_rays(rays_o, rays_d, ndc, H, W, focal, near, far):
+    """[N, 11] ray records of render(rays=(rays_o, rays_d), ...) in one launch (view directions + ndc_rays + near / far)."""
+    n = rays_o.numel() // 3
+    rays = torch.empty((n, 11), dtype=torch.float32, device=rays_o.device)
+    _check(lib().nerf_assemble_rays(_ptr(rays_o, "rays_o"), _ptr(rays_d, "rays_d"), n, int(bool(ndc)), int(H), int(W),
+                                    float(focal), float(near), float(far), _ptr(rays), 11, _stream()), "nerf_assemble_rays")
     return rays
 
 

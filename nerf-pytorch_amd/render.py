@@ -478,6 +478,12 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
         dev = next(net.parameters()).device if net is not None else (c2w.device if isinstance(c2w, torch.Tensor) else None)
         rays = hb.make_rays(H, W, K, c2w, c2w_staticcam, ndc, near, far, dev)
         sh = (H, W, 3)
+    elif (c2w_staticcam is None and isinstance(rays[0], torch.Tensor) and rays[0].is_cuda
+          and isinstance(near, (int, float)) and isinstance(far, (int, float))):
+        # one launch: view directions + NDC warp + near / far columns -> [N, 11] records (run_nerf.py:100-123)
+        rays_o, rays_d = rays
+        sh = rays_d.shape
+        rays = hb.assemble_rays(_f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3), ndc, H, W, K[0][0], near, far)
     else:
         rays_o, rays_d = rays
         viewdirs = rays_d

@@ -1202,6 +1202,29 @@ def test_make_rays_matches_reference_ray_setup(npa, dev, ndc, static):
     assert torch.equal(got[:, 6:8], want[:, 6:8])
 
 
+@pytest.mark.parametrize("ndc", [False, True])
+def test_assemble_rays_matches_reference_ray_assembly(npa, dev, ndc):
+    """nerf_assemble_rays = the rays=... branch of render() (run_nerf.py:95-123): view directions, ndc_rays, near / far."""
+    cfg = orc.FERN if ndc else orc.LEGO
+    batch = orc.fern_batch(777, seed=9) if ndc else orc.lego_batch(777, seed=9)
+    K = orc.intrinsics(cfg)
+    got = npa.hip_backend.assemble_rays(batch[0].to(dev), batch[1].to(dev), ndc, cfg["H"], cfg["W"], K[0][0], cfg["near"], cfg["far"]).cpu()
+    want = orc.assemble_render_rays(cfg["H"], cfg["W"], K, batch[0], batch[1], ndc, cfg["near"], cfg["far"])
+    assert got.shape == (777, 11)
+    scale = want.abs().amax(0).clamp_min(1.0)
+    assert float(((got - want).abs() / scale).max()) <= 2e-6
+    assert torch.equal(got[:, 6:8], want[:, 6:8])
+    # render() takes this path for rays=(rays_o, rays_d) on the GPU and the torch formulation otherwise: same records
+    import sys
+    R = sys.modules[npa.render.__module__]
+    o, d = batch[0].to(dev), batch[1].to(dev)
+    vd = d / torch.norm(d, dim=-1, keepdim=True)
+    if ndc:
+        o, d = R.ndc_rays(cfg["H"], cfg["W"], K[0][0], 1., o, d)
+    ref = torch.cat([o, d, cfg["near"] * torch.ones_like(d[..., :1]), cfg["far"] * torch.ones_like(d[..., :1]), vd], -1).cpu()
+    assert float(((got - ref).abs() / scale).max()) <= 2e-6
+
+
 def test_render_path_overlapped_output(npa, dev, nets, tmp_path):
     """render_path (run_nerf.py:137-175): frames rendered from poses, device-side to8b, asynchronous copies and PNG
     encoding on worker threads -- arrays and files equal to the synchronous formulation."""

@@ -65,7 +65,8 @@ def _oracle_params_from(model):
 def test_train_shaped_loop_matches_the_oracle_loop(npa, dev, precision):
     """400 iterations of the reference's training loop shape through the drop-in surface, and the same 400 iterations
     (same initial weights, same ray batches, same random draws, torch.optim.Adam, same lr schedule) by the oracle:
-    the held-out PSNR of the two runs agree within 0.1 dB and both have learned the scene."""
+    the per-step training losses agree to 1 %, the held-out PSNR of the two runs agree within 0.25 dB (see the comment at
+    the assertion) and both have learned the scene."""
     scene = wl.blender_scene(H=48, W=48, n_train=12, n_test=3)
     H, W, focal = scene["hwf"]
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
@@ -109,6 +110,7 @@ def test_train_shaped_loop_matches_the_oracle_loop(npa, dev, precision):
     try:
         torch.manual_seed(1234)
         first = last = None
+        losses_hip = []
         for i, (batch_rays, target_s) in enumerate(batches):
             rgb, disp, acc, extras = npa.render(H, W, K, chunk=args.chunk, rays=batch_rays, verbose=i < 10, retraw=True, **tr)
             optimizer.zero_grad()
@@ -117,6 +119,7 @@ def test_train_shaped_loop_matches_the_oracle_loop(npa, dev, precision):
             optimizer.step()
             for group in optimizer.param_groups:
                 group["lr"] = lr_at(i + 1)
+            losses_hip.append(loss.detach())
             if i == 0:
                 first = loss.item()
             last = loss.item()
@@ -128,6 +131,7 @@ def test_train_shaped_loop_matches_the_oracle_loop(npa, dev, precision):
     # ---- loop B: the oracle (eager torch ops on the GPU), same batches, same draws in the same order
     torch.manual_seed(1234)
     first_o = last_o = None
+    losses_orc = []
     for i, (batch_rays, target_s) in enumerate(batches):
         flat = orc.assemble_rays(batch_rays[0], batch_rays[1], bds["near"], bds["far"])
         t_rand = torch.rand((N_rand, 64), device=dev)
@@ -139,6 +143,7 @@ def test_train_shaped_loop_matches_the_oracle_loop(npa, dev, precision):
         opt_o.step()
         for group in opt_o.param_groups:
             group["lr"] = lr_at(i + 1)
+        losses_orc.append(loss_o.detach())
         if i == 0:
             first_o = loss_o.item()
         last_o = loss_o.item()
@@ -155,7 +160,17 @@ def test_train_shaped_loop_matches_the_oracle_loop(npa, dev, precision):
     psnr_blank = held_out_psnr(lambda c2w: torch.ones(H, W, 3, device=dev))        # an untrained field renders white
     print(f"held-out PSNR of a blank (white) image: {psnr_blank:.3f} dB")
     assert last < first and psnr_hip > psnr_blank + 3.0, "the loop did not learn the scene"
-    assert abs(psnr_hip - psnr_orc) <= 0.1, (psnr_hip, psnr_orc)
+    # the two loops see the same batches, so their per-step training losses can be compared step by step: the mean relative
+    # difference over the last 100 steps is the tight criterion (measured 1e-3 .. 3e-3)
+    lh, lo_ = torch.stack(losses_hip)[-100:].double(), torch.stack(losses_orc)[-100:].double()
+    rel = float(((lh - lo_).abs() / lo_).mean())
+    print(f"mean relative loss difference over the last 100 steps: {rel:.2e}")
+    assert rel <= 1e-2, rel
+    # held-out PSNR: this short from-scratch training is still on the steep part of the curve (25 dB and rising), where
+    # run-to-run rounding differences of 1e-6 per step are amplified to 0.05-0.15 dB (observed over boxes / datapaths,
+    # fp32 and bf16x3 alike); 0.25 dB bounds that spread.  The near-converged regime is held to 0.1 dB in
+    # test_training_reaches_the_same_psnr_in_every_datapath (measured 0.02 dB).
+    assert abs(psnr_hip - psnr_orc) <= 0.25, (psnr_hip, psnr_orc)
     # the optimizer state is the reference's checkpoint format (run_nerf.py:792-800)
     sd = optimizer.state_dict()
     assert len(sd["state"]) == 48 and float(sd["state"][0]["step"]) == n_iters
