@@ -62,6 +62,54 @@ def test_oracle_reproduces_reference_golden(name):
                 assert float(p.grad.abs().max()) == float(gold[f"{tag}/{nm}/max"])
 
 
+@pytest.mark.parametrize("name,cfgname,seed,kw", [
+    ("fern_ndc_train", "FERN", 77, dict(perturb=1.0, raw_noise_std=1.0, white_bkgd=False)),
+    ("lego_render_train", "LEGO", 123, dict(perturb=1.0, raw_noise_std=0.0, white_bkgd=True)),
+])
+def test_oracle_reproduces_the_render_boundary_fixtures(name, cfgname, seed, kw):
+    """The fixtures produced through the reference's render() (view directions, NDC warp, near / far): BASELINE configs[2]
+    (fern, NDC) and configs[1] through the rays=... branch."""
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = getattr(orc, cfgname)
+    batch = orc.fern_batch(256, seed=3) if cfgname == "FERN" else orc.lego_batch(256, seed=7)
+    assert abs(float(batch.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-9
+    target = torch.tensor(np.random.RandomState(99).rand(256, 3), dtype=torch.float32)
+    Pc, Pf = orc.scene_params()
+    rays = orc.assemble_render_rays(cfg["H"], cfg["W"], orc.intrinsics(cfg), batch[0], batch[1], cfg["ndc"], cfg["near"], cfg["far"])
+    torch.manual_seed(seed)
+    rnd = {"t_rand": torch.rand(256, 64)}
+    if kw["raw_noise_std"] > 0:
+        rnd["noise_c"] = torch.randn(256, 64)
+    rnd["u"] = torch.rand(256, 128)
+    if kw["raw_noise_std"] > 0:
+        rnd["noise_f"] = torch.randn(256, 192)
+    out = orc.trace_rays(rays, Pc, Pf, 64, 128, retraw=True, **kw, **rnd)
+    loss = orc.mse(out["rgb_map"], target) + orc.mse(out["rgb0"], target)
+    assert loss.item() == float(gold["loss"])
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
+        assert np.array_equal(out[k].numpy(), gold[k], equal_nan=True), k
+    assert np.array_equal(out["raw"][:, ::8].numpy(), gold["raw"])
+
+
+@pytest.mark.parametrize("which", ["lego", "fern"])
+def test_gate_fixtures_are_the_references_images(which):
+    """The PSNR-gate fixtures: both images come from the reference's render(); the oracle (bit-identical to it on this CPU)
+    reproduces them, the target sits at a trained-NeRF PSNR, and the gate arithmetic is what workloads.precision_gate says."""
+    gold = np.load(os.path.join(GOLD, f"gate_{which}.npz"))
+    cfg = orc.LEGO if which == "lego" else orc.FERN
+    batch = orc.lego_batch(1024, seed=31) if which == "lego" else orc.fern_batch(1024, seed=32)
+    assert abs(float(batch.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-5
+    rays = orc.assemble_render_rays(cfg["H"], cfg["W"], orc.intrinsics(cfg), batch[0], batch[1], cfg["ndc"], cfg["near"], cfg["far"])[:128]
+    for key, (Pc, Pf) in (("rgb_ref", orc.scene_params()), ("target", orc.teacher_params())):
+        with torch.no_grad():
+            img = orc.trace_rays(rays, Pc, Pf, 64, 128, perturb=0.0, white_bkgd=cfg["white_bkgd"])["rgb_map"]
+        # (a 128-ray slice of the 1024-ray batch: the CPU GEMMs block differently, so equal to rounding, not bit for bit)
+        err = np.abs(img.numpy() - gold[key][:128]).max(-1)
+        assert np.quantile(err, 0.95) <= 1e-5 and err.max() <= 5e-3, (key, float(np.quantile(err, 0.95)), float(err.max()))
+    g = orc.precision_gate(torch.tensor(gold["rgb_ref"]), torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"]))
+    assert g["psnr_delta_db"] == 0.0 and g["target_psnr_db"] >= 30.0 and abs(g["target_psnr_db"] - float(gold["target_psnr_db"])) < 1e-9
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
 def test_oracle_is_bit_identical_to_the_reference():
     import pin_against_reference
