@@ -40,6 +40,11 @@ N_SAMPLES, N_IMPORTANCE = 64, 128
 POINTS_PER_RAY = N_SAMPLES + N_SAMPLES + N_IMPORTANCE
 FLOP_FWD_PER_RAY = 2 * 593408 * POINTS_PER_RAY                                   # 303.82 MFLOP
 FLOP_TRAIN_PER_RAY = 2 * (593408 + 557696 + 593408) * POINTS_PER_RAY             # 893.19 MFLOP
+# the split-bf16 / mixed datapaths EXECUTE one 256x256 layer less per kernel (feature_linear folded into the view branch,
+# csrc/nerf_common.h); MFMA-issue fractions are priced on the executed work, rays/s on the reference's step
+FOLD_FLOP = 2 * 256 * 256 * POINTS_PER_RAY
+EXEC_FWD_PER_RAY = {"fp32": FLOP_FWD_PER_RAY, "bf16x3": FLOP_FWD_PER_RAY - FOLD_FLOP, "mixed": FLOP_FWD_PER_RAY - FOLD_FLOP}
+EXEC_TRAIN_PER_RAY = {"fp32": FLOP_TRAIN_PER_RAY, "bf16x3": FLOP_TRAIN_PER_RAY - 3 * FOLD_FLOP, "mixed": FLOP_TRAIN_PER_RAY - 3 * FOLD_FLOP}
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = vector rate; exact-fp32 datapath
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA; the bf16x3 datapath issues 3 MFMA FLOPs per algorithmic FLOP
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (~6.3 TB/s achievable, MI355X_MICROARCH.md)
@@ -489,7 +494,7 @@ def main():
     if rank == 0:
         total_rays = rays_per_step * world * args.steps
         value = total_rays / elapsed
-        flop_per_ray = FLOP_TRAIN_PER_RAY if args.mode == "train" else FLOP_FWD_PER_RAY
+        flop_per_ray = (EXEC_TRAIN_PER_RAY if args.mode == "train" else EXEC_FWD_PER_RAY)[args.precision]
         kernels = kernel_table(kern, args.precision)
         roofline = roofline_of(kernels)
         if roofline is not None:

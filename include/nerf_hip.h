@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 2
+#define NERF_ABI_VERSION 3
 #define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
 
@@ -159,7 +159,12 @@ int nerf_debug_pack16_table(int* out_host);
 int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
                             float* delta, void* stream);
 int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                            float* partial, float* grad, int accumulate, void* stream);
+                            float* partial, float* grad, int accumulate, const float* params, void* stream);
+/* The split-bf16 and mixed datapaths evaluate feature_linear and the feature columns of views_linears.0 as ONE layer
+ * (helpers:111-115: no activation between them): W' = Wv[:, :256] Wf, b' = Wv[:, :256] bf + bv are derived by
+ * nerf_pack_params_bf16x3.  `feature` and its delta are therefore neither computed nor saved; the weight-gradient entry
+ * points take the canonical parameter vector `params` (the one that was packed) and produce the gradients of Wf, bf and
+ * Wv[:, :256] from G = delta_hv^T h7:  dWv[:, :256] = G Wf^T + dbv bf^T,  dWf = Wv[:, :256]^T G,  dbf = Wv[:, :256]^T dbv. */
 /* ---- mixed-precision training variant: the forward is the split-bf16 datapath unchanged (same raw, bit for bit), but
  * what it saves for the backward is rounded to bf16 (same tiles, 2-byte elements), and the backward runs on single
  * bf16 MFMA products with fp32 accumulation: dgrad = W_hi^T * delta_hi, wgrad = delta_bf16^T * x_bf16 streamed straight
@@ -171,7 +176,7 @@ int nerf_field_fwd_mixed(const float* packed3, const float* rays, int ray_stride
 int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
                            float* delta, void* stream);
 int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                           float* partial, float* grad, int accumulate, void* stream);
+                           float* partial, float* grad, int accumulate, const float* params, void* stream);
 /* nerf_field_wgrad / nerf_field_wgrad_bf16x3 split into their three launches so that a profiler can bracket each:
  * phases bit 0 = the eight full-width (256x256) jobs (bf16x3: all 14 jobs), bit 1 = the six narrow jobs (fp32 datapath
  * only), bit 2 = reduction of the per-chunk partial gradients into grad.  Calling it with phases 1, 2, 4 in that order
@@ -180,7 +185,8 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
                            float* partial, float* grad, int accumulate,
                            int datapath /* 0 fp32; 1 bf16x3, act saved by nerf_field_fwd_bf16x3 (32-point tiles); 2 mixed;
                                            3 bf16x3, act saved by nerf_field_fwd16_bf16x3 (rows in 16-point tiles) */,
-                           int phases, void* stream);
+                           int phases, const float* params /* canonical parameters; may be NULL for datapath 0 */,
+                           void* stream);
 /* ---- optimizer.step() of run_nerf.py:776 for torch.optim.Adam(lr, betas=(beta1, beta2), eps) (run_nerf.py:207), fused over
  * a flat vector: params / grads / exp_avg / exp_avg_sq [n]; step = 1-based step count (bias correction). */
 int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,

@@ -196,16 +196,18 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 0, 7,
-                                                   (hipStream_t)stream));
+                                                   (hipStream_t)stream, nullptr));
 }
 
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                           float* partial, float* grad, int accumulate, int datapath, int phases, void* stream) {
+                           float* partial, float* grad, int accumulate, int datapath, int phases, const float* params,
+                           void* stream) {
     const int bf16x3 = datapath;
+    REQUIRE(datapath == 0 || params, "the split-bf16 / mixed datapaths need the canonical parameters (folded feature layer)");
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
     REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && bf16x3 >= 0 && bf16x3 <= 3, "bad size");
     return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate,
-                                                   bf16x3, phases, (hipStream_t)stream));
+                                                   bf16x3, phases, (hipStream_t)stream, params));
 }
 
 int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
@@ -229,19 +231,19 @@ int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* 
 }
 
 int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                           float* partial, float* grad, int accumulate, void* stream) {
-    REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
+                           float* partial, float* grad, int accumulate, const float* params, void* stream) {
+    REQUIRE(act && delta && d_raw && partial && grad && params, "null pointer");
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 2, 7,
-                                                   (hipStream_t)stream));
+                                                   (hipStream_t)stream, params));
 }
 
 int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                            float* partial, float* grad, int accumulate, void* stream) {
-    REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
+                            float* partial, float* grad, int accumulate, const float* params, void* stream) {
+    REQUIRE(act && delta && d_raw && partial && grad && params, "null pointer");
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 1, 7,
-                                                   (hipStream_t)stream));
+                                                   (hipStream_t)stream, params));
 }
 
 /* ---- split-bf16 ("bf16x3") datapath: same boundary, precision_mode = 1 */

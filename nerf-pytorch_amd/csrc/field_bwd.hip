@@ -716,19 +716,69 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate) {
+// fold == 0: every entry of the canonical gradient is the sum of its per-chunk partials.
+// fold == 1 (split-bf16 / mixed, feature layer folded into the view branch, nerf_common.h): the job (delta_hv, h7) left
+//   G = delta_hv^T h7 in the slot of views_linears.0.weight[:, :256]; G and this call's dbv = sum delta_hv go to
+//   `scratch` ([128][256] | [128]) for wgrad_fold_kernel, and feature_linear.{weight,bias} / Wv[:, :256] are left to it.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate,
+                                    int fold, float* __restrict__ scratch) {
+    constexpr Canon cn = canon();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N_PARAMS) return;
+    if (fold && i >= cn.wf && i < cn.bf + W) return;                    // produced by wgrad_fold_kernel (no partials exist)
     float s = 0.0f;
     for (int cix = 0; cix < n_chunks; ++cix) s += partial[(size_t)cix * N_PARAMS + i];
+    if (fold) {
+        if (i >= cn.wv && i < cn.bv) {
+            const int k = (i - cn.wv) / (W + IN_DIR), col = (i - cn.wv) % (W + IN_DIR);
+            if (col < W) { scratch[k * W + col] = s; return; }         // G[k][col]
+        } else if (i >= cn.bv && i < cn.bv + WV) {
+            scratch[WV * W + (i - cn.bv)] = s;                          // this call's dbv (grad may accumulate)
+        }
+    }
     grad[i] = accumulate ? grad[i] + s : s;
 }
 
+// Gradients of the two layers the split-bf16 datapath evaluates as one (nerf_common.h, folded feature layer), from
+// G = delta_hv^T h7 [128][256] and dbv [128]:   dWv[:, :256] = G Wf^T + dbv bf^T,  dWf = Wv[:, :256]^T G,
+// dbf = Wv[:, :256]^T dbv.   Plain fp32 FMA loops (K = 256 / 128): 16.8 MFLOP, one thread per output.
+__global__ void wgrad_fold_kernel(const float* __restrict__ params, const float* __restrict__ scratch, float* __restrict__ grad,
+                                  int accumulate) {
+    constexpr Canon cn = canon();
+    const float* G = scratch;
+    const float* dbv = scratch + WV * W;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    float v;
+    int dst;
+    if (idx < WV * W) {                                 // dWv[k][i], i < 256
+        const int k = idx / W, i = idx % W;
+        const float* wf = params + cn.wf + i * W;
+        float acc = 0.0f;
+        for (int j = 0; j < W; ++j) acc = fmaf(G[k * W + j], wf[j], acc);
+        v = fmaf(dbv[k], params[cn.bf + i], acc);
+        dst = cn.wv + k * (W + IN_DIR) + i;
+    } else if (idx < WV * W + W * W) {                  // dWf[i][j]
+        const int t = idx - WV * W, i = t / W, j = t % W;
+        float acc = 0.0f;
+        for (int k = 0; k < WV; ++k) acc = fmaf(params[cn.wv + k * (W + IN_DIR) + i], G[k * W + j], acc);
+        v = acc;
+        dst = cn.wf + t;
+    } else if (idx < WV * W + W * W + W) {              // dbf[i]
+        const int i = idx - WV * W - W * W;
+        float acc = 0.0f;
+        for (int k = 0; k < WV; ++k) acc = fmaf(params[cn.wv + k * (W + IN_DIR) + i], dbv[k], acc);
+        v = acc;
+        dst = cn.bf + i;
+    } else return;
+    grad[dst] = accumulate ? grad[dst] + v : v;
+}
+
 // ------------------------------------------------------------------ host side
-static int wgrad_chunks(long P, int* chunk_pts) {
-    // 128 point chunks: 14 jobs x 128 = 1792 = 7 x 256 workgroups (bf16x3, one workgroup per CU) and 8 x 128 = 4 x 256
-    // (fp32 full-width jobs) -> no partially filled last wave of workgroups; small inputs get >= 256-point chunks
-    long n = 128;
+static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
+    // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU): 14 jobs x 128 =
+    // 7 x 256 (fp32: 8 full-width jobs x 128 = 4 x 256); 13 jobs (folded feature layer) x 118 = 1534 of 6 x 256.
+    // Small inputs get >= 256-point chunks
+    long n = n_jobs == 13 ? 118 : 128;
     const long cap = (P + 255) / 256;
     if (n > cap) n = cap;
     if (n < 1) n = 1;
@@ -739,9 +789,10 @@ static int wgrad_chunks(long P, int* chunk_pts) {
 }
 
 size_t wgrad_partial_floats(long P) {
+    // sized for either job count, plus the scratch of the folded feature layer (G | dbv) behind the partial sums
     int pts;
-    const int n = wgrad_chunks(P, &pts);
-    return (size_t)n * N_PARAMS;
+    const int n14 = wgrad_chunks(P, &pts, 14), n13 = wgrad_chunks(P, &pts, 13);
+    return (size_t)(n14 > n13 ? n14 : n13) * N_PARAMS + N_DERIVED;
 }
 
 hipError_t launch_field_dgrad(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
@@ -800,13 +851,16 @@ __global__ void expand_dir_tiles_bf16_kernel(const float* __restrict__ dir_ray, 
 
 // phases: bit 0 = full-width jobs, bit 1 = narrow jobs, bit 2 = chunk reduction (7 = everything)
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
-                              float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream) {
+                              float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream,
+                              const float* params) {
     // bf16x3 (datapath): 0 = fp32, 1 = split-bf16 with act saved by the 32-point forward (32-point tiles), 2 = mixed-precision
     // backward (bf16 operands, one MFMA per product), 3 = split-bf16 with act saved by the 16-point forward (rows in
     // 16-point tiles, nerf_common.h row16)
     const bool mixed = bf16x3 == 2;
     const bool x_tile16 = bf16x3 == 3;
     if (x_tile16) bf16x3 = 1;
+    const bool fold = bf16x3 != 0;           // split-bf16 / mixed: feature layer folded into the view branch (nerf_common.h)
+    if (fold && !params) return hipErrorInvalidValue;
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     hipError_t e;
@@ -877,12 +931,14 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
             add(d_h[l], W, W, x_h[l - 1], W, W, 1, cn.w[l], W, cn.b[l]);
         }
     }
-    add(d_feat, W, W, x_h[D - 1], W, W, 1, cn.wf, W, cn.bf);
+    if (!fold) add(d_feat, W, W, x_h[D - 1], W, W, 1, cn.wf, W, cn.bf);
     add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);
-    add(d_hv, WV, WV, x_feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
+    // fold: G = delta_hv^T h7 lands in the slot of Wv[:, :256]; wgrad_fold_kernel turns it into dWv[:, :256], dWf, dbf
+    if (fold) add(d_hv, WV, WV, x_h[D - 1], W, W, 1, cn.wv, W + IN_DIR, cn.bv);
+    else add(d_hv, WV, WV, x_feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
     add(d_hv, WV, WV, x_dir, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
     add(d_rgb, ld_graw, 3, x_hv, WV, WV, 1, cn.wr, WV, cn.br);
-    if (nj != WG_MAX_JOBS) return hipErrorInvalidValue;
+    if (nj != (fold ? WG_MAX_JOBS - 1 : WG_MAX_JOBS)) return hipErrorInvalidValue;
     // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
     WgradArgs big{}, small{};
     int small_tiles = 0;
@@ -898,7 +954,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         }
     }
     int chunk_pts = 0;
-    const int n_chunks = wgrad_chunks(P, &chunk_pts);
+    const int n_chunks = wgrad_chunks(P, &chunk_pts, nj);
     big.P = small.P = P;
     big.chunk_pts = small.chunk_pts = chunk_pts;
     big.n_chunks = small.n_chunks = n_chunks;
@@ -939,9 +995,14 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (phases & 4)
+    if (phases & 4) {
+        float* scratch = partial + wgrad_partial_floats(P) - N_DERIVED;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, stream,
-                           (const float*)partial, n_chunks, grad, accumulate);
+                           (const float*)partial, n_chunks, grad, accumulate, fold ? 1 : 0, scratch);
+        if (fold)
+            hipLaunchKernelGGL(wgrad_fold_kernel, dim3((WV * W + W * W + W + 255) / 256), dim3(256), 0, stream,
+                               params, (const float*)scratch, grad, accumulate);
+    }
     return hipGetLastError();
 }
 
@@ -949,7 +1010,7 @@ hipError_t launch_field_bwd(const float* packed, const float* act, const float* 
                             float* delta, float* partial, float* grad, int accumulate, hipStream_t stream) {
     hipError_t e = launch_field_dgrad(packed, act, d_raw, n_rays, S, delta, stream);
     if (e != hipSuccess) return e;
-    return launch_field_wgrad(act, delta, d_raw, n_rays, S, partial, grad, accumulate, 0, 7, stream);
+    return launch_field_wgrad(act, delta, d_raw, n_rays, S, partial, grad, accumulate, 0, 7, stream, nullptr);
 }
 
 }  // namespace nerf

@@ -121,24 +121,13 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     };
 
     if constexpr (MIXED) {
-        // one 64 KiB chunk = 8 k-steps of the hi-only stream: views^T is one chunk, every 256-wide contraction two;
-        // half of the input's rows (64 stores) go out after each acquire
-        zero_acc();
+        // one 64 KiB chunk = 8 k-steps of the hi-only stream: W'^T (the folded view branch, nerf_common.h) is one chunk,
+        // every 256-wide contraction two; the feature_linear^T chunks behind it are skipped
+        load_alpha();           // acc = alpha_linear^T d_sigma; the view branch adds W'^T d_hv: delta of the trunk output
         {
-            const float* cur = ws.acquire();
+            const float* cur = ws.acquire(FOLD_SKIP_CHUNKS_BWD_HI);
             if (valid) store_tile3h<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32) + lslot, dhv);
             mma1_chunk<8, 8, 0, 0, 64>(acc, dhv, cur, lane);
-        }
-#pragma unroll
-        for (int i = 0; i < 128; ++i) d[i] = acc[i >> 4][i & 15];
-        load_alpha();
-        {
-            const float* cur = ws.template acquire<63>();
-            store_q(Q0{}, dl.feat); store_q(Q1{}, dl.feat);
-            mma1_chunk<8, 8, 0, 0, 128>(acc, d, cur, lane);
-            cur = ws.template acquire<63>();
-            store_q(Q2{}, dl.feat); store_q(Q3{}, dl.feat);
-            mma1_chunk<8, 8, 0, 64, 128>(acc, d, cur, lane);
         }
         apply_mask3<128>(d, acc, msk[D - 1]);
 #pragma unroll 1
@@ -159,33 +148,15 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     } else {
         auto mma_h = [&](auto voff, const float* cur) { mma3_chunk<8, 4, decltype(voff)::value, 128>(acc, d, cur, lane); };
 
-        // ---- views_linears.0^T (feature columns): 128 -> 256
-        zero_acc();
+        // ---- view branch folded with feature_linear (nerf_common.h): delta of the trunk output =
+        //      (alpha_linear^T d_sigma + W'^T d_hv) * relu'(h7); the feature_linear^T chunks of the stream are skipped
+        load_alpha();
         {
             const float* cur = ws.acquire();
             if (valid) store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);   // 64 stores
             mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
         }
-        mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<63>(), lane);
-#pragma unroll
-        for (int i = 0; i < 128; ++i) d[i] = acc[i >> 4][i & 15];
-
-        // ---- feature_linear^T + alpha_linear^T, ReLU mask of layer 7
-        load_alpha();
-        {
-            const float* cur = ws.acquire();
-            store_q(Q0{}, dl.feat);
-            mma_h(V0{}, cur);
-            cur = ws.template acquire<NQ>();
-            store_q(Q1{}, dl.feat);
-            mma_h(V32{}, cur);
-            cur = ws.template acquire<NQ>();
-            store_q(Q2{}, dl.feat);
-            mma_h(V64{}, cur);
-            cur = ws.template acquire<NQ>();
-            store_q(Q3{}, dl.feat);
-            mma_h(V96{}, cur);
-        }
+        mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<63>(FOLD_SKIP_CHUNKS_BWD), lane);
         apply_mask3<128>(d, acc, msk[D - 1]);
 
         // ---- trunk: delta_{l-1} = (W_l^T delta_l) * relu'(h_{l-1}),  l = 7 .. 1

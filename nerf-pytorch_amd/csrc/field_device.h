@@ -113,29 +113,38 @@ template <int MODE, int NWAVES>
 struct WeightStreamT {
     const float* next_src;
     float* lds;
-    int wave, lane, c;
+    int wave, lane;
+    int c_next;         // stream index of the chunk whose DMA is issued next
+    int buf;            // LDS buffer the chunk currently in flight lands in
     bool counted;       // wave-uniform: every lane of this wave issues the stores acquire<N> accounts for
     __device__ inline void start(const float* src, float* lds_, int wave_, int lane_, bool all_lanes_store = false) {
-        lds = lds_; wave = wave_; lane = lane_; c = 0;
+        lds = lds_; wave = wave_; lane = lane_; buf = 0;
         counted = __builtin_amdgcn_readfirstlane((int)__all(all_lanes_store)) != 0;
         const int nf = stream_chunk_words<MODE>(0);
         dma_chunk<NWAVES>(src, lds, nf, wave, lane);
         next_src = src + nf;
+        c_next = 1;
     }
     // NPEND = number of vector-memory instructions (activation stores) this wave issued AFTER the DMA of the
     // chunk being acquired: vmcnt retires in order, so waiting for "at most NPEND outstanding" guarantees the DMA
     // has landed while those stores keep draining under the next chunk's MFMAs.  Must never exceed the real count.
+    // skip_chunks (wave-uniform): full 64 KiB chunks of the stream to jump over before the prefetch issued here, i.e.
+    // the chunk AFTER the one returned is c + 1 + skip_chunks (the folded feature layer's weights stay in the stream
+    // for the benefit of one shared layout; the split-bf16 kernels never read them).
     template <int NPEND = 0>
-    __device__ inline const float* acquire() {
+    __device__ inline const float* acquire(int skip_chunks = 0) {
         // a wave with no (or predicated-off) stores has fewer entries in flight than NPEND: it must drain fully
         if (NPEND > 0 && counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPEND) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const float* cur = lds + (c & 1) * CHUNK_FLOATS;
-        const int nf = stream_chunk_words<MODE>(c + 1);
-        if (nf > 0) dma_chunk<NWAVES>(next_src, lds + ((c + 1) & 1) * CHUNK_FLOATS, nf, wave, lane);
+        const float* cur = lds + buf * CHUNK_FLOATS;
+        next_src += (size_t)skip_chunks * CHUNK_FLOATS;
+        c_next += skip_chunks;
+        const int nf = stream_chunk_words<MODE>(c_next);
+        if (nf > 0) dma_chunk<NWAVES>(next_src, lds + (buf ^ 1) * CHUNK_FLOATS, nf, wave, lane);
         next_src += nf;
-        ++c;
+        ++c_next;
+        buf ^= 1;
         return cur;
     }
 };

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
         cur = ws.template acquire<NQ>();
         save_quarter(Q2{}, prev_off, false, 0);
         mma3_chunk<8, 4, 64, 128>(acc, h, cur, lane);
-        cur = ws.template acquire<NQ>();
+        // (after layer 7 the feature_linear chunks of the stream are skipped: folded into the view branch)
+        cur = ws.template acquire<NQ>(l == D - 1 ? FOLD_SKIP_CHUNKS_FWD : 0);
         save_quarter(Q3{}, prev_off, false, 0);
         mma3_chunk<8, 4, 96, 128>(acc, h, cur, lane);
         take(true);
@@ -144,26 +145,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
         sigma = half_sum(sigma) + small_ptr(lds, SM_BALPHA)[0];
     }
 
-    // ---- feature_linear (no activation); layer 7's rows are written meanwhile
-    load_bias3<8>(acc, small_ptr(lds, SM_BFEAT), half);
-    {
-        const size_t prev_off = (size_t)(D - 1) * layer_floats;
-        const float* cur = ws.acquire();
-        save_quarter(Q0{}, prev_off, true, D - 1);
-        mma3_chunk<8, 4, 0, 128>(acc, h, cur, lane);
-        cur = ws.template acquire<SAVE ? NQ + 1 : 0>();
-        save_quarter(Q1{}, prev_off, false, 0);
-        mma3_chunk<8, 4, 32, 128>(acc, h, cur, lane);
-        cur = ws.template acquire<NQ>();
-        save_quarter(Q2{}, prev_off, false, 0);
-        mma3_chunk<8, 4, 64, 128>(acc, h, cur, lane);
-        cur = ws.template acquire<NQ>();
-        save_quarter(Q3{}, prev_off, false, 0);
-        mma3_chunk<8, 4, 96, 128>(acc, h, cur, lane);
-    }
-    take(false);
-
-    // ---- view branch: [feature, enc(dir)] -> 128, ReLU
+    // ---- view branch on the trunk output (feature_linear folded into it, nerf_common.h): [h7, enc(dir)] -> 128, ReLU
     float dv[16];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -190,13 +172,14 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_fwd3_kernel(FieldFwd3
     f32x16 av[4];
     load_bias3<4>(av, small_ptr(lds, SM_BVIEWS), half);
     {
-        const float* cur = ws.template acquire<NQ>();                      // quarter 3 of layer 7 is still draining
-        save_quarter(Q0{}, al.feat, false, 0);
-        save_quarter(Q1{}, al.feat, false, 0);
+        const size_t h7 = (size_t)(D - 1) * layer_floats;
+        const float* cur = ws.template acquire<NQ>();                      // quarter 3 of layer 6 is still draining
+        save_quarter(Q0{}, h7, true, D - 1);                               // layer 7's rows + its ReLU bitmask
+        save_quarter(Q1{}, h7, false, 0);
         mma3_chunk<4, 8, 0, 128>(av, h, cur, lane);
         cur = ws.template acquire<NQ2>();
-        save_quarter(Q2{}, al.feat, false, 0);
-        save_quarter(Q3{}, al.feat, false, 0);
+        save_quarter(Q2{}, h7, false, 0);
+        save_quarter(Q3{}, h7, false, 0);
         mma3_chunk<4, 8, 64, 128>(av, h, cur, lane);
         mma3_chunk<4, 2, 0, 16>(av, dv, ws.template acquire<NQ2>(), lane);
     }
@@ -365,7 +348,8 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
         mma16_kstep_with<8 * decltype(part)::value, 64>(acc, h, kstep_base, lane,
                                                          [&](auto gg) __attribute__((always_inline)) { if (store_rows) save_pair(part, gg, region); });
     };
-    auto contract_h = [&](const float* first, size_t region, bool store_rows) __attribute__((always_inline)) {
+    // skip_after: chunks of the stream to jump over behind this contraction's last chunk (the folded feature layer)
+    auto contract_h = [&](const float* first, size_t region, bool store_rows, int skip_after) __attribute__((always_inline)) {
         const float* cur = first;
         kstep_h(K0{}, cur, region, store_rows);
         kstep_h(K1{}, cur + KSTEP16_W16, region, store_rows);
@@ -375,7 +359,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
         cur = store_rows ? ws.template acquire<ST_C>() : ws.acquire();
         kstep_h(K4{}, cur, region, store_rows);
         kstep_h(K5{}, cur + KSTEP16_W16, region, store_rows);
-        cur = store_rows ? ws.template acquire<ST_C>() : ws.acquire();
+        cur = store_rows ? ws.template acquire<ST_C>(skip_after) : ws.acquire(skip_after);      // prefetches the chunk after this layer
         kstep_h(K6{}, cur, region, store_rows);
         kstep_h(K7{}, cur + KSTEP16_W16, region, store_rows);
     };
@@ -392,7 +376,8 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
         load_bias<16>(acc, bias + l * W, q);
         const float* cur = (l == 1) ? ws.template acquire<SAVE ? 1 : 0>() : ws.template acquire<SAVE ? ST_C + 1 : 0>();
         if (l == SKIP + 1) { mma16_chunk<16, 2, 0, 16>(acc, e, cur, lane); cur = ws.acquire(); }
-        contract_h(cur, (size_t)(l - 1) * layer_floats, SAVE != 0);
+        // after layer 7 the stream continues with the view branch: the feature_linear chunks are skipped (folded W')
+        contract_h(cur, (size_t)(l - 1) * layer_floats, SAVE != 0, l == D - 1 ? FOLD_SKIP_CHUNKS_FWD : 0);
         take(true);
         save_mask16(l);
     }
@@ -408,11 +393,8 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
         }
         sigma = quarter_sum(sigma) + small_ptr(lds, SM_BALPHA)[0];
     }
-    // ---- feature_linear 256 -> 256 (no activation); layer 7's rows are written meanwhile
-    load_bias<16>(acc, small_ptr(lds, SM_BFEAT), q);
-    contract_h(ws.template acquire<SAVE ? ST_C + 1 : 0>(), (size_t)(D - 1) * layer_floats, SAVE != 0);
-    take(false);
-    // ---- view branch: [feature, enc(dir)] 283 -> 128, ReLU: 4 + 4 k-steps of 128 outputs, then the dir k-step
+    // ---- view branch on the trunk output (feature_linear folded into it: W' = Wv[:, :256] Wf, b' in SM_BVIEWS;
+    // nerf_common.h): [h7, enc(dir)] -> 128, ReLU: 4 + 4 k-steps of 128 outputs, then the dir k-step
     float dv[8];
     {
         float v7[7];
@@ -431,12 +413,13 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     }
     f32x4 av[8];
     load_bias<8>(av, small_ptr(lds, SM_BVIEWS), q);
-    {   // the feature rows (h[]) are written under the two feature chunks of the view branch (4 k-steps of 128 outputs each)
-        const float* cur = ws.template acquire<ST_C>();
-        save_part(K0{}, al.feat); save_part(K1{}, al.feat); save_part(K2{}, al.feat); save_part(K3{}, al.feat);
+    {   // layer 7's rows (h[]) are written under the two trunk chunks of the view branch (4 k-steps of 128 outputs each)
+        const size_t h7 = (size_t)(D - 1) * layer_floats;
+        const float* cur = ws.template acquire<SAVE ? ST_C + 1 : 0>();      // pending: layer 6's last 16 rows + layer 7's mask
+        save_part(K0{}, h7); save_part(K1{}, h7); save_part(K2{}, h7); save_part(K3{}, h7);
         mma16_chunk<8, 4, 0, 64>(av, h, cur, lane);
         cur = ws.template acquire<4 * ST_K>();
-        save_part(K4{}, al.feat); save_part(K5{}, al.feat); save_part(K6{}, al.feat); save_part(K7{}, al.feat);
+        save_part(K4{}, h7); save_part(K5{}, h7); save_part(K6{}, h7); save_part(K7{}, h7);
         mma16_chunk<8, 4, 32, 64>(av, h, cur, lane);
         mma16_chunk<8, 1, 0, 8>(av, dv, ws.template acquire<4 * ST_K>(), lane);
     }

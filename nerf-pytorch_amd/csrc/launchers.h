@@ -53,7 +53,8 @@ hipError_t launch_field_bwd(const float* packed, const float* act, const float* 
 hipError_t launch_field_dgrad(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
                               float* delta, hipStream_t stream);
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
-                              float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream);
+                              float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream,
+                              const float* params);     // canonical parameters: required by the split-bf16 / mixed datapaths
 hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
                                float* delta, int mixed, hipStream_t stream);
 size_t wgrad_partial_floats(long P);

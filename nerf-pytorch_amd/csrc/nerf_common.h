@@ -217,7 +217,28 @@ constexpr int P16F_FEAT = P16F_L6 + 2 * KS16_H * KSTEP16_W16;
 constexpr int P16F_VIEWS = P16F_FEAT + KS16_H * KSTEP16_W16;
 constexpr int P16F_WORDS = P16F_VIEWS + (KS16_H + KS16_DIR) * KSTEP16_W8;
 static_assert(P16F_WORDS == P3F_END && P16F % 4 == 0, "the 16-point forward stream has the 32-point stream's size");
-constexpr int PACKED3_WORDS = P16F + P16F_WORDS;
+// ---- FOLDED FEATURE LAYER (split-bf16 and mixed datapaths).  feature_linear has no activation and feeds only
+// views_linears.0 (run_nerf_helpers.py:111-115), so the two consecutive linear maps compose:
+//     views_pre = Wv[:, :256] (Wf h7 + bf) + Wv[:, 256:] enc(dir) + bv = W' h7 + Wv[:, 256:] enc(dir) + b'
+//     W' = Wv[:, :256] Wf  [128][256],   b' = Wv[:, :256] bf + bv  [128]
+// The bf16x3 / mixed kernels evaluate the view branch directly on the trunk output with W' (one 256x256 layer less in
+// the forward, in dgrad and in the weight-gradient GEMM: -11 % MFMA work, and `feature` / its delta are neither saved
+// nor re-read: -4 KB of the 43 KB of HBM traffic per point and step).  The parameters stay Wf, bf, Wv, bv; their
+// gradients follow from ONE contraction G = delta_hv^T h7 [128][256] and dbv = sum delta_hv:
+//     dWv[:, :256] = G Wf^T + dbv bf^T,   dWf = Wv[:, :256]^T G,   dbf = Wv[:, :256]^T dbv
+// (wgrad_fold_kernel, exact fp32 FMA loops over K = 256 / 128).  W' and b' are derived at pack time (fp64 accumulation,
+// rounded once to fp32: 6e-8 relative, two orders below the datapath's product error) and appended to the packed
+// buffer; in the pack tables they appear as "canonical" indices N_PARAMS + k*256 + j and N_PARAMS + 128*256 + k.
+// The exact-fp32 datapath keeps the reference's two-layer formulation (it is the bitwise anchor).
+constexpr int DERIVED_WVF = N_PARAMS;
+constexpr int DERIVED_BV = DERIVED_WVF + WV * W;
+constexpr int N_DERIVED = WV * W + WV;                                   // 32,896 floats
+constexpr int P3_DERIVED = P16F + P16F_WORDS;                            // offset of (W', b') inside the packed3 buffer
+constexpr int FOLD_SKIP_CHUNKS_FWD = 4;                                  // feature_linear chunks skipped in the forward streams
+constexpr int FOLD_SKIP_CHUNKS_BWD = 4;                                  // feature_linear^T chunks skipped in the dgrad stream
+constexpr int FOLD_SKIP_CHUNKS_BWD_HI = 2;                               // ... in the hi-only (mixed) dgrad stream
+constexpr int PACKED3_WORDS = P3_DERIVED + N_DERIVED;
+static_assert(P3_DERIVED % 4 == 0, "alignment of the derived parameters");
 static_assert(P1B % 4 == 0 && (P1B_KSTEPS * KSTEP1_W8) % 16384 == 0, "hi-only stream: whole 64 KiB chunks");
 static_assert(P3F_VIEWS % 4096 == 0 && P3B_VIEWS % 4 == 0, "chunk alignment");
 

@@ -105,15 +105,15 @@ __host__ __device__ inline int pack3_source(int e16, int* is_lo) {
         return c.w[kind] + row * ld + h3slot(s, half, j);
     }
     if (kind == 8) return c.wf + row * W + h3slot(s, half, j);
-    if (kind == 9) {
-        if (s < KS3_H) return c.wv + row * (W + IN_DIR) + h3slot(s, half, j);
+    if (kind == 9) {        // view branch on the trunk output: folded W' (nerf_common.h)
+        if (s < KS3_H) return DERIVED_WVF + row * W + h3slot(s, half, j);
         const int d = dir3slot(8 * (s - KS3_H) + j, half);
         return d < 0 ? -1 : c.wv + row * (W + IN_DIR) + W + d;
     }
     // transposed: output row = input feature k of the layer, contraction slot = output feature n
     const int n = h3slot(s, half, j);
-    if (kind == 10) return c.wv + n * (W + IN_DIR) + row;
-    if (kind == 11) return c.wf + n * W + row;
+    if (kind == 10) return DERIVED_WVF + n * W + row;      // W'^T
+    if (kind == 11) return c.wf + n * W + row;               // (feature_linear^T: packed, skipped by the kernels)
     const int l = kind - 12;
     if (l == SKIP + 1) return c.w[l] + n * (W + IN_XYZ) + IN_XYZ + row;
     return c.w[l] + n * W + row;
@@ -123,24 +123,49 @@ __device__ inline unsigned short bf16_rne(float x) {
     return __builtin_bit_cast(unsigned short, (__bf16)x);
 }
 
-__global__ void pack3_params_kernel(const float* __restrict__ canon_params, unsigned short* __restrict__ packed16) {
+// W' = Wv[:, :256] Wf and b' = Wv[:, :256] bf + bv (nerf_common.h, folded feature layer): fp64 accumulation
+__global__ void derive_folded_kernel(const float* __restrict__ p, float* __restrict__ derived) {
+    constexpr Canon c = canon();
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N_DERIVED) return;
+    if (idx < WV * W) {
+        const int k = idx / W, j = idx % W;
+        double acc = 0.0;
+        for (int i = 0; i < W; ++i) acc += (double)p[c.wv + k * (W + IN_DIR) + i] * (double)p[c.wf + i * W + j];
+        derived[idx] = (float)acc;
+    } else {
+        const int k = idx - WV * W;
+        double acc = (double)p[c.bv + k];
+        for (int i = 0; i < W; ++i) acc += (double)p[c.wv + k * (W + IN_DIR) + i] * (double)p[c.bf + i];
+        derived[idx] = (float)acc;
+    }
+}
+__device__ inline float param_or_derived(const float* canon_params, const float* derived, int src) {
+    return src < N_PARAMS ? canon_params[src] : derived[src - N_PARAMS];
+}
+
+__global__ void pack3_params_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived,
+                                    unsigned short* __restrict__ packed16) {
     const int e16 = blockIdx.x * blockDim.x + threadIdx.x;
     if (e16 >= 2 * P3B_END) return;
     int is_lo;
     const int src = pack3_source(e16, &is_lo);
     unsigned short v = 0;
     if (src >= 0) {
-        const float x = canon_params[src];
+        const float x = param_or_derived(canon_params, derived, src);
         const unsigned short hi = bf16_rne(x);
         v = is_lo ? bf16_rne(x - __uint_as_float((unsigned)hi << 16)) : hi;
     }
     packed16[e16] = v;
 }
 
-__global__ void pack3_small_kernel(const float* __restrict__ canon_params, float* __restrict__ packed) {
+__global__ void pack3_small_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived,
+                                   float* __restrict__ packed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= PACKED_FLOATS - SM_BIAS) return;
-    const int src = pack_source(SM_BIAS + i);
+    const int idx = SM_BIAS + i;
+    if (idx >= SM_BVIEWS && idx < SM_WALPHA) { packed[P3_SMALL + i] = derived[WV * W + (idx - SM_BVIEWS)]; return; }     // b'
+    const int src = pack_source(idx);
     packed[P3_SMALL + i] = src < 0 ? 0.0f : canon_params[src];
 }
 
@@ -172,19 +197,21 @@ __host__ __device__ inline int pack16_source(int e16, int* is_lo) {
         return c.w[kind] + row * ld + hcol(8 * s + j, kq);
     }
     if (kind == 8) return c.wf + row * W + hcol(8 * s + j, kq);
-    if (s < KS16_H) return c.wv + row * (W + IN_DIR) + hcol(8 * s + j, kq);
+    if (s < KS16_H) return DERIVED_WVF + row * W + hcol(8 * s + j, kq);      // folded W'
+
     const int d = j < KS_DIR ? dirslot(j, kq) : -1;
     return d < 0 ? -1 : c.wv + row * (W + IN_DIR) + W + d;
 }
 
-__global__ void pack16_params_kernel(const float* __restrict__ canon_params, unsigned short* __restrict__ region16) {
+__global__ void pack16_params_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived,
+                                     unsigned short* __restrict__ region16) {
     const int e16 = blockIdx.x * blockDim.x + threadIdx.x;
     if (e16 >= 2 * P16F_WORDS) return;
     int is_lo;
     const int src = pack16_source(e16, &is_lo);
     unsigned short v = 0;
     if (src >= 0) {
-        const float x = canon_params[src];
+        const float x = param_or_derived(canon_params, derived, src);
         const unsigned short hi = bf16_rne(x);
         v = is_lo ? bf16_rne(x - __uint_as_float((unsigned)hi << 16)) : hi;
     }
@@ -211,13 +238,15 @@ __global__ void pack3_hi_only_kernel(float* __restrict__ packed) {
 
 hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream) {
     const int threads = 256;
+    float* derived = packed + P3_DERIVED;
+    hipLaunchKernelGGL(derive_folded_kernel, dim3((N_DERIVED + threads - 1) / threads), dim3(threads), 0, stream, canon_params, derived);
     hipLaunchKernelGGL(pack3_params_kernel, dim3((2 * P3B_END + threads - 1) / threads), dim3(threads), 0, stream,
-                       canon_params, reinterpret_cast<unsigned short*>(packed));
+                       canon_params, (const float*)derived, reinterpret_cast<unsigned short*>(packed));
     hipLaunchKernelGGL(pack3_small_kernel, dim3((PACKED_FLOATS - SM_BIAS + threads - 1) / threads), dim3(threads), 0, stream,
-                       canon_params, packed);
+                       canon_params, (const float*)derived, packed);
     hipLaunchKernelGGL(pack3_hi_only_kernel, dim3((P1B_KSTEPS * 8 * 64 + threads - 1) / threads), dim3(threads), 0, stream, packed);
     hipLaunchKernelGGL(pack16_params_kernel, dim3((2 * P16F_WORDS + threads - 1) / threads), dim3(threads), 0, stream,
-                       canon_params, reinterpret_cast<unsigned short*>(packed + P16F));
+                       canon_params, (const float*)derived, reinterpret_cast<unsigned short*>(packed + P16F));
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ from . import build as _build
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
-ABI_VERSION = 2        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
+ABI_VERSION = 3        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
 
 
 class NerfHipError(RuntimeError):
@@ -53,13 +53,13 @@ def _declare(lib):
         "nerf_field_fwd_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_debug_pack3_table": (i, [p]),
         "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, p]),
-        "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p]),
-        "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p]),
+        "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p, p]),
+        "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p, p]),
         "nerf_field_fwd_mixed": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_field_fwd16_bf16x3": (i, [p, p, i, p, i, i, p, p, i, p]),
         "nerf_debug_pack16_table": (i, [p]),
         "nerf_field_dgrad_mixed": (i, [p, p, p, i, i, p, p]),
-        "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p]),
+        "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p, p]),
         "nerf_adam_step": (i, [p, p, p, p, i, f, f, f, f, i, p]),
     }
     for name, (res, args) in sig.items():
@@ -161,6 +161,15 @@ BYTES_ACT_PER_POINT = 4 * (9 * 256 + 128 + 64 + 32) + 8 * 9  # saved activations
 BYTES_DELTA_PER_POINT = 4 * (9 * 256 + 128)             # deltas written by dgrad
 BYTES_WGRAD_BIG_PER_POINT = 4 * 8 * (256 + 256)         # each full-width job reads its delta and its input once
 BYTES_WGRAD_SMALL_PER_POINT = 4 * (2 * (256 + 64) + (4 + 256) + (128 + 256) + (128 + 32) + (4 + 128))
+# split-bf16 / mixed datapaths: feature_linear is folded into the view branch (csrc/nerf_common.h): one 256x256 layer
+# less is EXECUTED in each of the three kernels, `feature` and its delta are neither written nor re-read
+FOLD_MAC = 256 * 256
+FLOP_FWD3_PER_POINT = 2 * (593408 - FOLD_MAC)
+FLOP_DGRAD3_PER_POINT = 2 * (557696 - FOLD_MAC)
+FLOP_WGRAD3_PER_POINT = 2 * (593408 - FOLD_MAC)
+BYTES_ACT3_PER_POINT = BYTES_ACT_PER_POINT - 4 * 256
+BYTES_DELTA3_PER_POINT = BYTES_DELTA_PER_POINT - 4 * 256
+BYTES_WGRAD3_PER_POINT = BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256)
 
 
 N_PARAMS = 595844
@@ -203,13 +212,15 @@ def pack_table3():
     L = lib()
     # packed3 = (hi, lo) fragment streams | fp32 small parameters | hi-only copy of the transposed streams (136 k-steps
     # x 2048 words, csrc/nerf_common.h P1B) | 16-point forward stream (P16F); the table covers the fragment streams
-    n16 = 2 * (L.nerf_packed3_floats() - (L.nerf_packed_floats() - _small_offset()) - 136 * 2048 - P16F_WORDS)
+    n16 = 2 * (L.nerf_packed3_floats() - (L.nerf_packed_floats() - _small_offset()) - 136 * 2048 - P16F_WORDS - N_DERIVED)
     tab = np.empty(n16, dtype=np.int32)
     _check(L.nerf_debug_pack3_table(tab.ctypes.data_as(ctypes.c_void_p)), "nerf_debug_pack3_table")
     return tab
 
 
 P16F_WORDS = 593920        # csrc/nerf_common.h: the 16-point forward stream has the 32-point forward stream's size
+N_DERIVED = 128 * 256 + 128  # csrc/nerf_common.h: W' = Wv[:, :256] Wf and b' (folded feature layer), appended to packed3;
+#                              in the pack tables they are "canonical" indices N_PARAMS + k*256 + j, N_PARAMS + 32768 + k
 
 
 def pack_table16():
@@ -351,7 +362,8 @@ def _row16(f):
 
 def saved_rows(buf, P, region, precision="fp32", tile16=None):
     """Debug/test view of one saved region (activations or deltas) as a point-major [P, F] tensor.
-    region: "h0".."h7", "feat", "hv", "enc".  The fp32 datapath stores point-major rows (act_layout); the bf16x3
+    region: "h0".."h7", "feat" (fp32 datapath only: the split-bf16 / mixed datapaths fold feature_linear into the view
+    branch and never write it), "hv", "enc".  The fp32 datapath stores point-major rows (act_layout); the bf16x3
     datapath stores 32-point feature-major tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32 -- except
     the 256- / 128-wide activation rows saved by the 16-point forward (precision "bf16x3" with FWD_16PT), which are in
     16-point tiles with the row16 row order (tile16=True; default: what field_fwd recorded on the buffer)."""
@@ -384,10 +396,12 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     if act is not None:
         act.nerf_tile16 = False
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
+    if precision in ("bf16x3", "mixed"):
+        nbytes = BYTES_ACT3_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in ("bf16x3", "mixed") and FWD_16PT:
         bf16_save = int(precision == "mixed")
         label = "field_fwd16_kernel" + (("<save bf16>" if bf16_save else "<save>") if save_act else "")
-        with _timed(label, FLOP_FWD_PER_POINT * n * S, (0.5 if bf16_save and save_act else 1.0) * nbytes):
+        with _timed(label, FLOP_FWD3_PER_POINT * n * S, (0.5 if bf16_save and save_act else 1.0) * nbytes):
             _check(lib().nerf_field_fwd16_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                                  n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
                    "nerf_field_fwd16_bf16x3")
@@ -395,12 +409,12 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
             act.nerf_tile16 = True      # rows in 16-point tiles (csrc/nerf_common.h row16): the weight-gradient GEMM must know
         return raw, act
     if precision == "mixed" and save_act:
-        with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD_PER_POINT * n * S, 0.5 * nbytes):
+        with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD3_PER_POINT * n * S, 0.5 * nbytes):
             _check(lib().nerf_field_fwd_mixed(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                               n, S, _ptr(raw), _ptr(act, "act"), _stream()), "nerf_field_fwd_mixed")
         return raw, act
     if precision in ("bf16x3", "mixed"):
-        with _timed("field_fwd3_kernel<save>" if save_act else "field_fwd3_kernel", FLOP_FWD_PER_POINT * n * S, nbytes):
+        with _timed("field_fwd3_kernel<save>" if save_act else "field_fwd3_kernel", FLOP_FWD3_PER_POINT * n * S, nbytes):
             _check(lib().nerf_field_fwd_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                                n, S, _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd_bf16x3")
         return raw, act
@@ -462,29 +476,35 @@ def sample_pdf(bins, weights, n_samples, u, u_lin):
     return out
 
 
-def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32"):
+def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32", params=None):
+    """Parameter gradients of one field evaluation into the flat vector `grad`.  `params`: the canonical (flat) parameter
+    vector `packed` was made from -- required by the split-bf16 / mixed datapaths, whose folded feature layer needs Wf, bf
+    and Wv[:, :256] to turn G = delta_hv^T h7 into their gradients (csrc/nerf_common.h)."""
+    if precision != "fp32" and params is None:
+        raise NerfHipError("field_bwd: the split-bf16 / mixed datapaths need params= (the flat parameter vector)")
     n, S, _ = d_raw.shape
     L = lib()
     dev = d_raw.device
     delta = WORKSPACE.take(L.nerf_delta_floats(n, S), dev)
     partial = WORKSPACE.take(L.nerf_wgrad_partial_floats(n, S), dev)
     try:
-        return _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S)
+        return _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S, params)
     finally:        # stream-ordered: the next lease is written by kernels enqueued after these
         WORKSPACE.give(delta)
         WORKSPACE.give(partial)
 
 
-def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S):
+def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S, params):
     b3 = precision == "bf16x3"
     mx = precision == "mixed"
     P = n * S
     if mx:
-        with _timed("field_dgrad3_kernel<mixed>", FLOP_DGRAD_PER_POINT * P, 0.5 * BYTES_DELTA_PER_POINT * P):
+        with _timed("field_dgrad3_kernel<mixed>", FLOP_DGRAD3_PER_POINT * P, 0.5 * BYTES_DELTA3_PER_POINT * P):
             _check(L.nerf_field_dgrad_mixed(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
                                             _ptr(delta), _stream()), "nerf_field_dgrad_mixed")
     else:
-        with _timed("field_dgrad3_kernel" if b3 else "field_dgrad_kernel", FLOP_DGRAD_PER_POINT * P, BYTES_DELTA_PER_POINT * P):
+        with _timed("field_dgrad3_kernel" if b3 else "field_dgrad_kernel", (FLOP_DGRAD3_PER_POINT if b3 else FLOP_DGRAD_PER_POINT) * P,
+                    (BYTES_DELTA3_PER_POINT if b3 else BYTES_DELTA_PER_POINT) * P):
             if b3:
                 _check(L.nerf_field_dgrad_bf16x3(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
                                                  _ptr(delta), _stream()), "nerf_field_dgrad_bf16x3")
@@ -494,22 +514,23 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
     datapath = 2 if mx else ((3 if getattr(act, "nerf_tile16", False) else 1) if b3 else 0)
     args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),
             int(bool(accumulate)), datapath)
+    tail = (_ptr(params, "params", True), _stream())
     if TIMER is None:
-        _check(L.nerf_field_wgrad_phase(*args, 7, _stream()), "nerf_field_wgrad_phase")
+        _check(L.nerf_field_wgrad_phase(*args, 7, *tail), "nerf_field_wgrad_phase")
         return grad
     if mx:      # all 14 jobs stream bf16 operands straight into the MFMA
-        with _timed("wgrad1_kernel", FLOP_WGRAD_PER_POINT * P, 0.5 * (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT) * P):
-            _check(L.nerf_field_wgrad_phase(*args, 3, _stream()), "nerf_field_wgrad_phase")
+        with _timed("wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, 0.5 * BYTES_WGRAD3_PER_POINT * P):
+            _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
     elif b3:    # all 14 jobs (full-width and narrow) run through the masked bf16x3 tile kernel
-        with _timed("wgrad3_256_kernel", FLOP_WGRAD_PER_POINT * P, (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT) * P):
-            _check(L.nerf_field_wgrad_phase(*args, 3, _stream()), "nerf_field_wgrad_phase")
+        with _timed("wgrad3_256_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD3_PER_POINT * P):
+            _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
     else:
         with _timed("wgrad256_kernel", FLOP_WGRAD_BIG_PER_POINT * P, BYTES_WGRAD_BIG_PER_POINT * P):
-            _check(L.nerf_field_wgrad_phase(*args, 1, _stream()), "nerf_field_wgrad_phase")
+            _check(L.nerf_field_wgrad_phase(*args, 1, *tail), "nerf_field_wgrad_phase")
         with _timed("wgrad_kernel(narrow jobs)", (FLOP_WGRAD_PER_POINT - FLOP_WGRAD_BIG_PER_POINT) * P, BYTES_WGRAD_SMALL_PER_POINT * P):
-            _check(L.nerf_field_wgrad_phase(*args, 2, _stream()), "nerf_field_wgrad_phase")
+            _check(L.nerf_field_wgrad_phase(*args, 2, *tail), "nerf_field_wgrad_phase")
     with _timed("wgrad_reduce_kernel", 0.0, 4.0 * N_PARAMS * (partial.numel() // N_PARAMS + 1)):
-        _check(L.nerf_field_wgrad_phase(*args, 4, _stream()), "nerf_field_wgrad_phase")
+        _check(L.nerf_field_wgrad_phase(*args, 4, *tail), "nerf_field_wgrad_phase")
     return grad
 
 

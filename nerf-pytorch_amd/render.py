@@ -71,7 +71,8 @@ class _FieldQuery(torch.autograd.Function):
         if ctx.act is None:
             raise RuntimeError(_FREED_MSG)
         grad = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=d_raw.device)
-        hb.field_bwd(ctx.packed, ctx.act, d_raw.contiguous(), grad, accumulate=False, precision=ctx.prec)
+        hb.field_bwd(ctx.packed, ctx.act, d_raw.contiguous(), grad, accumulate=False, precision=ctx.prec,
+                     params=model.flat_params())
         hb.WORKSPACE.give(ctx.act)
         ctx.act = None      # ~10 KB per point: back to the workspace pool as soon as the gradient exists
         model.last_flat_grad = grad
@@ -181,7 +182,7 @@ class _RenderRays(torch.autograd.Function):
         grad_f = None if (ctx.same_net or not fine) else torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
         wrote = {"c": False, "f": False}
 
-        def field_grad(rays, packed, act, raw, z, noise, up, lo, hi, grad, key):
+        def field_grad(rays, model, packed, act, raw, z, noise, up, lo, hi, grad, key):
             d_rgb, d_disp, d_acc, d_raw_up = (None if g is None else g[lo:hi] for g in up)
             m = hi - lo
             if d_rgb is None and (d_disp is not None or d_acc is not None):
@@ -194,19 +195,19 @@ class _RenderRays(torch.autograd.Function):
                                            rays_d_offset=3)
                 if d_raw_up is not None:
                     d_raw += d_raw_up
-            hb.field_bwd(packed, act, d_raw, grad, wrote[key], precision=prec)
+            hb.field_bwd(packed, act, d_raw, grad, wrote[key], precision=prec, params=model.flat_params())
             wrote[key] = True
 
         def backprop(r, rays, rnd, lo, hi):
             if has(up_c):
-                field_grad(rays, r["packed_c"], r["act_c"], r["raw_c"], r["z_c"], rnd.get("noise_c"), up_c, lo, hi, grad_c, "c")
+                field_grad(rays, ctx.model_c, r["packed_c"], r["act_c"], r["raw_c"], r["z_c"], rnd.get("noise_c"), up_c, lo, hi, grad_c, "c")
             hb.WORKSPACE.give(r["act_c"])
             r["act_c"] = None
             if fine and has(up_f):
                 if ctx.same_net:
-                    field_grad(rays, r["packed_f"], r["act_f"], r["raw_f"], r["z_f"], rnd.get("noise_f"), up_f, lo, hi, grad_c, "c")
+                    field_grad(rays, ctx.model_c, r["packed_f"], r["act_f"], r["raw_f"], r["z_f"], rnd.get("noise_f"), up_f, lo, hi, grad_c, "c")
                 else:
-                    field_grad(rays, r["packed_f"], r["act_f"], r["raw_f"], r["z_f"], rnd.get("noise_f"), up_f, lo, hi, grad_f, "f")
+                    field_grad(rays, ctx.model_f, r["packed_f"], r["act_f"], r["raw_f"], r["z_f"], rnd.get("noise_f"), up_f, lo, hi, grad_f, "f")
             _release(r)
 
         if not ctx.checkpoint:

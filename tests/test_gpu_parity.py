@@ -716,7 +716,7 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     rows = lambda region: npa.hip_backend.saved_rows(act, P, region, "bf16x3", tile16=True)
     for l in range(8):
         assert maxdiff(rows(f"h{l}"), hidden[l]) <= 3e-4 * max(1.0, float(hidden[l].abs().max())), l
-    assert maxdiff(rows("feat"), feat) <= 3e-4 * max(1.0, float(feat.abs().max()))
+    # (`feature` is not saved by this datapath: feature_linear is folded into the view branch, csrc/nerf_common.h)
     assert maxdiff(rows("hv"), hv) <= 3e-4 * max(1.0, float(hv.abs().max()))
     assert maxdiff(rows("enc")[:, :63], feats[:, :63]) <= 5e-6
     # the ReLU bitmasks the backward reads must be exactly the signs of the rows saved next to them: word (layer, p,
@@ -743,7 +743,7 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     assert not getattr(act32, "nerf_tile16", False)
     act32 = act32.cpu()
     check_masks(act32, False)
-    for region in [f"h{l}" for l in range(8)] + ["feat", "hv", "enc"]:
+    for region in [f"h{l}" for l in range(8)] + ["hv", "enc"]:
         a16 = npa.hip_backend.saved_rows(act, P, region, "bf16x3", tile16=True)
         a32 = npa.hip_backend.saved_rows(act32, P, region, "bf16x3", tile16=False)
         if region == "enc":
@@ -770,7 +770,13 @@ def test_field_backward_bf16x3(npa, dev, nets, n_rays, S, fwd16, monkeypatch):
     raw, act = npa.hip_backend.field_fwd(packed3, rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
     assert bool(getattr(act, "nerf_tile16", False)) == fwd16
     grad = torch.full((595844,), float("nan"), device=dev)
-    npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), grad, accumulate=False, precision="bf16x3")
+    npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), grad, accumulate=False, precision="bf16x3", params=nf.flat_params())
+    # accumulate=True adds (also through the fold kernel that produces dWf, dbf and dWv[:, :256])
+    g2 = grad.clone()
+    npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), g2, accumulate=True, precision="bf16x3", params=nf.flat_params())
+    assert maxdiff(g2, 2 * grad) <= 1e-3 * float(grad.abs().max())
+    with pytest.raises(npa.hip_backend.NerfHipError):
+        npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), g2, accumulate=False, precision="bf16x3")       # params required
     P64 = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
     pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]
     ref = orc.query_field(P64, pts.double(), rays[:, 8:11].double())
@@ -830,7 +836,7 @@ def test_mixed_forward_is_bf16x3_and_saves_bf16(npa, dev, nets, n_rays, S):
     rawm, actm = hb.field_fwd(packed3, rays, z, save_act=True, precision="mixed")
     assert torch.equal(raw3, rawm)
     P = n_rays * S
-    for region in [f"h{l}" for l in range(8)] + ["feat", "hv"]:
+    for region in [f"h{l}" for l in range(8)] + ["hv"]:
         want = hb.saved_rows(act3, P, region, "bf16x3").bfloat16().float()
         got = hb.saved_rows(actm, P, region, "mixed")
         assert torch.equal(got, want), region
@@ -851,7 +857,7 @@ def test_mixed_backward(npa, dev, nets, n_rays, S):
     packed3 = nf.packed_params("mixed")
     raw, act = npa.hip_backend.field_fwd(packed3, rays.to(dev), z.to(dev), save_act=True, precision="mixed")
     grad = torch.full((595844,), float("nan"), device=dev)
-    npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), grad, accumulate=False, precision="mixed")
+    npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), grad, accumulate=False, precision="mixed", params=nf.flat_params())
     P64 = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
     pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]
     ref = orc.query_field(P64, pts.double(), rays[:, 8:11].double())

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/nerf_hip.h but not exported"
     assert declared == set(npa.hip_backend.EXPORTS), declared ^ set(npa.hip_backend.EXPORTS)
     L = npa.hip_backend.lib()
-    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 2 and L.nerf_param_count() == 595844
+    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 3 and L.nerf_param_count() == 595844
     assert L.nerf_packed_floats() % 4 == 0
 
 
@@ -37,7 +37,7 @@ def test_argument_errors_are_codes_not_crashes():
         Pp = (P + 31) // 32 * 32       # the bf16x3 datapath saves 32-point tiles; the sizes cover both layouts
         assert L.nerf_act_floats(n, S) == Pp * (9 * 256 + 128 + 64 + 32) + n * 32 + 9 * P * 8 + (-(Pp * 32 + n * 32) % 4) + 2048
         assert L.nerf_delta_floats(n, S) == Pp * (9 * 256 + 128 + 4) + 2048
-    assert L.nerf_wgrad_partial_floats(n, S) % 595844 == 0
+    assert (L.nerf_wgrad_partial_floats(n, S) - (128 * 256 + 128)) % 595844 == 0      # per-chunk partials + fold scratch (G | dbv)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

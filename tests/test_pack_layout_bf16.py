@@ -89,7 +89,11 @@ def test_bf16x3_table_covers_every_weight_once_per_part():
     expect = []
     for nm, off, shp in npa.hip_backend.param_table():
         if nm.endswith("weight") and not nm.startswith(("alpha", "rgb")):
-            expect.append(np.arange(off, off + shp[0] * shp[1]))
+            idx = np.arange(off, off + shp[0] * shp[1])
+            if nm == "views_linears.0.weight":      # its feature columns are folded with feature_linear into the derived W'
+                idx = idx.reshape(shp)[:, 256:].reshape(-1)
+            expect.append(idx)
+    expect.append(np.arange(595844, 595844 + 128 * 256))       # W' = Wv[:, :256] Wf (csrc/nerf_common.h, DERIVED_WVF)
     expect = np.sort(np.concatenate(expect))
     assert np.array_equal(np.sort(hi), expect) and np.array_equal(np.sort(lo), expect)
 
@@ -98,6 +102,9 @@ def test_bf16x3_forward_wave_emulation_matches_oracle():
     torch.manual_seed(0)
     Pc, _ = orc.scene_params()
     flat = np.concatenate([Pc[nm].double().numpy().reshape(-1) for nm, _ in orc.param_shapes()])
+    Wv, Wf = Pc["views_linears.0.weight"].double().numpy(), Pc["feature_linear.weight"].double().numpy()
+    b_fold = Wv[:, :256] @ Pc["feature_linear.bias"].double().numpy() + Pc["views_linears.0.bias"].double().numpy()
+    flat = np.concatenate([flat, (Wv[:, :256] @ Wf).reshape(-1), b_fold])       # derived W', b' (folded feature layer)
     tab = npa.hip_backend.pack_table3()
     w16 = np.where((tab >= 0) & (tab % 2 == 0), flat[np.maximum(tab, 0) // 2], 0.0)
     P64 = {k: v.double() for k, v in Pc.items()}
@@ -130,9 +137,8 @@ def test_bf16x3_forward_wave_emulation_matches_oracle():
     sigma = sum(h[i] * wa[32 * (i >> 4) + d32row(i & 15, HALF)] for i in range(128))
     sigma = sigma.reshape(2, 32).sum(0) + g("alpha_linear.bias")[0]
     np.testing.assert_allclose(sigma, want[:, 3].numpy(), rtol=1e-9, atol=1e-9)
-    acc = layer(w16, P3F_FEAT, 8, ksteps(h, 16), lane_bias(g("feature_linear.bias"), 8))
-    f = lane_vals_from_acc(acc, False)
-    acc = layer(w16, P3F_VIEWS, 4, ksteps(f, 16) + ksteps(dv, 2), lane_bias(g("views_linears.0.bias"), 4))
+    # the view branch runs on the trunk output with the folded W' / b' (the feature_linear region of the stream is skipped)
+    acc = layer(w16, P3F_VIEWS, 4, ksteps(h, 16) + ksteps(dv, 2), lane_bias(b_fold, 4))
     hvr = lane_vals_from_acc(acc, True)
     wr = g("rgb_linear.weight")
     for c in range(3):

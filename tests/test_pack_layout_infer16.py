@@ -81,7 +81,11 @@ def test_infer16_table_covers_every_weight_once_per_part():
     expect = []
     for nm, off, shp in npa.hip_backend.param_table():
         if nm.endswith("weight") and not nm.startswith(("alpha", "rgb")):
-            expect.append(np.arange(off, off + shp[0] * shp[1]))
+            idx = np.arange(off, off + shp[0] * shp[1])
+            if nm == "views_linears.0.weight":      # its feature columns are folded with feature_linear into the derived W'
+                idx = idx.reshape(shp)[:, 256:].reshape(-1)
+            expect.append(idx)
+    expect.append(np.arange(595844, 595844 + 128 * 256))       # W' = Wv[:, :256] Wf (csrc/nerf_common.h, DERIVED_WVF)
     expect = np.sort(np.concatenate(expect))
     assert np.array_equal(np.sort(hi), expect) and np.array_equal(np.sort(lo), expect)
 
@@ -90,6 +94,10 @@ def test_infer16_forward_wave_emulation_matches_oracle():
     torch.manual_seed(0)
     Pc, _ = orc.scene_params()
     flat = np.concatenate([Pc[nm].double().numpy().reshape(-1) for nm, _ in orc.param_shapes()])
+    # derived parameters of the folded feature layer, appended behind the canonical vector like in the pack tables
+    Wv, Wf = Pc["views_linears.0.weight"].double().numpy(), Pc["feature_linear.weight"].double().numpy()
+    b_fold = Wv[:, :256] @ Pc["feature_linear.bias"].double().numpy() + Pc["views_linears.0.bias"].double().numpy()
+    flat = np.concatenate([flat, (Wv[:, :256] @ Wf).reshape(-1), b_fold])
     tab = npa.hip_backend.pack_table16()
     w16 = np.where((tab >= 0) & (tab % 2 == 0), flat[np.maximum(tab, 0) // 2], 0.0)
     P64 = {k: v.double() for k, v in Pc.items()}
@@ -122,9 +130,8 @@ def test_infer16_forward_wave_emulation_matches_oracle():
     wa = g("alpha_linear.weight")[0]
     sigma = sum(h[i] * wa[hcol(i, Q)] for i in range(64)).reshape(4, 16).sum(0) + g("alpha_linear.bias")[0]
     np.testing.assert_allclose(sigma, want[:, 3].numpy(), rtol=1e-9, atol=1e-9)
-    acc = layer(w16, FEAT, 16, ksteps(h, 8), lane_bias(g("feature_linear.bias"), 16))
-    f = lane_vals(acc, False)
-    acc = layer(w16, VIEWS, 8, ksteps(f, 8) + ksteps(dv, 1), lane_bias(g("views_linears.0.bias"), 8))
+    # the view branch runs on the trunk output with the folded W' / b' (the feature_linear region of the stream is skipped)
+    acc = layer(w16, VIEWS, 8, ksteps(h, 8) + ksteps(dv, 1), lane_bias(b_fold, 8))
     hvr = lane_vals(acc, True)
     wr = g("rgb_linear.weight")
     for c in range(3):

@@ -30,7 +30,7 @@ if "--bwd" in sys.argv:
     g = lambda: L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), s)
     f(act.data_ptr()); print("   dgrad3 %.3f ms" % timeit(g), flush=True)
     partial = torch.empty(L.nerf_wgrad_partial_floats(N, 192), device=dev); grad = torch.empty(595844, device=dev)
-    w = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 1, ph, s)
+    w = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 3, ph, nf.flat_params().data_ptr(), s)
     print("   wgrad3 %.3f ms  (+reduce %.3f ms)" % (timeit(lambda: w(1)), timeit(lambda: w(4))), flush=True)
 
 if "--mixed" in sys.argv:
@@ -38,5 +38,5 @@ if "--mixed" in sys.argv:
     print("   mixed: fwd<save bf16> %.3f ms" % timeit(fm), flush=True)
     gm = lambda: L.nerf_field_dgrad_mixed(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), s)
     print("   mixed: dgrad %.3f ms" % timeit(gm), flush=True)
-    wm = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 2, ph, s)
+    wm = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 2, ph, nf.flat_params().data_ptr(), s)
     print("   mixed: wgrad1 %.3f ms" % timeit(lambda: wm(1)), flush=True)
