@@ -161,6 +161,12 @@ struct WgradJob {
     int tiles_k, tile_base;         // tiles of this job: [tile_base, tile_base + tiles_n*tiles_k)
     int vecA, vecB;                 // 16-byte aligned full-row loads allowed
     int b_tile16;                   // bf16x3: B is stored in 16-point tiles with the row16 row order (field_fwd16_kernel<1>)
+    // bf16x3 only: a rank-1 rider on this job's B operand.  aux != nullptr: dW_aux[f] = sum_p aux[p] * B[p][f] and
+    // db_aux = sum_p aux[p] are accumulated in fp32 by the B-staging threads from the values they convert anyway
+    // (4 FMAs per round) -- the alpha_linear weight gradient rides on the job that stages the trunk output h7, which
+    // saves its own job re-reading all of h7 (1 KB per point).  aux = row of a 4-wide 32-point tile region (d_sigma).
+    const float* aux;
+    int aux_w_off, aux_b_off;
 };
 struct WgradArgs {
     WgradJob job[WG_MAX_JOBS];
@@ -455,9 +461,20 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
         for (int r = 0; r < WG3_ROUNDS; ++r)        // row clamped into the operand: always inside the tile
             dst[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(cbase + (off0 + row_bytes * (unsigned)min(32 * r + sf0, sflast))));
     };
+    // rank-1 rider (see WgradJob::aux): the B-staging waves weight their column sums with aux[p]
+    const bool rider = sop == 1 && jb.aux != nullptr;              // wave-uniform
+    const float* aux_base = jb.aux + (p_begin >> 5) * (long)(4 * 32) + 4 * sg;
+    float aux_sum = 0.0f;
     auto swrite_from = [&](const f32x4 (&src)[WG3_ROUNDS], int buf, int st) {
         unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + sfeat * WG3_FEAT_BYTES + 8 * sg;
         const int left = nrows - st * WG_STAGE - 4 * sg;           // points of this thread's group that exist
+        f32x4 wgt = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (rider) {    // 16 bytes of a 128-byte row every thread of the stage shares (L1 hits after the first)
+            const f32x4 ds = *reinterpret_cast<const f32x4*>(aux_base + (size_t)st * (4 * 32));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wgt[e] = e < left ? ds[e] : 0.0f;
+            if (sfeat == 0) aux_sum += (wgt[0] + wgt[1]) + (wgt[2] + wgt[3]);
+        }
 #pragma unroll
         for (int r = 0; r < WG3_ROUNDS; ++r) {
             const bool fv = 32 * r + sf0 <= sflast;
@@ -468,7 +485,8 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
             split4(v, hi, lo);
             *reinterpret_cast<u32x2*>(dst + r * 32 * WG3_FEAT_BYTES) = hi;
             *reinterpret_cast<u32x2*>(dst + r * 32 * WG3_FEAT_BYTES + 64) = lo;
-            colsum[r] += (v[0] + v[1]) + (v[2] + v[3]);
+            // A operand: bias gradient (plain column sum); B operand with a rider: aux-weighted column sum
+            colsum[r] += rider ? (v[0] * wgt[0] + v[1] * wgt[1]) + (v[2] * wgt[2] + v[3] * wgt[3]) : (v[0] + v[1]) + (v[2] + v[3]);
         }
     };
     f32x16 acc[4][2];
@@ -547,7 +565,7 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
                 }
             }
         }
-    if (jb.bias_off >= 0 && sop == 0) {
+    if ((jb.bias_off >= 0 && sop == 0) || rider) {
 #pragma unroll
         for (int r = 0; r < WG3_ROUNDS; ++r) {
                 float s = colsum[r];                // sum over the 8 point groups: lane bits 0, 4, 5
@@ -555,8 +573,18 @@ __global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
                 s += __shfl_xor(s, 16);
                 s += __shfl_xor(s, 32);
                 const int f = 32 * r + sfeat;
-                if (sg == 0 && f < swidth) out[jb.bias_off + f] = s;
+                if (sg == 0 && f < swidth) {
+                    if (rider) out[jb.aux_w_off + (jb.b_tile16 ? row16_feature(f) : f)] = s;
+                    else out[jb.bias_off + f] = s;
+                }
             }
+    }
+    if (rider) {                                    // db_aux = sum_p aux[p]: the threads of staged row 0, over the point groups
+        float s = aux_sum;
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (sfeat == 0 && sg == 0) out[jb.aux_b_off] = s;
     }
 }
 
@@ -778,7 +806,7 @@ static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
     // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU): 14 jobs x 128 =
     // 7 x 256 (fp32: 8 full-width jobs x 128 = 4 x 256); 13 jobs (folded feature layer) x 118 = 1534 of 6 x 256.
     // Small inputs get >= 256-point chunks
-    long n = n_jobs == 13 ? 118 : 128;
+    long n = n_jobs == 13 ? 118 : 128;          // 12 jobs (split-bf16: alpha rides on the h7 job) x 128 = 6 x 256
     const long cap = (P + 255) / 256;
     if (n > cap) n = cap;
     if (n < 1) n = 1;
@@ -791,7 +819,7 @@ static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
 size_t wgrad_partial_floats(long P) {
     // sized for either job count, plus the scratch of the folded feature layer (G | dbv) behind the partial sums
     int pts;
-    const int n14 = wgrad_chunks(P, &pts, 14), n13 = wgrad_chunks(P, &pts, 13);
+    const int n14 = wgrad_chunks(P, &pts, 14), n13 = wgrad_chunks(P, &pts, 13);     // (12 jobs chunk like 14)
     return (size_t)(n14 > n13 ? n14 : n13) * N_PARAMS + N_DERIVED;
 }
 
@@ -932,13 +960,18 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         }
     }
     if (!fold) add(d_feat, W, W, x_h[D - 1], W, W, 1, cn.wf, W, cn.bf);
-    add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);
+    // the alpha_linear gradient (A = d_sigma, one row) is its own job except on the split-bf16 datapath, where it rides
+    // on the job that stages the trunk output h7 anyway (WgradJob::aux)
+    const bool ride_sigma = fold && !mixed;
+    if (!ride_sigma) add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);
     // fold: G = delta_hv^T h7 lands in the slot of Wv[:, :256]; wgrad_fold_kernel turns it into dWv[:, :256], dWf, dbf
-    if (fold) add(d_hv, WV, WV, x_h[D - 1], W, W, 1, cn.wv, W + IN_DIR, cn.bv);
-    else add(d_hv, WV, WV, x_feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
+    if (fold) {
+        add(d_hv, WV, WV, x_h[D - 1], W, W, 1, cn.wv, W + IN_DIR, cn.bv);
+        if (ride_sigma) { wa.job[nj - 1].aux = d_sigma; wa.job[nj - 1].aux_w_off = cn.wa; wa.job[nj - 1].aux_b_off = cn.ba; }
+    } else add(d_hv, WV, WV, x_feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
     add(d_hv, WV, WV, x_dir, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
     add(d_rgb, ld_graw, 3, x_hv, WV, WV, 1, cn.wr, WV, cn.br);
-    if (nj != (fold ? WG_MAX_JOBS - 1 : WG_MAX_JOBS)) return hipErrorInvalidValue;
+    if (nj != WG_MAX_JOBS - (fold ? 1 : 0) - (ride_sigma ? 1 : 0)) return hipErrorInvalidValue;
     // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
     WgradArgs big{}, small{};
     int small_tiles = 0;
