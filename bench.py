@@ -83,7 +83,7 @@ def relaunch_if_needed(args):
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
     import socket
-    if not args.dry_run:
+    if not args.dry_run and os.environ.get("NERF_ALLOW_SHARED_GPU") != "1":
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -326,7 +326,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run with "
                          f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` without a torchrun environment)")
-    if torch.cuda.device_count() < (world if "LOCAL_RANK" in os.environ else 1):
+    if torch.cuda.device_count() < (world if "LOCAL_RANK" in os.environ else 1) and os.environ.get("NERF_ALLOW_SHARED_GPU") != "1":
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
 
     cfg = wl.LEGO if args.config == "lego" else wl.FERN
@@ -528,7 +528,8 @@ def main():
                        "parallelism": f"ray-shard dp{world}" if args.mode != "render_only" else f"frame-parallel x{world}",
                        "boundary": "nerf_pytorch_amd.render(H, W, K, chunk, rays=batch_rays, **render_kwargs) as run_nerf.py:760"},
             "world_size": dist.get_world_size() if world > 1 else 1,
-            "collective": (f"RCCL {rccl_version()} all-reduce (torch.distributed backend nccl), 2 x 2.38 MB fp32 per step"
+            "collective": ((f"RCCL {rccl_version()} all-reduce (torch.distributed backend nccl)" if dist.get_backend() == "nccl"
+                            else f"all-reduce over torch.distributed backend {dist.get_backend()}") + ", 2 x 2.38 MB fp32 per step"
                            if world > 1 and args.mode == "train" else None),
             "precision_gate": gate, "roofline": roofline, "kernels": kernels,
         }

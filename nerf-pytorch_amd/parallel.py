@@ -27,6 +27,9 @@ def init_distributed(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    if use_cuda and os.environ.get("NERF_ALLOW_SHARED_GPU") == "1":
+        # test rigs with fewer GPUs than ranks (RCCL refuses two ranks on one device: combine with backend="gloo")
+        local = local % torch.cuda.device_count()
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
