@@ -169,7 +169,9 @@ FLOP_DGRAD3_PER_POINT = 2 * (557696 - FOLD_MAC)
 FLOP_WGRAD3_PER_POINT = 2 * (593408 - FOLD_MAC)
 BYTES_ACT3_PER_POINT = BYTES_ACT_PER_POINT - 4 * 256
 BYTES_DELTA3_PER_POINT = BYTES_DELTA_PER_POINT - 4 * 256
-BYTES_WGRAD3_PER_POINT = BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256)
+BYTES_WGRAD_MIXED_PER_POINT = 0.5 * (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256))   # 13 jobs, bf16 operands
+# bf16x3: the alpha_linear gradient rides on the staging of the (delta_hv, h7) job — h7 is not re-read for it (12 jobs)
+BYTES_WGRAD3_PER_POINT = BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256) - 4 * 256
 
 
 N_PARAMS = 595844
@@ -518,10 +520,10 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
     if TIMER is None:
         _check(L.nerf_field_wgrad_phase(*args, 7, *tail), "nerf_field_wgrad_phase")
         return grad
-    if mx:      # all 14 jobs stream bf16 operands straight into the MFMA
-        with _timed("wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, 0.5 * BYTES_WGRAD3_PER_POINT * P):
+    if mx:      # all 13 jobs stream bf16 operands straight into the MFMA
+        with _timed("wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD_MIXED_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
-    elif b3:    # all 14 jobs (full-width and narrow) run through the masked bf16x3 tile kernel
+    elif b3:    # all 12 jobs (full-width and narrow) run through the masked bf16x3 tile kernel
         with _timed("wgrad3_256_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD3_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
     else:
