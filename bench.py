@@ -378,6 +378,8 @@ def main():
             r["noise_f"] = torch.randn((n_global, N_SAMPLES + N_IMPORTANCE), device=dev, generator=strong_gen)
         return {k: v[lo:hi].contiguous() for k, v in r.items()}
 
+    sync = parallel.GradientSync([net_c, net_f]) if world > 1 else None
+
     def train_step(i):
         batch_rays, target_s = batches[i % pool], targets[i % pool]
         extra = {"randoms": strong_randoms()} if args.strong else {}
@@ -385,8 +387,9 @@ def main():
                                             **render_kwargs_train, **extra)
         optimizer.zero_grad()
         loss = npa.img2mse(rgb, target_s) + npa.img2mse(extras["rgb0"], target_s)
-        loss.backward()
-        parallel.allreduce_gradients([net_c, net_f])
+        loss.backward()       # (the coarse bucket's all-reduce starts inside, under the fine network's backward)
+        if sync is not None:
+            sync.finish()
         optimizer.step()
 
     def infer_step(i):
@@ -529,7 +532,7 @@ def main():
                        "boundary": "nerf_pytorch_amd.render(H, W, K, chunk, rays=batch_rays, **render_kwargs) as run_nerf.py:760"},
             "world_size": dist.get_world_size() if world > 1 else 1,
             "collective": ((f"RCCL {rccl_version()} all-reduce (torch.distributed backend nccl)" if dist.get_backend() == "nccl"
-                            else f"all-reduce over torch.distributed backend {dist.get_backend()}") + ", 2 x 2.38 MB fp32 per step"
+                            else f"all-reduce over torch.distributed backend {dist.get_backend()}") + ", 2 x 2.38 MB fp32 per step, the coarse network's started under the fine network's backward"
                            if world > 1 and args.mode == "train" else None),
             "precision_gate": gate, "roofline": roofline, "kernels": kernels,
         }

@@ -115,6 +115,66 @@ def allreduce_gradients(models, group=None):
             off += g.numel()
 
 
+class GradientSync:
+    """Gradient averaging overlapped with the backward pass.
+
+    The backward of render_rays produces the coarse network's flat gradient first and then runs the (3x larger) fine
+    network's backward; the two are independent.  While a GradientSync is installed, the all-reduce of a
+    network's bucket is started (async, on the communicator's own stream — RCCL orders it after the kernels already
+    enqueued) the moment render.py reports the bucket final, so the coarse bucket travels under the fine backward
+    and only the last bucket's exchange is exposed.  finish() waits for the started exchanges, reduces whatever was
+    not started (networks whose .grad already existed — accumulation reads the bucket — or that did not come through
+    the hook) the plain way, and applies the 1/G.
+
+        sync = GradientSync([model, model_fine])      # once
+        ...
+        loss.backward(); sync.finish(); optimizer.step()
+    """
+
+    def __init__(self, models, group=None):
+        from .render import GRAD_READY_HOOKS
+        self.models = [m for m in models if m is not None]
+        self.group = group
+        self.pending = {}           # id(model) -> (flat, work)
+        self._hooks = GRAD_READY_HOOKS
+        self._hooks.append(self._on_ready)
+        self.started = 0            # exchanges started under the backward (for tests / reporting)
+
+    def close(self):
+        if self._on_ready in self._hooks:
+            self._hooks.remove(self._on_ready)
+
+    def _on_ready(self, model, flat):
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        if not any(model is m for m in self.models) or id(model) in self.pending:
+            return
+        if any(p.grad is not None for p in model.parameters()):
+            return      # autograd will ADD the bucket into the existing .grad: it must not change under that read
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending[id(model)] = (flat, work)
+        self.started += 1
+
+    def finish(self):
+        world_ = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world_ == 1:
+            return
+        rest = []
+        for m in self.models:
+            started = self.pending.pop(id(m), None)
+            if started is None:
+                rest.append(m)
+                continue
+            flat, work = started
+            work.wait()
+            flat.mul_(1.0 / world_)
+            if _flat_grad_of(m) is not flat:    # autograd copied instead of adopting the views: hand the averages over
+                from .render import _grad_views
+                for p, g in zip(m.param_list(), _grad_views(m, flat)):
+                    p.grad.copy_(g)
+        allreduce_gradients(rest, group=self.group)
+
+
 def broadcast_parameters(models, src=0, group=None):
     """Make every rank start from rank `src`'s parameters (one broadcast per network)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

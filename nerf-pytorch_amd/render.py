@@ -51,6 +51,19 @@ _FREED_MSG = ("nerf-pytorch_amd: the saved activations of this render were alrea
               "backward once)")
 
 
+# Called as hook(model, flat_grad) from inside the backward pass the moment a network's flat gradient vector is final
+# (all of its kernels are enqueued on the current stream).  parallel.GradientSync uses it to start that network's
+# all-reduce while the other network's backward still runs (the coarse and fine backward are independent: the
+# reference detaches z_samples, run_nerf.py:394).
+GRAD_READY_HOOKS = []
+
+
+def _grad_ready(model, flat_grad):
+    model.last_flat_grad = flat_grad
+    for hook in GRAD_READY_HOOKS:
+        hook(model, flat_grad)
+
+
 class _FieldQuery(torch.autograd.Function):
     """raw = field(rays, z) for explicit rays/depths; gradients w.r.t. the parameters only."""
 
@@ -75,7 +88,7 @@ class _FieldQuery(torch.autograd.Function):
                      params=model.flat_params())
         hb.WORKSPACE.give(ctx.act)
         ctx.act = None      # ~10 KB per point: back to the workspace pool as soon as the gradient exists
-        model.last_flat_grad = grad
+        _grad_ready(model, grad)
         return (None, None, None, None) + _grad_views(model, grad)
 
 
@@ -198,16 +211,24 @@ class _RenderRays(torch.autograd.Function):
             hb.field_bwd(packed, act, d_raw, grad, wrote[key], precision=prec, params=model.flat_params())
             wrote[key] = True
 
-        def backprop(r, rays, rnd, lo, hi):
+        shared = ctx.same_net and fine and has(up_f)      # the fine pass adds into the coarse network's gradient
+
+        def backprop(r, rays, rnd, lo, hi, last=True):
             if has(up_c):
                 field_grad(rays, ctx.model_c, r["packed_c"], r["act_c"], r["raw_c"], r["z_c"], rnd.get("noise_c"), up_c, lo, hi, grad_c, "c")
+                if last and not shared:     # final: its all-reduce may start under the fine network's backward
+                    _grad_ready(ctx.model_c, grad_c)
             hb.WORKSPACE.give(r["act_c"])
             r["act_c"] = None
             if fine and has(up_f):
                 if ctx.same_net:
                     field_grad(rays, ctx.model_c, r["packed_f"], r["act_f"], r["raw_f"], r["z_f"], rnd.get("noise_f"), up_f, lo, hi, grad_c, "c")
+                    if last:
+                        _grad_ready(ctx.model_c, grad_c)
                 else:
                     field_grad(rays, ctx.model_f, r["packed_f"], r["act_f"], r["raw_f"], r["z_f"], rnd.get("noise_f"), up_f, lo, hi, grad_f, "f")
+                    if last:
+                        _grad_ready(ctx.model_f, grad_f)
             _release(r)
 
         if not ctx.checkpoint:
@@ -218,18 +239,16 @@ class _RenderRays(torch.autograd.Function):
                 hi = min(lo + step, n_all)
                 rays = rays_all[lo:hi]
                 rnd = {k: v[lo:hi] for k, v in rnd_all.items()}
-                backprop(_field_pass(cfg, rays, rnd, ctx.model_c, ctx.model_f, save=True), rays, rnd, lo, hi)
+                backprop(_field_pass(cfg, rays, rnd, ctx.model_c, ctx.model_f, save=True), rays, rnd, lo, hi, last=hi == n_all)
         ctx.saved = None
         ctx.consumed = True
         out_c = none_c
         if wrote["c"]:
-            ctx.model_c.last_flat_grad = grad_c
             out_c = _grad_views(ctx.model_c, grad_c)
         if ctx.same_net:
             return (None,) * n_lead + out_c
         out_f = none_c
         if wrote["f"]:
-            ctx.model_f.last_flat_grad = grad_f
             out_f = _grad_views(ctx.model_f, grad_f)
         return (None,) * n_lead + out_c + out_f
 

@@ -64,6 +64,31 @@ def _worker(rank, world, port, q):
     parallel.allreduce_gradients([net])
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
     opt.step()
+    # GradientSync: bucket A is reported final while its .grads do not exist yet -> its exchange starts right there
+    # (under the rest of the backward); bucket B's .grads exist (accumulation) -> exchanged in finish(); C copied by autograd
+    import sys
+    render = sys.modules[parallel.__name__.rsplit(".", 1)[0] + ".render"]     # (the package attribute `render` is the function)
+    nets = [npa.NeRF(**kw) for _ in range(3)]
+    sync = parallel.GradientSync(nets)
+    fl = [torch.full((npa.hip_backend.N_PARAMS,), float(10 * (i + 1) + rank)) for i in range(3)]
+    table = npa.hip_backend.param_table()
+
+    def install(net, flat, views=True):
+        for nm, off, shape in table:
+            v = flat[off:off + int(np.prod(shape))].view(shape)
+            dict(net.named_parameters())[nm].grad = v if views else v.clone()
+    install(nets[1], fl[1])
+    for i in (0, 1, 2):
+        render._grad_ready(nets[i], fl[i])
+    assert sync.started == 2 and set(sync.pending) == {id(nets[0]), id(nets[2])}
+    install(nets[0], fl[0])
+    install(nets[2], fl[2], views=False)
+    sync.finish()
+    sync.close()
+    assert render.GRAD_READY_HOOKS == [] and not sync.pending
+    for i in range(3):          # mean over the two ranks of 10(i+1) + rank
+        want = 10.0 * (i + 1) + 0.5
+        assert all(bool((p.grad == want).all()) for p in nets[i].parameters()), i
     frames = parallel.frames_of_rank(7)
     got = parallel.gather_frames([np.full((2, 2), i) for i in frames], frames, 7)
     q.put((rank, flat.numpy().copy(), net.flat_params().detach().numpy().copy(), {k: v.numpy().copy() for k, v in P0.items()},

@@ -64,8 +64,12 @@ def _worker(rank, world, port, q):
         full = torch.cat([nc.last_flat_grad, nf.last_flat_grad]).cpu().numpy().copy()
     sh_rays, sh_tgt = parallel.shard_rays(batch, target)
     lo, hi = parallel.shard_slice(n, rank, world)
+    sync = parallel.GradientSync([nc, nf])                       # the coarse bucket's exchange starts under the fine backward
     grads(sh_rays.contiguous(), sh_tgt, {k: v[lo:hi].contiguous() for k, v in rnd_all.items()})
-    parallel.allreduce_gradients([nc, nf])
+    assert sync.started == 2, sync.started
+    sync.finish()
+    sync.close()
+    assert parallel._flat_grad_of(nc) is nc.last_flat_grad and parallel._flat_grad_of(nf) is nf.last_flat_grad
     avg = torch.cat([nc.last_flat_grad, nf.last_flat_grad]).cpu().numpy().copy()
     opt = npa.FlatAdam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4)
     opt.step()
