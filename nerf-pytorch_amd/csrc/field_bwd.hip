@@ -803,10 +803,12 @@ __global__ void wgrad_fold_kernel(const float* __restrict__ params, const float*
 
 // ------------------------------------------------------------------ host side
 static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
-    // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU): 14 jobs x 128 =
-    // 7 x 256 (fp32: 8 full-width jobs x 128 = 4 x 256); 13 jobs (folded feature layer) x 118 = 1534 of 6 x 256.
-    // Small inputs get >= 256-point chunks
-    long n = n_jobs == 13 ? 118 : 128;          // 12 jobs (split-bf16: alpha rides on the h7 job) x 128 = 6 x 256
+    // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU).  fp32: 14 jobs x
+    // 128 = 7 x 256 (the 8 full-width jobs x 128 = 4 x 256).  Split-bf16 (12 jobs: folded feature layer, alpha rides on
+    // the h7 job): 12 x 64 = 3 x 256; mixed (13 jobs): 13 x 59 = 767.  (Measured for the 12 jobs: 64 and 128 chunks run
+    // the GEMM in the same time, 96 — a partial last round — is 10 % slower, and the partial-sum traffic of the
+    // deterministic reduction halves with 64: 0.113 -> 0.057 ms per launch.)  Small inputs get >= 256-point chunks.
+    long n = n_jobs == 14 ? 128 : (n_jobs == 13 ? 59 : 64);
     const long cap = (P + 255) / 256;
     if (n > cap) n = cap;
     if (n < 1) n = 1;
@@ -819,7 +821,7 @@ static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
 size_t wgrad_partial_floats(long P) {
     // sized for either job count, plus the scratch of the folded feature layer (G | dbv) behind the partial sums
     int pts;
-    const int n14 = wgrad_chunks(P, &pts, 14), n13 = wgrad_chunks(P, &pts, 13);     // (12 jobs chunk like 14)
+    const int n14 = wgrad_chunks(P, &pts, 14), n13 = wgrad_chunks(P, &pts, 13);     // (12 jobs: 64 chunks)
     return (size_t)(n14 > n13 ? n14 : n13) * N_PARAMS + N_DERIVED;
 }
 

@@ -531,7 +531,9 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
             _check(L.nerf_field_wgrad_phase(*args, 1, *tail), "nerf_field_wgrad_phase")
         with _timed("wgrad_kernel(narrow jobs)", (FLOP_WGRAD_PER_POINT - FLOP_WGRAD_BIG_PER_POINT) * P, BYTES_WGRAD_SMALL_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 2, *tail), "nerf_field_wgrad_phase")
-    with _timed("wgrad_reduce_kernel", 0.0, 4.0 * N_PARAMS * (partial.numel() // N_PARAMS + 1)):
+    # chunks of partial sums the reduction reads (csrc/field_bwd.hip, wgrad_chunks)
+    n_chunks = min(64 if b3 else (59 if mx else 128), max(1, (P + 255) // 256))
+    with _timed("wgrad_reduce_kernel", 0.0, 4.0 * N_PARAMS * (n_chunks + 1)):
         _check(L.nerf_field_wgrad_phase(*args, 4, *tail), "nerf_field_wgrad_phase")
     return grad
 

@@ -22,7 +22,40 @@ VARIANTS = {
     "norows": lambda d: patch(os.path.join(d, "field_fwd_bf16.hip"), "        if (valid) {\n#pragma unroll\n            for (int nb = 0; nb < 16; ++nb)\n#pragma unroll\n                for (int r = 0; r < 4; ++r) store_val(region, W,", "        if (false) {\n#pragma unroll\n            for (int nb = 0; nb < 16; ++nb)\n#pragma unroll\n                for (int r = 0; r < 4; ++r) store_val(region, W,"),
     # dgrad: no delta stores
     "dgrad_nostore": lambda d: patch(os.path.join(d, "field_bwd_bf16.hip"), "    auto store_q = [&](auto part, size_t off) {\n        if (!valid) return;", "    auto store_q = [&](auto part, size_t off) {\n        return;"),
+    # weight-gradient GEMM: the two waves of a SIMD in anti-phase (waves 0-3 MFMA then stage, waves 4-7 stage then MFMA)
+    "wg_anti": lambda d: wg_anti(d, prio=False),
+    "wg_anti_prio": lambda d: wg_anti(d, prio=True),
+    # s_setprio around the MFMA phase / around the staging phase
+    "wg_prio_mfma": lambda d: wg_prio(d, True),
+    "wg_prio_stage": lambda d: wg_prio(d, False),
 }
+
+def wg_anti(d, prio):
+    # (an if/else with both orders spills 1.6k VGPRs; two predicated copies of the staging around one compute do not)
+    f = os.path.join(d, "field_bwd.hip")
+    hi, lo = ("__builtin_amdgcn_s_setprio(1); ", " __builtin_amdgcn_s_setprio(0);") if prio else ("", "")
+    patch(f, """        compute(0);
+        if (st + 1 < n_stages) swrite_from(rv, 1, st + 1);
+        __syncthreads();""", f"""        if (sop != 0 && st + 1 < n_stages) {{ {hi}swrite_from(rv, 1, st + 1);{lo} }}
+        compute(0);
+        if (sop == 0 && st + 1 < n_stages) {{ {hi}swrite_from(rv, 1, st + 1);{lo} }}
+        __syncthreads();""")
+    patch(f, """        compute(1);
+        if (st + 2 < n_stages) swrite_from(rw, 0, st + 2);
+        __syncthreads();""", f"""        if (sop != 0 && st + 2 < n_stages) {{ {hi}swrite_from(rw, 0, st + 2);{lo} }}
+        compute(1);
+        if (sop == 0 && st + 2 < n_stages) {{ {hi}swrite_from(rw, 0, st + 2);{lo} }}
+        __syncthreads();""")
+
+def wg_prio(d, mfma):
+    f = os.path.join(d, "field_bwd.hip")
+    a, b = ("1", "0") if mfma else ("0", "1")
+    patch(f, """        compute(0);
+        if (st + 1 < n_stages) swrite_from(rv, 1, st + 1);""", f"""        __builtin_amdgcn_s_setprio({a}); compute(0); __builtin_amdgcn_s_setprio({b});
+        if (st + 1 < n_stages) swrite_from(rv, 1, st + 1);""")
+    patch(f, """        compute(1);
+        if (st + 2 < n_stages) swrite_from(rw, 0, st + 2);""", f"""        __builtin_amdgcn_s_setprio({a}); compute(1); __builtin_amdgcn_s_setprio({b});
+        if (st + 2 < n_stages) swrite_from(rw, 0, st + 2);""")
 
 def main(names):
     inc = os.path.join(ROOT, "include")
