@@ -48,7 +48,9 @@ EXEC_TRAIN_PER_RAY = {"fp32": FLOP_TRAIN_PER_RAY, "bf16x3": FLOP_TRAIN_PER_RAY -
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = vector rate; exact-fp32 datapath
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA; the bf16x3 datapath issues 3 MFMA FLOPs per algorithmic FLOP
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (~6.3 TB/s achievable, MI355X_MICROARCH.md)
-DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products, f32 accumulate/activations/gradients)",
+DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products W_hi x_hi + W_hi x_lo + W_lo x_hi in the forward and the delta chain, f32 "
+                                        "accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are stored as "
+                                        "bf16 and multiplied exactly, f32 accumulate — NERF_WGRAD_OPERANDS=fp32 stores and splits fp32)",
               "mixed": "bf16x3 forward + bf16 backward (mixed-precision training option)"}
 
 
@@ -235,10 +237,14 @@ def pmc_traffic(kernel_name, precision):
         tmpl = base.split("<")[1].split(">")[0] if "<" in base else ""
         if base.split("<")[0].split("(")[0] != key:
             continue
-        if key in ("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd_kernel") and (tmpl not in ("0", "false", "")) != ("<save" in kernel_name):
-            continue
-        if key == "field_dgrad3_kernel" and (tmpl in ("1", "true")) != ("<mixed>" in kernel_name):
-            continue
+        if key in ("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd_kernel"):
+            want = "2" if "<save bf16>" in kernel_name else ("1" if "<save" in kernel_name else "0")
+            if {"false": "0", "true": "1", "": "0"}.get(tmpl, tmpl) != want:
+                continue
+        if key == "field_dgrad3_kernel":
+            want = "1" if "<mixed>" in kernel_name else ("2" if "<bf16 out>" in kernel_name else "0")
+            if {"false": "0", "true": "1", "": "0"}.get(tmpl, tmpl) != want:
+                continue
         if cn == "FETCH_SIZE":
             fetch = float(val)
         elif cn == "WRITE_SIZE":
@@ -508,9 +514,18 @@ def main():
                 roofline["traffic_note"] = (f"bytes per launch (mean over coarse+fine launches) from {src} (rocprofv3 --pmc passes of this "
                                             f"command): 2*FETCH_SIZE + WRITE_SIZE; algorithmic bytes per launch here: "
                                             f"{k['algorithmic_GBps'] * 1e9 * k['avg_ms'] * 1e-3:.4g}")
-            issued = 1.0 if args.precision == "fp32" else 3.0
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-            roofline["whole_step_mfma_frac"] = value * flop_per_ray * issued / world / 1e12 / peak
+            # MFMA FLOPs issued per executed FLOP: fp32 1; split-bf16 3 — except a weight-gradient GEMM on bf16-stored
+            # operands (1 MFMA per product): bf16x3 with bf16 operand storage (default) and mixed (whose dgrad is 1 too)
+            issued_flop = flop_per_ray * (1.0 if args.precision == "fp32" else 3.0)
+            if args.mode == "train" and args.precision != "fp32":
+                third = (FLOP_TRAIN_PER_RAY - 3 * FOLD_FLOP) * (593408 - 65536) / (593408 + 557696 + 593408 - 3 * 65536)   # wgrad share
+                dg = (FLOP_TRAIN_PER_RAY - 3 * FOLD_FLOP) * (557696 - 65536) / (593408 + 557696 + 593408 - 3 * 65536)      # dgrad share
+                if args.precision == "mixed":
+                    issued_flop -= 2.0 * (third + dg)
+                elif hb.WGRAD_OPERANDS == "bf16":
+                    issued_flop -= 2.0 * third
+            roofline["whole_step_mfma_frac"] = value * issued_flop / world / 1e12 / peak
         workload = {
             "train": f"{args.config}-like {W}x{H}, N_rand={n} rays/GPU x (64 coarse + 128 fine) samples, two 8x256 networks, perturb=1, "
                      + ("white_bkgd" if cfg["white_bkgd"] else f"NDC rays near=0 far=1, raw_noise_std={cfg['raw_noise_std']}")

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 3
+#define NERF_ABI_VERSION 4
 #define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
 
@@ -155,9 +155,13 @@ int nerf_debug_pack16_table(int* out_host);
 /* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  dgrad also leaves a tiled
  * copy of d_raw inside delta, which is what wgrad contracts with: nerf_field_wgrad_bf16x3 must be given the delta
  * buffer of nerf_field_dgrad_bf16x3 for the same d_raw (its own d_raw argument is not read).  All 14 weight-gradient
- * jobs, full-width and narrow, run on the split-bf16 MFMA kernel. */
+ * jobs, full-width and narrow, run on the split-bf16 MFMA kernel.
+ * delta_bf16 != 0: the chain is computed exactly as with 0 (3-term products, fp32 deltas in registers), but the deltas
+ * are WRITTEN rounded to bf16 (same tiles, 2-byte elements) for the bf16-operand weight-gradient GEMM: pair it with an
+ * act buffer saved with bf16_save != 0 and with nerf_field_wgrad_phase(datapath = 2).  Only the operands of the
+ * weight-gradient contraction are rounded (zero-mean, averaged over all points), never the delta chain. */
 int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
-                            float* delta, void* stream);
+                            float* delta, int delta_bf16, void* stream);
 int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                             float* partial, float* grad, int accumulate, const float* params, void* stream);
 /* The split-bf16 and mixed datapaths evaluate feature_linear and the feature columns of views_linears.0 as ONE layer

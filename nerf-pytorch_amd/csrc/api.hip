@@ -211,13 +211,13 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
 }
 
 int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
-                            float* delta, void* stream) {
+                            float* delta, int delta_bf16, void* stream) {
     REQUIRE(packed3 && act && d_raw && delta, "null pointer");
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
             "packed/act/d_raw/delta must be 16-byte aligned");
-    return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, 0, (hipStream_t)stream));
+    return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, delta_bf16 ? 2 : 0, (hipStream_t)stream));
 }
 
 int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,

@@ -25,10 +25,17 @@ __device__ inline void apply_mask3(float (&d)[NV], const f32x16* acc, u32x4 m) {
     }
 }
 
-// MIXED = mixed-precision backward: single bf16 product W_hi^T * delta_hi per term (the lo fragments of the same
-// weight stream are skipped) and bf16 deltas in HBM; otherwise the split-bf16 (3-term) chain with fp32 deltas
-template <bool MIXED>
+// MODE 0: the split-bf16 (3-term) chain, fp32 deltas in HBM (operands of wgrad3_256_kernel).
+// MODE 2: the same chain — every delta is computed exactly as in mode 0 — but what is WRITTEN for the weight-gradient
+//         GEMM is rounded to bf16 (RNE; same tiles, 2-byte elements: operands of wgrad1_kernel).  The rounding touches
+//         only the GEMM operands, never the chain: zero-mean, 2^-9 relative per element, averaged over the ~10^6 points
+//         of the contraction (1e-4 of |dW| at 131 k points, falling with 1/sqrt(points)).
+// MODE 1: mixed-precision backward: single bf16 product W_hi^T * delta_hi per term (the lo fragments of the same weight
+//         stream are skipped) and bf16 deltas in HBM — here the rounding IS in the chain.
+template <int MODE>
 __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBwd3Args a) {
+    constexpr bool MIXED = MODE == 1;
+    constexpr bool OUT16 = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     const f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);       // (d_rgb3, d_sigma)
     if (valid) {        // tile-major copy of d_raw: the A operand of the rgb_linear / alpha_linear weight gradients
         const size_t goff = tile * (4 * 32) + half * 64 + (lane & 31);
-        if (MIXED) {
+        if (OUT16) {
             __bf16* gt = reinterpret_cast<__bf16*>(a.delta + dl.graw) + goff;
             nt_store(gt, (__bf16)(half ? g[2] : g[0]));
             nt_store(gt + 32, (__bf16)(half ? g[3] : g[1]));
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
     auto store_q = [&](auto part, size_t off) {
         if (!valid) return;
-        if (MIXED) store_tile3h<2 * decltype(part)::value, 2>(reinterpret_cast<__bf16*>(a.delta + off) + tile * (W * 32) + lslot, d);
+        if (OUT16) store_tile3h<2 * decltype(part)::value, 2>(reinterpret_cast<__bf16*>(a.delta + off) + tile * (W * 32) + lslot, d);
         else store_tile3<2 * decltype(part)::value, 2>(a.delta + off + tile * (W * 32) + lslot, d);
     };
     using V0 = std::integral_constant<int, 0>; using V32 = std::integral_constant<int, 32>;
@@ -153,7 +160,10 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         load_alpha();
         {
             const float* cur = ws.acquire();
-            if (valid) store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);   // 64 stores
+            if (valid) {                                                                        // 64 stores
+                if (OUT16) store_tile3h<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32) + lslot, dhv);
+                else store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);
+            }
             mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
         }
         mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<63>(FOLD_SKIP_CHUNKS_BWD), lane);
@@ -183,27 +193,30 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         }
     }
     if (valid) {                                                           // dl.h[0]
-        if (MIXED) store_tile3h<0, 8>(reinterpret_cast<__bf16*>(a.delta) + tile * (W * 32) + lslot, d);
+        if (OUT16) store_tile3h<0, 8>(reinterpret_cast<__bf16*>(a.delta) + tile * (W * 32) + lslot, d);
         else store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);
     }
 }
 
 hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
-                               float* delta, int mixed, hipStream_t stream) {
+                               float* delta, int mode, hipStream_t stream) {
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)field_dgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        e = hipFuncSetAttribute((const void*)field_dgrad3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)field_dgrad3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FIELD_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     FieldBwd3Args ba{packed3, act, d_raw, delta, n_rays, S};
     const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
-    if (mixed) hipLaunchKernelGGL(field_dgrad3_kernel<true>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
-    else hipLaunchKernelGGL(field_dgrad3_kernel<false>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
+    if (mode == 1) hipLaunchKernelGGL(field_dgrad3_kernel<1>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
+    else if (mode == 2) hipLaunchKernelGGL(field_dgrad3_kernel<2>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
+    else hipLaunchKernelGGL(field_dgrad3_kernel<0>, dim3(blocks), dim3(FIELD3_WAVES * 64), FIELD_LDS_FLOATS * 4, stream, ba);
     return hipGetLastError();
 }
 

@@ -56,7 +56,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
                               float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream,
                               const float* params);     // canonical parameters: required by the split-bf16 / mixed datapaths
 hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
-                               float* delta, int mixed, hipStream_t stream);
+                               float* delta, int mode /* 0 x3 chain + fp32 deltas, 1 mixed, 2 x3 chain + bf16 deltas */, hipStream_t stream);
 size_t wgrad_partial_floats(long P);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2, float eps, int step,
                        hipStream_t stream);

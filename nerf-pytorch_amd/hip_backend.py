@@ -15,7 +15,7 @@ from . import build as _build
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
-ABI_VERSION = 3        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
+ABI_VERSION = 4        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
 
 
 class NerfHipError(RuntimeError):
@@ -52,7 +52,7 @@ def _declare(lib):
         "nerf_pack_params_bf16x3": (i, [p, p, p]),
         "nerf_field_fwd_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_debug_pack3_table": (i, [p]),
-        "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, p]),
+        "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, i, p]),
         "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p, p]),
         "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p, p]),
         "nerf_field_fwd_mixed": (i, [p, p, i, p, i, i, p, p, p]),
@@ -233,6 +233,23 @@ def pack_table16():
     return tab
 
 
+# Storage of the operands of the weight-gradient GEMM (saved activations, deltas) on the bf16x3 datapath:
+#   "bf16" (default): written once, rounded to bf16 (RNE), contracted by the bf16 streaming GEMM (wgrad1_kernel, exact
+#           products, fp32 accumulation).  The forward and the delta chain are the 3-term split-bf16 arithmetic either
+#           way — only the GEMM's operands are rounded: zero-mean 2^-9 per element, averaged over the ~10^6 points of the
+#           contraction (1e-4 of |dW| at 131 k points, ~4e-5 at the 786 k points of a fine pass: below the datapath's
+#           own error against fp64; tests/test_gpu_parity.py test_bf16_operand_storage_*).  Half the HBM bytes of the
+#           training step.
+#   "fp32": fp32 tiles, split into (hi, lo) by the GEMM itself (wgrad3_256_kernel, 3 MFMAs per product).
+WGRAD_OPERANDS = __import__("os").environ.get("NERF_WGRAD_OPERANDS", "bf16")
+if WGRAD_OPERANDS not in ("bf16", "fp32"):
+    raise ValueError("NERF_WGRAD_OPERANDS must be 'bf16' or 'fp32'")
+
+
+def _bf16_operands(precision):
+    return precision == "mixed" or (precision == "bf16x3" and WGRAD_OPERANDS == "bf16")
+
+
 # the bf16x3 / mixed forward runs the 16-point-per-wave kernel (2 waves / SIMD); "0" selects the 32-point kernel
 # (1 wave / SIMD), which writes the same save buffer and agrees to rounding
 FWD_16PT = __import__("os").environ.get("NERF_FWD16", "1") != "0"
@@ -362,16 +379,19 @@ def _row16(f):
     return (f & ~15) + 8 * ((f >> 3) & 1) + 2 * (f & 3) + ((f >> 2) & 1)
 
 
-def saved_rows(buf, P, region, precision="fp32", tile16=None):
+def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
     """Debug/test view of one saved region (activations or deltas) as a point-major [P, F] tensor.
     region: "h0".."h7", "feat" (fp32 datapath only: the split-bf16 / mixed datapaths fold feature_linear into the view
     branch and never write it), "hv", "enc".  The fp32 datapath stores point-major rows (act_layout); the bf16x3
     datapath stores 32-point feature-major tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32 -- except
     the 256- / 128-wide activation rows saved by the 16-point forward (precision "bf16x3" with FWD_16PT), which are in
-    16-point tiles with the row16 row order (tile16=True; default: what field_fwd recorded on the buffer)."""
+    16-point tiles with the row16 row order (tile16=True; default: what field_fwd recorded on the buffer).  bf16=True:
+    2-byte elements in 32-point tiles (mixed; bf16x3 with WGRAD_OPERANDS == "bf16"; default: what field_fwd recorded)."""
     tiled = precision in ("bf16x3", "mixed")
     if tile16 is None:
         tile16 = getattr(buf, "nerf_tile16", False)
+    if bf16 is None:
+        bf16 = precision == "mixed" or bool(getattr(buf, "nerf_bf16", False))
     Pa = (P + 31) // 32 * 32 if tiled else P
     widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
     off = 0
@@ -380,9 +400,9 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None):
             flat = buf[off:off + Pa * F]
             if not tiled:
                 return flat.view(P, F)
-            if precision == "mixed":        # 2-byte elements in the first half of the region
+            if bf16:                        # 2-byte elements in the first half of the region
                 flat = flat.view(torch.bfloat16)[:Pa * F].float()
-            if tile16 and precision == "bf16x3" and F in (256, 128):
+            if tile16 and not bf16 and precision == "bf16x3" and F in (256, 128):
                 rows = flat.view(Pa // 16, F, 16).permute(0, 2, 1).reshape(Pa, F)[:P]      # [P, row]
                 return rows[:, _row16(torch.arange(F, device=rows.device))]              # feature f sits at row16(f)
             return flat.view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
@@ -397,20 +417,24 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     act = WORKSPACE.take(act_floats(n, S), rays.device) if save_act else None
     if act is not None:
         act.nerf_tile16 = False
+        act.nerf_bf16 = False
+    b16 = _bf16_operands(precision)
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in ("bf16x3", "mixed"):
         nbytes = BYTES_ACT3_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in ("bf16x3", "mixed") and FWD_16PT:
-        bf16_save = int(precision == "mixed")
+        bf16_save = int(b16)
         label = "field_fwd16_kernel" + (("<save bf16>" if bf16_save else "<save>") if save_act else "")
         with _timed(label, FLOP_FWD3_PER_POINT * n * S, (0.5 if bf16_save and save_act else 1.0) * nbytes):
             _check(lib().nerf_field_fwd16_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                                  n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
                    "nerf_field_fwd16_bf16x3")
-        if act is not None and not bf16_save:
-            act.nerf_tile16 = True      # rows in 16-point tiles (csrc/nerf_common.h row16): the weight-gradient GEMM must know
+        if act is not None:
+            act.nerf_tile16 = not bf16_save     # fp32 rows: 16-point tiles (csrc/nerf_common.h row16): the GEMM must know
+            act.nerf_bf16 = bool(bf16_save)
         return raw, act
-    if precision == "mixed" and save_act:
+    if b16 and save_act:
+        act.nerf_bf16 = True
         with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD3_PER_POINT * n * S, 0.5 * nbytes):
             _check(lib().nerf_field_fwd_mixed(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                               n, S, _ptr(raw), _ptr(act, "act"), _stream()), "nerf_field_fwd_mixed")
@@ -499,28 +523,30 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32", params=Non
 def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S, params):
     b3 = precision == "bf16x3"
     mx = precision == "mixed"
+    b16 = b3 and bool(getattr(act, "nerf_bf16", False))        # bf16x3 chain, bf16-stored GEMM operands (WGRAD_OPERANDS)
     P = n * S
     if mx:
         with _timed("field_dgrad3_kernel<mixed>", FLOP_DGRAD3_PER_POINT * P, 0.5 * BYTES_DELTA3_PER_POINT * P):
             _check(L.nerf_field_dgrad_mixed(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
                                             _ptr(delta), _stream()), "nerf_field_dgrad_mixed")
+    elif b3:
+        with _timed("field_dgrad3_kernel<bf16 out>" if b16 else "field_dgrad3_kernel", FLOP_DGRAD3_PER_POINT * P,
+                    (0.5 if b16 else 1.0) * BYTES_DELTA3_PER_POINT * P):
+            _check(L.nerf_field_dgrad_bf16x3(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
+                                             _ptr(delta), int(b16), _stream()), "nerf_field_dgrad_bf16x3")
     else:
-        with _timed("field_dgrad3_kernel" if b3 else "field_dgrad_kernel", (FLOP_DGRAD3_PER_POINT if b3 else FLOP_DGRAD_PER_POINT) * P,
-                    (BYTES_DELTA3_PER_POINT if b3 else BYTES_DELTA_PER_POINT) * P):
-            if b3:
-                _check(L.nerf_field_dgrad_bf16x3(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
-                                                 _ptr(delta), _stream()), "nerf_field_dgrad_bf16x3")
-            else:
-                _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
-                                          _stream()), "nerf_field_dgrad")
-    datapath = 2 if mx else ((3 if getattr(act, "nerf_tile16", False) else 1) if b3 else 0)
+        with _timed("field_dgrad_kernel", FLOP_DGRAD_PER_POINT * P, BYTES_DELTA_PER_POINT * P):
+            _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
+                                      _stream()), "nerf_field_dgrad")
+    bf16_gemm = mx or b16
+    datapath = 2 if bf16_gemm else ((3 if getattr(act, "nerf_tile16", False) else 1) if b3 else 0)
     args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),
             int(bool(accumulate)), datapath)
     tail = (_ptr(params, "params", True), _stream())
     if TIMER is None:
         _check(L.nerf_field_wgrad_phase(*args, 7, *tail), "nerf_field_wgrad_phase")
         return grad
-    if mx:      # all 13 jobs stream bf16 operands straight into the MFMA
+    if bf16_gemm:   # all 13 jobs stream bf16 operands straight into the MFMA
         with _timed("wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD_MIXED_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
     elif b3:    # all 12 jobs (full-width and narrow) run through the masked bf16x3 tile kernel
@@ -532,7 +558,7 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
         with _timed("wgrad_kernel(narrow jobs)", (FLOP_WGRAD_PER_POINT - FLOP_WGRAD_BIG_PER_POINT) * P, BYTES_WGRAD_SMALL_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 2, *tail), "nerf_field_wgrad_phase")
     # chunks of partial sums the reduction reads (csrc/field_bwd.hip, wgrad_chunks)
-    n_chunks = min(64 if b3 else (59 if mx else 128), max(1, (P + 255) // 256))
+    n_chunks = min(59 if bf16_gemm else (64 if b3 else 128), max(1, (P + 255) // 256))
     with _timed("wgrad_reduce_kernel", 0.0, 4.0 * N_PARAMS * (n_chunks + 1)):
         _check(L.nerf_field_wgrad_phase(*args, 4, *tail), "nerf_field_wgrad_phase")
     return grad

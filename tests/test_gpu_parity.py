@@ -684,7 +684,7 @@ def test_render_c2w_ndc_matches_rays_branch_and_oracle(npa, dev, nets, precision
 
 # ---------------------------------------------------------------- split-bf16 datapath (precision "bf16x3")
 @pytest.mark.parametrize("n_rays,S", [(64, 64), (37, 192), (5, 3)])
-def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
+def test_field_forward_bf16x3(npa, dev, nets, n_rays, S, monkeypatch):
     """W*x = W_hi*x_hi + W_hi*x_lo + W_lo*x_hi on bf16 MFMA: ~1e-5 relative per product (fp32: 6e-8, bf16: 4e-3)."""
     nc, nf, Pc, Pf = nets
     rays = orc.synthetic_rays(n_rays, seed=S)
@@ -697,6 +697,9 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     e3, e32 = maxdiff(raw, ref64), maxdiff(raw32, ref64)
     print(f"bf16x3 max|raw-ref64| = {e3:.2e} (fp32 kernel: {e32:.2e}) at |raw|max = {scale:.1f}")
     assert e3 <= 3e-4 * scale, (e3, scale)
+    # (the layouts checked below are those of the fp32-operand weight-gradient GEMM; bf16 operand storage — the default —
+    # is the "mixed" layout, checked in test_mixed_forward_is_bf16x3_and_saves_bf16 / test_bf16_operand_storage_*)
+    monkeypatch.setattr(npa.hip_backend, "WGRAD_OPERANDS", "fp32")
     raw_s, act = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
     # inference and the saving forward are the same 16-point kernel: bit-identical; the 32-point kernel (FWD_16PT off)
     # sums in a different order: equal to rounding, and it writes the same save buffer (compared below)
@@ -751,9 +754,10 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
         assert maxdiff(a16, a32) <= 1e-4 * max(1.0, float(a32.abs().max())), region
 
 
+@pytest.mark.parametrize("operands", ["bf16", "fp32"])
 @pytest.mark.parametrize("fwd16", [True, False])
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192)])
-def test_field_backward_bf16x3(npa, dev, nets, n_rays, S, fwd16, monkeypatch):
+def test_field_backward_bf16x3(npa, dev, nets, n_rays, S, fwd16, operands, monkeypatch):
     """Split-bf16 forward + dgrad + wgrad vs fp64 autograd.  Besides the ~1e-5 product error, ReLU units whose
     pre-activation lies within the forward's ~1e-4 error of zero pick the other side of the kink (a few units per
     point out of 2176), which moves a gradient by up to ~1e-2 of its max while its direction is unchanged
@@ -766,9 +770,13 @@ def test_field_backward_bf16x3(npa, dev, nets, n_rays, S, fwd16, monkeypatch):
     packed3 = nf.packed_params("bf16x3")
     # both forwards: the 16-point kernel saves its rows in 16-point tiles, the 32-point kernel in 32-point tiles; the
     # weight-gradient GEMM stages either (datapath 3 / 1 of nerf_field_wgrad_phase)
+    # operands: how the weight-gradient GEMM's operands are stored (hip_backend.WGRAD_OPERANDS): bf16 tiles + the bf16
+    # streaming GEMM (default), or fp32 tiles split by the GEMM itself; the delta chain is the 3-term arithmetic either way
     monkeypatch.setattr(npa.hip_backend, "FWD_16PT", fwd16)
+    monkeypatch.setattr(npa.hip_backend, "WGRAD_OPERANDS", operands)
     raw, act = npa.hip_backend.field_fwd(packed3, rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
-    assert bool(getattr(act, "nerf_tile16", False)) == fwd16
+    assert bool(getattr(act, "nerf_tile16", False)) == (fwd16 and operands == "fp32")
+    assert bool(getattr(act, "nerf_bf16", False)) == (operands == "bf16")
     grad = torch.full((595844,), float("nan"), device=dev)
     npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), grad, accumulate=False, precision="bf16x3", params=nf.flat_params())
     # accumulate=True adds (also through the fold kernel that produces dWf, dbf and dWv[:, :256])
@@ -823,12 +831,102 @@ def test_bf16x3_training_step_tracks_fp32(npa, dev):
         assert abs(a - b) <= 2e-3 * abs(a), losses
 
 
+def _flat_grads_through_render(npa, dev, n, operands, monkeypatch, seed=17):
+    """gradient of the training loss (teacher-scene target) w.r.t. both networks through render(), bf16x3 datapath"""
+    import workloads as wl
+    monkeypatch.setattr(npa.hip_backend, "WGRAD_OPERANDS", operands)
+    cfg = wl.LEGO
+    Pc, Pf = wl.scene_params()
+    Tc, Tf = wl.teacher_params()
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    nets = [npa.NeRF(**kw).to(dev) for _ in range(4)]
+    for m, P in zip(nets, (Pc, Pf, Tc, Tf)):
+        m.load_state_dict(P)
+    batch = wl.lego_batch(n, seed=seed).to(dev)
+    rnd = {k: v.to(dev) for k, v in wl.synthetic_randoms(n, 64, 128, seed=seed).items() if k in ("t_rand", "u")}
+    args = dict(chunk=1 << 15, ndc=False, near=cfg["near"], far=cfg["far"], use_viewdirs=True, network_query_fn=None,
+                N_samples=64, N_importance=128, perturb=1.0, white_bkgd=True, raw_noise_std=0.)
+    npa.set_precision("bf16x3")
+    try:
+        with torch.no_grad():
+            target = npa.render(cfg["H"], cfg["W"], wl.intrinsics(cfg), rays=batch, randoms=rnd, network_fn=nets[2],
+                                network_fine=nets[3], **args)[0]
+        rgb, _, _, ex = npa.render(cfg["H"], cfg["W"], wl.intrinsics(cfg), rays=batch, randoms=rnd, network_fn=nets[0],
+                                   network_fine=nets[1], **args)
+        (npa.img2mse(rgb, target) + npa.img2mse(ex["rgb0"], target)).backward()
+    finally:
+        npa.set_precision("fp32")
+    return torch.cat([nets[0].last_flat_grad, nets[1].last_flat_grad]).double().cpu()
+
+
+def test_bf16_operand_storage_full_batch(npa, dev, monkeypatch):
+    """BASELINE configs[1] batch (4096 rays x (64+128)): the gradient of the training loss with the weight-gradient
+    GEMM's operands stored as bf16 (default) vs stored as fp32 and split by the GEMM (3 MFMAs per product).  The forward
+    and the delta chain are identical arithmetic; the operand rounding is zero-mean and averages over the 262 k / 786 k
+    points of the contraction."""
+    g16 = _flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch)
+    g32 = _flat_grads_through_render(npa, dev, 4096, "fp32", monkeypatch)
+    rel = float((g16 - g32).norm() / g32.norm())
+    cosdef = 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    per = {}
+    for tag, base in (("c", 0), ("f", 595844)):
+        for nm, off, shape in npa.hip_backend.param_table():
+            a, b = g16[base + off:base + off + int(np.prod(shape))], g32[base + off:base + off + int(np.prod(shape))]
+            per[f"{tag}/{nm}"] = float((a - b).norm() / (b.norm() + 1e-300))
+    wk = max(per, key=per.get)
+    print(f"bf16 vs fp32 operand storage, 4096 rays: relative L2 difference {rel:.2e}, cosine deficit {cosdef:.1e}; worst tensor {wk} {per[wk]:.2e}")
+    assert rel <= 3e-4 and cosdef <= 1e-7, (rel, cosdef)
+    assert per[wk] <= 2e-3, (wk, per[wk])
+
+
+def test_bf16_operand_storage_against_fp64(npa, dev, nets, monkeypatch):
+    """Both operand storages against fp64 autograd of the oracle on 98 k points with a RANDOM upstream gradient — the
+    worst case for operand rounding: the sums over points are incoherent (|sum| ~ sqrt(N) terms), so the zero-mean
+    2^-9 rounding of the operands does not average down relative to the result and shows at its bound, 2^-9 * sqrt(2) =
+    2.8e-3 of the gradient norm (measured 2.1e-3) — next to 4.9e-3 of the datapath itself on this input (3-term products,
+    ReLU units within rounding of zero that take the other side of their kink).  The two add in quadrature.  On the
+    coherent gradient of the training loss the same rounding is 9e-5 (test_bf16_operand_storage_full_batch)."""
+    nc, nf, Pc, Pf = nets
+    n_rays, S = 512, 192
+    g = torch.Generator().manual_seed(5)
+    rays = orc.synthetic_rays(n_rays, seed=23)
+    z = torch.sort(torch.rand(n_rays, S, generator=g) * 4.0 + 2.0, -1)[0]
+    d_raw = torch.randn(n_rays, S, 4, generator=g)
+    packed3 = nf.packed_params("bf16x3")
+    got = {}
+    for operands in ("bf16", "fp32"):
+        monkeypatch.setattr(npa.hip_backend, "WGRAD_OPERANDS", operands)
+        _, act = npa.hip_backend.field_fwd(packed3, rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
+        grad = torch.full((595844,), float("nan"), device=dev)
+        npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), grad, accumulate=False, precision="bf16x3", params=nf.flat_params())
+        npa.hip_backend.WORKSPACE.give(act)
+        got[operands] = grad.double().cpu()
+    P64 = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]
+    for lo in range(0, n_rays, 64):         # (chunks: the fp64 autograd graph of 98 k points at once is ~3 GB)
+        (orc.query_field(P64, pts[lo:lo + 64].double(), rays[lo:lo + 64, 8:11].double()) * d_raw[lo:lo + 64].double()).sum().backward()
+    ref = torch.cat([P64[nm].grad.reshape(-1) for nm, _, _ in npa.hip_backend.param_table()])
+    err = {k: float((v - ref).norm() / ref.norm()) for k, v in got.items()}
+    between = float((got["bf16"] - got["fp32"]).norm() / ref.norm())
+    print(f"relative L2 error vs fp64, 98 k points: bf16 operands {err['bf16']:.2e}, fp32 operands {err['fp32']:.2e}; between them {between:.2e}")
+    assert err["fp32"] <= 8e-3 and err["bf16"] <= 8e-3, err
+    assert between <= 2.0 ** -9 * 2 ** 0.5 * 1.1, between                  # the rounding bound of incoherent sums
+    assert err["bf16"] ** 2 <= 1.1 * (err["fp32"] ** 2 + between ** 2), (err, between)    # independent errors
+
+
 # ---------------------------------------------------------------- mixed-precision training option ("mixed")
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192), (5, 3)])
-def test_mixed_forward_is_bf16x3_and_saves_bf16(npa, dev, nets, n_rays, S):
-    """precision "mixed": the forward is the bf16x3 kernel (raw bit-identical); what it saves is the same tiles rounded to bf16."""
+def test_mixed_forward_is_bf16x3_and_saves_bf16(npa, dev, nets, n_rays, S, monkeypatch):
+    """precision "mixed" — and "bf16x3" with bf16 operand storage (the default): the forward is the bf16x3 kernel (raw
+    bit-identical); what it saves is the fp32-operand variant's rows rounded to bf16 (RNE), in 32-point tiles."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
+    raw_b, act_b = hb.field_fwd(nf.packed_params("bf16x3"), orc.synthetic_rays(n_rays, seed=S + 5).to(dev),
+                                torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0].to(dev),
+                                save_act=True, precision="bf16x3")
+    assert hb.WGRAD_OPERANDS == "bf16" and act_b.nerf_bf16 and not act_b.nerf_tile16
+    act_b = act_b.clone()
+    monkeypatch.setattr(hb, "WGRAD_OPERANDS", "fp32")
     rays = orc.synthetic_rays(n_rays, seed=S + 5).to(dev)
     z = torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0].to(dev)
     packed3 = nf.packed_params("mixed")
@@ -841,6 +939,9 @@ def test_mixed_forward_is_bf16x3_and_saves_bf16(npa, dev, nets, n_rays, S):
         got = hb.saved_rows(actm, P, region, "mixed")
         assert torch.equal(got, want), region
     assert torch.equal(hb.saved_rows(actm, P, "enc", "mixed")[:, :63], hb.saved_rows(act3, P, "enc", "bf16x3")[:, :63].bfloat16().float())
+    assert torch.equal(raw_b, raw3)
+    for region in [f"h{l}" for l in range(8)] + ["hv", "enc"]:
+        assert torch.equal(hb.saved_rows(act_b, P, region, "bf16x3", bf16=True), hb.saved_rows(actm, P, region, "mixed")), region
 
 
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192), (3, 5)])

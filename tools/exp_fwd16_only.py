@@ -16,7 +16,7 @@ act = torch.empty(hb.act_floats(N, 192), device=dev); raw = torch.empty(N, 192, 
 L = hb.lib(); s = torch.cuda.current_stream().cuda_stream
 f16 = lambda a, bf: L.nerf_field_fwd16_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, 192, raw.data_ptr(), a, bf, s)
 d_raw = torch.randn(N, 192, 4, device=dev); delta = torch.empty(L.nerf_delta_floats(N, 192), device=dev)
-g = lambda: L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), s)
+g = lambda: L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), 0, s)
 for _ in range(6):
     f16(None, 0); f16(act.data_ptr(), 0); f16(act.data_ptr(), 1); g()
 torch.cuda.synchronize()

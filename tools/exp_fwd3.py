@@ -27,7 +27,7 @@ f16 = lambda a, bf: L.nerf_field_fwd16_bf16x3(p3.data_ptr(), rays.data_ptr(), 11
 print("   fwd16 nosave %.3f ms | save %.3f ms | save bf16 %.3f ms" % (timeit(lambda: f16(None, 0)), timeit(lambda: f16(act.data_ptr(), 0)), timeit(lambda: f16(act.data_ptr(), 1))), flush=True)
 if "--bwd" in sys.argv:
     d_raw = torch.randn(N, 192, 4, device=dev); delta = torch.empty(L.nerf_delta_floats(N, 192), device=dev)
-    g = lambda: L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), s)
+    g = lambda: L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), 0, s)
     f(act.data_ptr()); print("   dgrad3 %.3f ms" % timeit(g), flush=True)
     partial = torch.empty(L.nerf_wgrad_partial_floats(N, 192), device=dev); grad = torch.empty(595844, device=dev)
     w = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 3, ph, nf.flat_params().data_ptr(), s)
@@ -36,7 +36,7 @@ if "--bwd" in sys.argv:
 if "--mixed" in sys.argv:
     fm = lambda: L.nerf_field_fwd_mixed(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, 192, raw.data_ptr(), act.data_ptr(), s)
     print("   mixed: fwd<save bf16> %.3f ms" % timeit(fm), flush=True)
-    gm = lambda: L.nerf_field_dgrad_mixed(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), s)
+    gm = lambda: L.nerf_field_dgrad_mixed(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), 0, s)
     print("   mixed: dgrad %.3f ms" % timeit(gm), flush=True)
     wm = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 2, ph, nf.flat_params().data_ptr(), s)
     print("   mixed: wgrad1 %.3f ms" % timeit(lambda: wm(1)), flush=True)

@@ -29,7 +29,7 @@ for S in (64, 192):
     act = torch.empty(hb.act_floats(N, S), device=dev); raw = torch.empty(N, S, 4, device=dev)
     L.nerf_field_fwd16_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, S, raw.data_ptr(), act.data_ptr(), 0, s)
     d_raw = torch.randn(N, S, 4, device=dev); delta = torch.empty(L.nerf_delta_floats(N, S), device=dev)
-    L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, S, delta.data_ptr(), s)
+    L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, S, delta.data_ptr(), 0, s)
     partial = torch.empty(L.nerf_wgrad_partial_floats(N, S), device=dev); grad = torch.zeros(595844, device=dev)
     w = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, S, partial.data_ptr(), grad.data_ptr(), 0, 3, ph, nf.flat_params().data_ptr(), s)
     t1, t4 = timeit(lambda: w(3)), timeit(lambda: w(4))
