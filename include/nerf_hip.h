@@ -146,7 +146,8 @@ int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_strid
 /* the same forward on 16 points per wavefront at 2 waves / SIMD instead of 32 at 1 (same arithmetic class: 3 bf16
  * MFMAs per product, fp32 accumulate): a second resident wave hides the LDS latency and the save work the 32-point
  * kernel leaves exposed.  act NULL = inference; otherwise it writes EXACTLY the save buffer of nerf_field_fwd_bf16x3
- * (bf16_save = 0) or nerf_field_fwd_mixed (bf16_save != 0), so the backward entry points are shared.  Sums the
+ * (bf16_save = 0; rows of the 256- / 128-wide regions in 16-point tiles, datapath 3 of nerf_field_wgrad_phase) or the
+ * same regions with bf16 elements (bf16_save != 0; rows in 16-point tiles of 2-byte elements, datapath 4).  Sums the
  * products in a different order than the 32-point kernel: the two agree to rounding (~1e-5 of |raw|), not bit for bit.
  * nerf_debug_pack16_table: host gather table of its fragment stream (tests). */
 int nerf_field_fwd16_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
@@ -187,8 +188,11 @@ int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_
  * equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate,
-                           int datapath /* 0 fp32; 1 bf16x3, act saved by nerf_field_fwd_bf16x3 (32-point tiles); 2 mixed;
-                                           3 bf16x3, act saved by nerf_field_fwd16_bf16x3 (rows in 16-point tiles) */,
+                           int datapath /* 0 fp32; 1 fp32 operands split by the GEMM, act saved by nerf_field_fwd_bf16x3
+                                           (32-point tiles); 3 the same, act saved by nerf_field_fwd16_bf16x3 (rows in
+                                           16-point tiles); 2 bf16 operands (act from nerf_field_fwd_mixed, delta from
+                                           nerf_field_dgrad_mixed or nerf_field_dgrad_bf16x3(delta_bf16 = 1)); 4 the
+                                           same, act saved by nerf_field_fwd16_bf16x3(bf16_save = 1) (16-point tiles) */,
                            int phases, const float* params /* canonical parameters; may be NULL for datapath 0 */,
                            void* stream);
 /* ---- optimizer.step() of run_nerf.py:776 for torch.optim.Adam(lr, betas=(beta1, beta2), eps) (run_nerf.py:207), fused over

@@ -205,7 +205,7 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
     const int bf16x3 = datapath;
     REQUIRE(datapath == 0 || params, "the split-bf16 / mixed datapaths need the canonical parameters (folded feature layer)");
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && bf16x3 >= 0 && bf16x3 <= 3, "bad size");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && bf16x3 >= 0 && bf16x3 <= 4, "bad size");
     return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate,
                                                    bf16x3, phases, (hipStream_t)stream, params));
 }

@@ -270,17 +270,33 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
         else nt_store(a.act + region + idx, v);
     };
     // rows of the 256- / 128-wide regions: 16-point tiles whose row order turns the four 64-byte runs of one store
-    // instruction into two full 128-byte lines (nerf_common.h, row16); bf16 saves (SAVE == 2) keep the 32-point tiles
+    // instruction into two full 128-byte lines (nerf_common.h, row16); bf16 saves (SAVE == 2): see store_pair below
     // The wave's 16 points are one tile: the tile base is wave-uniform (SGPR pair), the lane contributes a 32-bit offset
     // (its row inside a 16-feature block and its point), the (block, register) part is an immediate -- no 64-bit VALU
     // address arithmetic per store, no address registers held across the MFMA loop.
     const unsigned tile16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * FIELD_WAVES + wave)));
     const unsigned lane_row_off = (unsigned)((8 * (q >> 1) + (q & 1)) * 16 + (lane & 15));      // floats
     auto store_row = [&](size_t region, int F, int nb, int r, float v) __attribute__((always_inline)) {
-        if (SAVE == 2) { store_val(region, F, 16 * nb + 4 * q + r, v); return; }
         // feature f = 16*nb + 4*q + r: row16(f) * 16 = nb*256 + (8*(q>>1) + (q&1))*16 + r*32
         float* tile_base = a.act + region + (size_t)tile16 * (size_t)(F * 16);                 // uniform
         nt_store(tile_base + (nb * 256 + r * 32) + lane_row_off, v);
+    };
+    // SAVE == 2 (bf16 rows, operands of the bf16 weight-gradient GEMM): 16-point tiles as well, natural row order,
+    // [tile][F rows][16 points] of 2 bytes.  Two lanes with adjacent points pair up: both pack their rows (r, r+1), swap
+    // the packed word with the neighbour (DPP quad_perm [1,0,3,2]) and pick — the even lane row r of both points, the odd
+    // lane row r+1 — with one v_perm: 3 VALU ops and ONE dword store per two values, and the 16 lanes of a quarter write
+    // rows r, r+1 = 64 contiguous bytes (2-byte stores into 32-point tiles left 32-byte runs: a quarter of a line each,
+    // which cost the same HBM time as the fp32 rows).
+    const unsigned odd = (unsigned)lane & 1u;
+    const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;      // v_perm_b32 bytes of {neighbour word, own word}
+    const unsigned lane_pair_off = (unsigned)((4 * q + (int)odd) * 8 + ((lane & 15) >> 1));     // dwords: row 4q + odd, point pair
+    const bool pair_valid = (p_raw & ~1L) < P;                       // the pair's even point exists (its partner may be padding)
+    auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
+        const unsigned own = pack_bf16x2(v0, v1);                                       // rows r0 (lo), r0 + 1 (hi) of this point
+        const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
+        const unsigned word = __builtin_amdgcn_perm(nbr, own, pair_sel);                // (point 2j, point 2j+1) of row r0 + odd
+        unsigned* tile_base = reinterpret_cast<unsigned*>(a.act + region) + (size_t)tile16 * (size_t)(F * 8);      // uniform
+        if (pair_valid) nt_store(tile_base + (16 * nb + r0) * 8 + lane_pair_off, word);
     };
     if (SAVE) {
         al = act_layout3((size_t)P, (size_t)a.n_rays);
@@ -309,14 +325,15 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     // (they stay live in h[] as the B operand of layer L+1) are therefore written DURING layer L+1, one group of 8
     // stores per k-step, i.e. 16 per weight chunk; every acquire<> of that layer waits with a counted vmcnt so that the
     // 16 newest stores keep draining under the next chunk's MFMAs (WeightStreamT::acquire).
-    constexpr int ST_K = SAVE ? 8 : 0;                   // row stores per k-step
+    constexpr int ST_K = SAVE == 2 ? 4 : (SAVE ? 8 : 0);  // row stores per k-step (bf16 rows: one paired store per two rows)
     constexpr int ST_C = 2 * ST_K;                       // per 2-k-step chunk
     // value 4*nb + r of h = feature 16*nb + 4*q + r; k-step k writes blocks 2k, 2k+1: two stores after each of its four
     // MFMA groups (group g: block 2k + (g >> 1), registers 2*(g & 1), 2*(g & 1) + 1)
     auto save_pair = [&](auto kk, auto gg, size_t region) __attribute__((always_inline)) {
-        if (!SAVE || !valid) return;
+        if (!SAVE || (SAVE == 1 && !valid)) return;      // (paired stores: every lane takes part in the exchange)
         constexpr int nb = 2 * decltype(kk)::value + (decltype(gg)::value >> 1);
         constexpr int r0 = 2 * (decltype(gg)::value & 1);
+        if (SAVE == 2) { store_pair(region, W, nb, r0, h[4 * nb + r0], h[4 * nb + r0 + 1]); return; }
         store_row(region, W, nb, r0, h[4 * nb + r0]);
         store_row(region, W, nb, r0 + 1, h[4 * nb + r0 + 1]);
     };
@@ -429,7 +446,12 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[4 * nb + r] = fmaxf(av[nb][r], 0.0f);
     if (SAVE) {
-        if (valid) {
+        if (SAVE == 2) {
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) store_pair(al.hv, WV, nb, r, hv[4 * nb + r], hv[4 * nb + r + 1]);
+        } else if (valid) {
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb)
 #pragma unroll

@@ -386,7 +386,8 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
     datapath stores 32-point feature-major tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32 -- except
     the 256- / 128-wide activation rows saved by the 16-point forward (precision "bf16x3" with FWD_16PT), which are in
     16-point tiles with the row16 row order (tile16=True; default: what field_fwd recorded on the buffer).  bf16=True:
-    2-byte elements in 32-point tiles (mixed; bf16x3 with WGRAD_OPERANDS == "bf16"; default: what field_fwd recorded)."""
+    2-byte elements (mixed; bf16x3 with WGRAD_OPERANDS == "bf16"; default: what field_fwd recorded) in 32-point tiles,
+    or — rows saved by the 16-point forward, tile16=True — in 16-point tiles with the natural row order."""
     tiled = precision in ("bf16x3", "mixed")
     if tile16 is None:
         tile16 = getattr(buf, "nerf_tile16", False)
@@ -402,8 +403,10 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
                 return flat.view(P, F)
             if bf16:                        # 2-byte elements in the first half of the region
                 flat = flat.view(torch.bfloat16)[:Pa * F].float()
-            if tile16 and not bf16 and precision == "bf16x3" and F in (256, 128):
+            if tile16 and F in (256, 128):
                 rows = flat.view(Pa // 16, F, 16).permute(0, 2, 1).reshape(Pa, F)[:P]      # [P, row]
+                if bf16:
+                    return rows                                                          # bf16 tiles: natural row order
                 return rows[:, _row16(torch.arange(F, device=rows.device))]              # feature f sits at row16(f)
             return flat.view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
         off += Pa * F
@@ -430,7 +433,7 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
                                                  n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
                    "nerf_field_fwd16_bf16x3")
         if act is not None:
-            act.nerf_tile16 = not bf16_save     # fp32 rows: 16-point tiles (csrc/nerf_common.h row16): the GEMM must know
+            act.nerf_tile16 = True      # rows in 16-point tiles (fp32: row16 order, bf16: natural order): the GEMM must know
             act.nerf_bf16 = bool(bf16_save)
         return raw, act
     if b16 and save_act:
@@ -539,7 +542,8 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
             _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
                                       _stream()), "nerf_field_dgrad")
     bf16_gemm = mx or b16
-    datapath = 2 if bf16_gemm else ((3 if getattr(act, "nerf_tile16", False) else 1) if b3 else 0)
+    t16 = bool(getattr(act, "nerf_tile16", False))
+    datapath = (4 if t16 else 2) if bf16_gemm else ((3 if t16 else 1) if b3 else 0)
     args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),
             int(bool(accumulate)), datapath)
     tail = (_ptr(params, "params", True), _stream())

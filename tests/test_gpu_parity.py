@@ -775,7 +775,7 @@ def test_field_backward_bf16x3(npa, dev, nets, n_rays, S, fwd16, operands, monke
     monkeypatch.setattr(npa.hip_backend, "FWD_16PT", fwd16)
     monkeypatch.setattr(npa.hip_backend, "WGRAD_OPERANDS", operands)
     raw, act = npa.hip_backend.field_fwd(packed3, rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
-    assert bool(getattr(act, "nerf_tile16", False)) == (fwd16 and operands == "fp32")
+    assert bool(getattr(act, "nerf_tile16", False)) == fwd16
     assert bool(getattr(act, "nerf_bf16", False)) == (operands == "bf16")
     grad = torch.full((595844,), float("nan"), device=dev)
     npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), grad, accumulate=False, precision="bf16x3", params=nf.flat_params())
@@ -924,8 +924,7 @@ def test_mixed_forward_is_bf16x3_and_saves_bf16(npa, dev, nets, n_rays, S, monke
     raw_b, act_b = hb.field_fwd(nf.packed_params("bf16x3"), orc.synthetic_rays(n_rays, seed=S + 5).to(dev),
                                 torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0].to(dev),
                                 save_act=True, precision="bf16x3")
-    assert hb.WGRAD_OPERANDS == "bf16" and act_b.nerf_bf16 and not act_b.nerf_tile16
-    act_b = act_b.clone()
+    assert hb.WGRAD_OPERANDS == "bf16" and act_b.nerf_bf16 and act_b.nerf_tile16      # bf16 rows in 16-point tiles
     monkeypatch.setattr(hb, "WGRAD_OPERANDS", "fp32")
     rays = orc.synthetic_rays(n_rays, seed=S + 5).to(dev)
     z = torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0].to(dev)
@@ -941,7 +940,15 @@ def test_mixed_forward_is_bf16x3_and_saves_bf16(npa, dev, nets, n_rays, S, monke
     assert torch.equal(hb.saved_rows(actm, P, "enc", "mixed")[:, :63], hb.saved_rows(act3, P, "enc", "bf16x3")[:, :63].bfloat16().float())
     assert torch.equal(raw_b, raw3)
     for region in [f"h{l}" for l in range(8)] + ["hv", "enc"]:
-        assert torch.equal(hb.saved_rows(act_b, P, region, "bf16x3", bf16=True), hb.saved_rows(actm, P, region, "mixed")), region
+        n_col = 63 if region == "enc" else None         # (column 63 of the encoding tiles is padding, never written)
+        assert torch.equal(hb.saved_rows(act_b, P, region, "bf16x3")[:, :n_col], hb.saved_rows(actm, P, region, "mixed")[:, :n_col]), region
+    # the 32-point forward writes the same values into 32-point bf16 tiles
+    monkeypatch.setattr(hb, "FWD_16PT", False)
+    raw32, actm32 = hb.field_fwd(packed3, rays, z, save_act=True, precision="mixed")
+    assert actm32.nerf_bf16 and not actm32.nerf_tile16
+    for region in [f"h{l}" for l in range(8)] + ["hv"]:
+        a, b = hb.saved_rows(actm32, P, region, "mixed"), hb.saved_rows(actm, P, region, "mixed")
+        assert maxdiff(a, b) <= 1e-2 * max(1.0, float(b.abs().max())), region      # same rows to bf16 rounding of ~1e-5 differences
 
 
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192), (3, 5)])

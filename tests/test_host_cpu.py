@@ -255,6 +255,18 @@ def test_precision_selection_and_saved_row_views():
         off += Pp * F
     for name, F in widths:
         assert torch.equal(npa.hip_backend.saved_rows(buf16t, P, name, "bf16x3", tile16=True), want[name]), name
+    # bf16 rows saved by the 16-point forward (operands of the bf16 weight-gradient GEMM): 16-point tiles of 2-byte
+    # elements, natural row order; the 64-wide encoding stays in 32-point tiles
+    bufh = torch.zeros(total).view(torch.bfloat16)
+    off = 0
+    for name, F in widths:
+        p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
+        idx = (p // 16) * F * 16 + f * 16 + p % 16 if F in (256, 128) else (p // 32) * F * 32 + f * 32 + p % 32
+        bufh[2 * off + idx] = want[name].bfloat16()
+        off += Pp * F
+    for name, F in widths:
+        assert torch.equal(npa.hip_backend.saved_rows(bufh.view(torch.float32), P, name, "bf16x3", tile16=True, bf16=True), want[name]), name
+    assert npa.hip_backend.WGRAD_OPERANDS in ("bf16", "fp32")
     # one store instruction of that kernel (j fixed, q = 0..3) covers rows {2j, 2j+1} and {8+2j, 8+2j+1}: two full lines
     r16 = npa.hip_backend._row16
     for j in range(4):

@@ -27,8 +27,8 @@ f16 = lambda a, bf: L.nerf_field_fwd16_bf16x3(p3.data_ptr(), rays.data_ptr(), 11
 print("   fwd16 nosave %.3f ms | save %.3f ms | save bf16 %.3f ms" % (timeit(lambda: f16(None, 0)), timeit(lambda: f16(act.data_ptr(), 0)), timeit(lambda: f16(act.data_ptr(), 1))), flush=True)
 if "--bwd" in sys.argv:
     d_raw = torch.randn(N, 192, 4, device=dev); delta = torch.empty(L.nerf_delta_floats(N, 192), device=dev)
-    g = lambda: L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), 0, s)
-    f(act.data_ptr()); print("   dgrad3 %.3f ms" % timeit(g), flush=True)
+    g = lambda b: L.nerf_field_dgrad_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), b, s)
+    f(act.data_ptr()); print("   dgrad3 %.3f ms | bf16 deltas %.3f ms" % (timeit(lambda: g(0)), timeit(lambda: g(1))), flush=True)
     partial = torch.empty(L.nerf_wgrad_partial_floats(N, 192), device=dev); grad = torch.empty(595844, device=dev)
     w = lambda ph: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, 192, partial.data_ptr(), grad.data_ptr(), 0, 3, ph, nf.flat_params().data_ptr(), s)
     print("   wgrad3 %.3f ms  (+reduce %.3f ms)" % (timeit(lambda: w(1)), timeit(lambda: w(4))), flush=True)
