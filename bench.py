@@ -495,6 +495,29 @@ def main():
                 rgb_g = npa.render(H, W, K, chunk=args.chunk, rays=gbatch,
                                    **dict(render_kwargs_test, network_fn=gate_nets[0], network_fine=gate_nets[1]))[0]
             gate = wl.precision_gate(rgb_g, torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"]))
+            if args.precision == "bf16x3" and hb.WGRAD_OPERANDS == "bf16":
+                # the one place this datapath stores less than fp32: the operands of the weight-gradient GEMM (bf16, RNE).
+                # Gradient of the training loss against the fixture's target, this storage vs fp32 storage (same kernels
+                # otherwise; tests/test_gpu_parity.py test_bf16_operand_storage_* hold the 4096-ray batch to <= 3e-4)
+                tgt = torch.tensor(gold["target"]).to(dev)
+
+                def grads_with(operands):
+                    prev = hb.WGRAD_OPERANDS
+                    hb.WGRAD_OPERANDS = operands
+                    try:
+                        for m in gate_nets:
+                            m.zero_grad()
+                        rgb, _, _, ex = npa.render(H, W, K, chunk=args.chunk, rays=gbatch,
+                                                   **dict(render_kwargs_test, network_fn=gate_nets[0], network_fine=gate_nets[1]))
+                        (npa.img2mse(rgb, tgt) + npa.img2mse(ex["rgb0"], tgt)).backward()
+                        return torch.cat([gate_nets[0].last_flat_grad, gate_nets[1].last_flat_grad]).double()
+                    finally:
+                        hb.WGRAD_OPERANDS = prev
+                g16, g32 = grads_with("bf16"), grads_with("fp32")
+                gate["wgrad_operands"] = {
+                    "stored_as": "bf16 (forward and delta chain: 3-term split-bf16 arithmetic, unchanged)",
+                    "gradient_rel_l2_vs_fp32_operand_storage": float((g16 - g32).norm() / g32.norm()),
+                    "gradient_cosine_deficit": 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm())), "rays": 1024}
             gate.update(datapath=args.precision, rays=1024, bar_psnr_delta_db=0.01,
                         passed=bool(gate["psnr_delta_db"] < 0.01 and gate["target_psnr_db"] >= 30.0),
                         what="PSNR of our image vs the reference's image (real reference, CPU fp32, fixture gate_%s.npz) against a "

@@ -642,7 +642,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     const unsigned tile_bytes = 64u * (unsigned)sld;
     const char* cbase = reinterpret_cast<const char*>(sop == 0 ? jb.A : jb.B) + (size_t)(p_begin >> 5) * tile_bytes;
     // B operands saved by field_fwd16_kernel<2>: the stage's 32 points are two consecutive 16-point tiles of sld rows x
-    // 32 B (natural row order); 8-point group g of feature f sits at tile (g >> 1), row f, bytes 16 * (g & 1)
+    // 32 B (row16h order, nerf_common.h); 8-point group g of feature f sits at tile (g >> 1), row16h(f), bytes 16 * (g & 1)
     const bool t16 = sop == 1 && jb.b_tile16 != 0;
     unsigned doff[4];
 #pragma unroll
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
         const int q = 64 * (4 * (wave & 3) + u) + lane;
         const int f = q >> 2, jj = q & 3;
         const unsigned fc = (unsigned)min(f, swidth - 1), g = (unsigned)(jj ^ ((f >> 2) & 3));
-        doff[u] = t16 ? (g >> 1) * 32u * (unsigned)sld + 32u * fc + 16u * (g & 1u) : 64u * fc + 16u * g;
+        doff[u] = t16 ? (g >> 1) * 32u * (unsigned)sld + 32u * (unsigned)row16h((int)fc) + 16u * (g & 1u) : 64u * fc + 16u * g;
     }
     const unsigned lds0 = lds_addr(sm1) + (unsigned)(sop * WG1_OP_BYTES + (wave & 3) * 4096);
     auto issue = [&](int st) {
@@ -890,7 +890,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     // bf16x3 (datapath): 0 = fp32, 1 = split-bf16 with act saved by the 32-point forward (32-point tiles), 2 = mixed-precision
     // backward (bf16 operands, one MFMA per product), 3 = split-bf16 with act saved by the 16-point forward (rows in
     // 16-point tiles, nerf_common.h row16)
-    // 4 = bf16 operands whose B rows were saved by the 16-point forward (16-point bf16 tiles, natural row order)
+    // 4 = bf16 operands whose B rows were saved by the 16-point forward (16-point bf16 tiles, row16h order)
     const bool mixed = bf16x3 == 2 || bf16x3 == 4;
     const bool x_tile16 = bf16x3 == 3 || bf16x3 == 4;
     bf16x3 = bf16x3 == 0 ? 0 : (mixed ? 2 : 1);

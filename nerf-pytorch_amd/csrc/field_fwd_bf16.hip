@@ -281,22 +281,24 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
         float* tile_base = a.act + region + (size_t)tile16 * (size_t)(F * 16);                 // uniform
         nt_store(tile_base + (nb * 256 + r * 32) + lane_row_off, v);
     };
-    // SAVE == 2 (bf16 rows, operands of the bf16 weight-gradient GEMM): 16-point tiles as well, natural row order,
-    // [tile][F rows][16 points] of 2 bytes.  Two lanes with adjacent points pair up: both pack their rows (r, r+1), swap
-    // the packed word with the neighbour (DPP quad_perm [1,0,3,2]) and pick — the even lane row r of both points, the odd
-    // lane row r+1 — with one v_perm: 3 VALU ops and ONE dword store per two values, and the 16 lanes of a quarter write
-    // rows r, r+1 = 64 contiguous bytes (2-byte stores into 32-point tiles left 32-byte runs: a quarter of a line each,
-    // which cost the same HBM time as the fp32 rows).
+    // SAVE == 2 (bf16 rows, operands of the bf16 weight-gradient GEMM): 16-point tiles as well, [tile][F rows][16 points]
+    // of 2 bytes, rows in row16h order (nerf_common.h).  Two lanes with adjacent points pair up: both pack their rows
+    // (r, r+1), swap the packed word with the neighbour (DPP quad_perm [1,0,3,2]) and pick — the even lane row r of both
+    // points, the odd lane row r+1 — with one v_perm: 3 VALU ops and ONE dword store per two values.  The 16 lanes of
+    // quarter q then hold rows 4q + r, 4q + r + 1 = 64 bytes; row16h puts the four quarters' pairs next to each other, so
+    // one store instruction writes 256 contiguous bytes = two full 128-byte lines.  (Natural row order — 64-byte halves
+    // of a line written by instructions ~400 clk apart — cost 1.39x the write requests: PMC WRITE_SIZE 6.0 KB/point for
+    // 4.35 KB of rows; 2-byte stores into 32-point tiles left 32-byte runs and took the HBM time of the fp32 rows.)
     const unsigned odd = (unsigned)lane & 1u;
     const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;      // v_perm_b32 bytes of {neighbour word, own word}
-    const unsigned lane_pair_off = (unsigned)((4 * q + (int)odd) * 8 + ((lane & 15) >> 1));     // dwords: row 4q + odd, point pair
+    const unsigned lane_pair_off = (unsigned)((2 * q + (int)odd) * 8 + ((lane & 15) >> 1));     // dwords: row16h(4q + r0 + odd) - 4*r0, point pair
     const bool pair_valid = (p_raw & ~1L) < P;                       // the pair's even point exists (its partner may be padding)
     auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
         const unsigned own = pack_bf16x2(v0, v1);                                       // rows r0 (lo), r0 + 1 (hi) of this point
         const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
         const unsigned word = __builtin_amdgcn_perm(nbr, own, pair_sel);                // (point 2j, point 2j+1) of row r0 + odd
         unsigned* tile_base = reinterpret_cast<unsigned*>(a.act + region) + (size_t)tile16 * (size_t)(F * 8);      // uniform
-        if (pair_valid) nt_store(tile_base + (16 * nb + r0) * 8 + lane_pair_off, word);
+        if (pair_valid) nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);       // r0 in {0, 2}: rows 0-7 / 8-15 of the block
     };
     if (SAVE) {
         al = act_layout3((size_t)P, (size_t)a.n_rays);

@@ -269,6 +269,11 @@ __host__ __device__ inline size_t tile_index(size_t p, int F, int f) { return (p
 // feature a staged row is (row16_feature).
 __host__ __device__ constexpr int row16(int f) { return (f & ~15) + 8 * ((f >> 3) & 1) + 2 * (f & 3) + ((f >> 2) & 1); }
 __host__ __device__ constexpr int row16_feature(int r) { return (r & ~15) + 8 * ((r >> 3) & 1) + 4 * (r & 1) + ((r >> 1) & 3); }
+// bf16 rows saved by field_fwd16_kernel<2> (operands of the bf16 weight-gradient GEMM): 16-point tiles of 2-byte
+// elements, 32 bytes per row; lane pairs store (row 4q + r, row 4q + r + 1) x 2 points per dword for r in {0, 2}, so the
+// feature 4*q + r sits at row 8*(r>>1) + 2*q + (r&1): the eight rows one instruction writes are contiguous (256 B).
+//     element (p, f): 2-byte index (p >> 4) * F * 16 + row16h(f) * 16 + (p & 15)
+__host__ __device__ constexpr int row16h(int f) { return (f & ~15) + 8 * ((f >> 1) & 1) + 2 * ((f >> 2) & 3) + (f & 1); }
 __host__ __device__ inline size_t tile16_index(size_t p, int F, int f) { return (p >> 4) * (size_t)(F * 16) + (size_t)row16(f) * 16 + (p & 15); }
 
 struct ActLayout3 {

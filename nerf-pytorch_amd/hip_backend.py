@@ -169,6 +169,8 @@ FLOP_DGRAD3_PER_POINT = 2 * (557696 - FOLD_MAC)
 FLOP_WGRAD3_PER_POINT = 2 * (593408 - FOLD_MAC)
 BYTES_ACT3_PER_POINT = BYTES_ACT_PER_POINT - 4 * 256
 BYTES_DELTA3_PER_POINT = BYTES_DELTA_PER_POINT - 4 * 256
+BYTES_ACT3_BF16_PER_POINT = 2 * (8 * 256 + 128 + 64) + 8 * 9      # bf16 rows + encodings, ReLU bitmasks
+BYTES_DELTA3_BF16_PER_POINT = 2 * (8 * 256 + 128 + 4)
 BYTES_WGRAD_MIXED_PER_POINT = 0.5 * (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256))   # 13 jobs, bf16 operands
 # bf16x3: the alpha_linear gradient rides on the staging of the (delta_hv, h7) job — h7 is not re-read for it (12 jobs)
 BYTES_WGRAD3_PER_POINT = BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256) - 4 * 256
@@ -379,6 +381,11 @@ def _row16(f):
     return (f & ~15) + 8 * ((f >> 3) & 1) + 2 * (f & 3) + ((f >> 2) & 1)
 
 
+def _row16h(f):
+    """csrc/nerf_common.h row16h(): row of feature f inside a 16-point tile of bf16 rows."""
+    return (f & ~15) + 8 * ((f >> 1) & 1) + 2 * ((f >> 2) & 3) + (f & 1)
+
+
 def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
     """Debug/test view of one saved region (activations or deltas) as a point-major [P, F] tensor.
     region: "h0".."h7", "feat" (fp32 datapath only: the split-bf16 / mixed datapaths fold feature_linear into the view
@@ -387,7 +394,7 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
     the 256- / 128-wide activation rows saved by the 16-point forward (precision "bf16x3" with FWD_16PT), which are in
     16-point tiles with the row16 row order (tile16=True; default: what field_fwd recorded on the buffer).  bf16=True:
     2-byte elements (mixed; bf16x3 with WGRAD_OPERANDS == "bf16"; default: what field_fwd recorded) in 32-point tiles,
-    or — rows saved by the 16-point forward, tile16=True — in 16-point tiles with the natural row order."""
+    or — rows saved by the 16-point forward, tile16=True — in 16-point tiles with the row16h row order."""
     tiled = precision in ("bf16x3", "mixed")
     if tile16 is None:
         tile16 = getattr(buf, "nerf_tile16", False)
@@ -406,7 +413,7 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
             if tile16 and F in (256, 128):
                 rows = flat.view(Pa // 16, F, 16).permute(0, 2, 1).reshape(Pa, F)[:P]      # [P, row]
                 if bf16:
-                    return rows                                                          # bf16 tiles: natural row order
+                    return rows[:, _row16h(torch.arange(F, device=rows.device))]         # bf16 tiles: feature f at row16h(f)
                 return rows[:, _row16(torch.arange(F, device=rows.device))]              # feature f sits at row16(f)
             return flat.view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
         off += Pa * F
@@ -428,17 +435,17 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     if precision in ("bf16x3", "mixed") and FWD_16PT:
         bf16_save = int(b16)
         label = "field_fwd16_kernel" + (("<save bf16>" if bf16_save else "<save>") if save_act else "")
-        with _timed(label, FLOP_FWD3_PER_POINT * n * S, (0.5 if bf16_save and save_act else 1.0) * nbytes):
+        with _timed(label, FLOP_FWD3_PER_POINT * n * S, BYTES_ACT3_BF16_PER_POINT * n * S if bf16_save and save_act else nbytes):
             _check(lib().nerf_field_fwd16_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                                  n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
                    "nerf_field_fwd16_bf16x3")
         if act is not None:
-            act.nerf_tile16 = True      # rows in 16-point tiles (fp32: row16 order, bf16: natural order): the GEMM must know
+            act.nerf_tile16 = True      # rows in 16-point tiles (fp32: row16 order, bf16: row16h order): the GEMM must know
             act.nerf_bf16 = bool(bf16_save)
         return raw, act
     if b16 and save_act:
         act.nerf_bf16 = True
-        with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD3_PER_POINT * n * S, 0.5 * nbytes):
+        with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD3_PER_POINT * n * S, BYTES_ACT3_BF16_PER_POINT * n * S):
             _check(lib().nerf_field_fwd_mixed(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                               n, S, _ptr(raw), _ptr(act, "act"), _stream()), "nerf_field_fwd_mixed")
         return raw, act
@@ -529,12 +536,12 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
     b16 = b3 and bool(getattr(act, "nerf_bf16", False))        # bf16x3 chain, bf16-stored GEMM operands (WGRAD_OPERANDS)
     P = n * S
     if mx:
-        with _timed("field_dgrad3_kernel<mixed>", FLOP_DGRAD3_PER_POINT * P, 0.5 * BYTES_DELTA3_PER_POINT * P):
+        with _timed("field_dgrad3_kernel<mixed>", FLOP_DGRAD3_PER_POINT * P, BYTES_DELTA3_BF16_PER_POINT * P):
             _check(L.nerf_field_dgrad_mixed(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
                                             _ptr(delta), _stream()), "nerf_field_dgrad_mixed")
     elif b3:
         with _timed("field_dgrad3_kernel<bf16 out>" if b16 else "field_dgrad3_kernel", FLOP_DGRAD3_PER_POINT * P,
-                    (0.5 if b16 else 1.0) * BYTES_DELTA3_PER_POINT * P):
+                    (BYTES_DELTA3_BF16_PER_POINT if b16 else BYTES_DELTA3_PER_POINT) * P):
             _check(L.nerf_field_dgrad_bf16x3(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
                                              _ptr(delta), int(b16), _stream()), "nerf_field_dgrad_bf16x3")
     else:

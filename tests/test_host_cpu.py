@@ -256,12 +256,14 @@ def test_precision_selection_and_saved_row_views():
     for name, F in widths:
         assert torch.equal(npa.hip_backend.saved_rows(buf16t, P, name, "bf16x3", tile16=True), want[name]), name
     # bf16 rows saved by the 16-point forward (operands of the bf16 weight-gradient GEMM): 16-point tiles of 2-byte
-    # elements, natural row order; the 64-wide encoding stays in 32-point tiles
+    # elements, row16h row order (one paired store instruction = 8 consecutive rows = two full lines); the 64-wide
+    # encoding stays in 32-point tiles
     bufh = torch.zeros(total).view(torch.bfloat16)
     off = 0
     for name, F in widths:
         p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
-        idx = (p // 16) * F * 16 + f * 16 + p % 16 if F in (256, 128) else (p // 32) * F * 32 + f * 32 + p % 32
+        rowh = (f // 16) * 16 + 8 * ((f >> 1) & 1) + 2 * ((f >> 2) & 3) + (f & 1)     # feature 4q + r at row 8*(r>>1) + 2q + (r&1)
+        idx = (p // 16) * F * 16 + rowh * 16 + p % 16 if F in (256, 128) else (p // 32) * F * 32 + f * 32 + p % 32
         bufh[2 * off + idx] = want[name].bfloat16()
         off += Pp * F
     for name, F in widths:
