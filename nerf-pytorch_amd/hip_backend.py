@@ -157,7 +157,7 @@ FLOP_DGRAD_PER_POINT = 2 * 557696
 FLOP_WGRAD_PER_POINT = 2 * 593408
 FLOP_WGRAD_BIG_PER_POINT = 2 * 8 * 256 * 256            # the eight full-width jobs
 # algorithmic HBM bytes per point (SURVEY §8d / DESIGN.md §2): what a launch must move once
-BYTES_ACT_PER_POINT = 4 * (9 * 256 + 128 + 64 + 32) + 8 * 9  # saved activations + encodings + bitmasks (forward, training)
+BYTES_ACT_PER_POINT = 4 * (9 * 256 + 128 + 64 + 32) + 32 * 9 + 16  # saved activations + encodings + ReLU bitmasks (256 bits x 9 layers) + raw
 BYTES_DELTA_PER_POINT = 4 * (9 * 256 + 128)             # deltas written by dgrad
 BYTES_WGRAD_BIG_PER_POINT = 4 * 8 * (256 + 256)         # each full-width job reads its delta and its input once
 BYTES_WGRAD_SMALL_PER_POINT = 4 * (2 * (256 + 64) + (4 + 256) + (128 + 256) + (128 + 32) + (4 + 128))
@@ -169,7 +169,7 @@ FLOP_DGRAD3_PER_POINT = 2 * (557696 - FOLD_MAC)
 FLOP_WGRAD3_PER_POINT = 2 * (593408 - FOLD_MAC)
 BYTES_ACT3_PER_POINT = BYTES_ACT_PER_POINT - 4 * 256
 BYTES_DELTA3_PER_POINT = BYTES_DELTA_PER_POINT - 4 * 256
-BYTES_ACT3_BF16_PER_POINT = 2 * (8 * 256 + 128 + 64) + 8 * 9      # bf16 rows + encodings, ReLU bitmasks
+BYTES_ACT3_BF16_PER_POINT = 2 * (8 * 256 + 128 + 64) + 32 * 9 + 16  # bf16 rows + encodings, ReLU bitmasks, raw
 BYTES_DELTA3_BF16_PER_POINT = 2 * (8 * 256 + 128 + 4)
 BYTES_WGRAD_MIXED_PER_POINT = 0.5 * (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256))   # 13 jobs, bf16 operands
 # bf16x3: the alpha_linear gradient rides on the staging of the (delta_hv, h7) job — h7 is not re-read for it (12 jobs)
