@@ -105,13 +105,13 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     };
     // every delta is written while the NEXT contraction runs, a quarter (32 stores) after each chunk acquire;
     // the following acquire<NQ> keeps those stores in flight (counted vmcnt, see WeightStreamT::acquire)
-    constexpr int NQ = STORES_PER_QUARTER3;
+    constexpr int NQ = OUT16 ? STORES_PER_QUARTER3 / 2 : STORES_PER_QUARTER3;   // bf16 deltas leave as paired stores
+    const bool pair_valid = (p_raw & ~(size_t)1) < P;
     using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
     auto store_q = [&](auto part, size_t off) {
-        if (!valid) return;
-        if (OUT16) store_tile3h<2 * decltype(part)::value, 2>(reinterpret_cast<__bf16*>(a.delta + off) + tile * (W * 32) + lslot, d);
-        else store_tile3<2 * decltype(part)::value, 2>(a.delta + off + tile * (W * 32) + lslot, d);
+        if (OUT16) store_tile3h_pair<2 * decltype(part)::value, 2>(reinterpret_cast<__bf16*>(a.delta + off) + tile * (W * 32), lane, pair_valid, d);
+        else if (valid) store_tile3<2 * decltype(part)::value, 2>(a.delta + off + tile * (W * 32) + lslot, d);
     };
     using V0 = std::integral_constant<int, 0>; using V32 = std::integral_constant<int, 32>;
     using V64 = std::integral_constant<int, 64>; using V96 = std::integral_constant<int, 96>;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         load_alpha();           // acc = alpha_linear^T d_sigma; the view branch adds W'^T d_hv: delta of the trunk output
         {
             const float* cur = ws.acquire(FOLD_SKIP_CHUNKS_BWD_HI);
-            if (valid) store_tile3h<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32) + lslot, dhv);
+            store_tile3h_pair<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32), lane, pair_valid, dhv);
             mma1_chunk<8, 8, 0, 0, 64>(acc, dhv, cur, lane);
         }
         apply_mask3<128>(d, acc, msk[D - 1]);
@@ -141,10 +141,10 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         for (int l = D - 1; l >= 1; --l) {
             zero_acc();
             const size_t off = (size_t)l * pad32(P) * W;                       // dl.h[l]
-            const float* cur = ws.template acquire<63>();
+            const float* cur = ws.template acquire<2 * NQ>();
             store_q(Q0{}, off); store_q(Q1{}, off);
             mma1_chunk<8, 8, 0, 0, 128>(acc, d, cur, lane);
-            cur = ws.template acquire<63>();
+            cur = ws.template acquire<2 * NQ>();
             store_q(Q2{}, off); store_q(Q3{}, off);
             mma1_chunk<8, 8, 0, 64, 128>(acc, d, cur, lane);
             u32x4 m = msk[0];                   // ReLU bitmask of h_{l-1} (static indices only: msk stays in registers)
@@ -160,13 +160,12 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         load_alpha();
         {
             const float* cur = ws.acquire();
-            if (valid) {                                                                        // 64 stores
-                if (OUT16) store_tile3h<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32) + lslot, dhv);
-                else store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);
-            }
+            // 64 stores (paired bf16: 32)
+            if (OUT16) store_tile3h_pair<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32), lane, pair_valid, dhv);
+            else if (valid) store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);
             mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
         }
-        mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<63>(FOLD_SKIP_CHUNKS_BWD), lane);
+        mma3_chunk<8, 4, 32, 64>(acc, dhv, ws.template acquire<OUT16 ? 32 : 63>(FOLD_SKIP_CHUNKS_BWD), lane);
         apply_mask3<128>(d, acc, msk[D - 1]);
 
         // ---- trunk: delta_{l-1} = (W_l^T delta_l) * relu'(h_{l-1}),  l = 7 .. 1
@@ -192,10 +191,9 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
             apply_mask3<128>(d, acc, m);
         }
     }
-    if (valid) {                                                           // dl.h[0]
-        if (OUT16) store_tile3h<0, 8>(reinterpret_cast<__bf16*>(a.delta) + tile * (W * 32) + lslot, d);
-        else store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);
-    }
+    // dl.h[0]
+    if (OUT16) store_tile3h_pair<0, 8>(reinterpret_cast<__bf16*>(a.delta) + tile * (W * 32), lane, pair_valid, d);
+    else if (valid) store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);
 }
 
 hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
