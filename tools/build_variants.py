@@ -24,6 +24,8 @@ VARIANTS = {
     "f16_norows": lambda d: patch(os.path.join(d, "field_fwd_bf16.hip"), "        if (pair_valid) nt_store(tile_base + (16 * nb + r0) * 8 + lane_pair_off, word);", "        if (word == 0x12345678u) nt_store(tile_base + (16 * nb + r0) * 8 + lane_pair_off, word);"),
     "f16_nosave": lambda d: patch(os.path.join(d, "field_fwd_bf16.hip"), "        if (SAVE == 2) { store_pair(region, W, nb, r0, h[4 * nb + r0], h[4 * nb + r0 + 1]); return; }", "        if (SAVE == 2) return;"),
     "f16_nomask": lambda d: patch(os.path.join(d, "field_fwd_bf16.hip"), "        if (!SAVE) return;\n        unsigned w[4] = {0u, 0u, 0u, 0u};", "        return;\n        unsigned w[4] = {0u, 0u, 0u, 0u};"),
+    # bf16 weight-gradient GEMM: operand DMA without the nt hint
+    "wg1_plain": lambda d: patch(os.path.join(d, "field_bwd.hip"), '"global_load_lds_dwordx4 %1, %2 nt\\n\\t"', '"global_load_lds_dwordx4 %1, %2\\n\\t"'),
     # dgrad: no delta stores
     "dgrad_nostore": lambda d: patch(os.path.join(d, "field_bwd_bf16.hip"), "    auto store_q = [&](auto part, size_t off) {\n        if (!valid) return;", "    auto store_q = [&](auto part, size_t off) {\n        return;"),
     # weight-gradient GEMM: the two waves of a SIMD in anti-phase (waves 0-3 MFMA then stage, waves 4-7 stage then MFMA)
