@@ -756,7 +756,7 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S, monkeypatch):
 
 @pytest.mark.parametrize("operands", ["bf16", "fp32"])
 @pytest.mark.parametrize("fwd16", [True, False])
-@pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192)])
+@pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192), (3, 5), (1, 1)])      # (3, 5), (1, 1): odd point counts (ragged lane pairs / tiles)
 def test_field_backward_bf16x3(npa, dev, nets, n_rays, S, fwd16, operands, monkeypatch):
     """Split-bf16 forward + dgrad + wgrad vs fp64 autograd.  Besides the ~1e-5 product error, ReLU units whose
     pre-activation lies within the forward's ~1e-4 error of zero pick the other side of the kink (a few units per
