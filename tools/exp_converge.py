@@ -26,7 +26,9 @@ def psnr(nc, nf):
     with torch.no_grad():
         out = npa.render_rays(held, nc, None, network_fine=nf, perturb=0., **rk)["rgb_map"]
     return -10 * math.log10(float(((out - tgt_held) ** 2).mean()))
-for prec in ("fp32", "bf16x3", "mixed"):
+for prec, operands in (("fp32", None), ("bf16x3", "bf16"), ("bf16x3", "fp32"), ("mixed", None)):
+    if operands is not None:        # storage of the weight-gradient GEMM's operands on the split-bf16 datapath
+        npa.hip_backend.WGRAD_OPERANDS = operands
     torch.manual_seed(0)
     nc, nf = net(Sc), net(Sf)
     opt = npa.FlatAdam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4, betas=(0.9, 0.999))
@@ -42,4 +44,5 @@ for prec in ("fp32", "bf16x3", "mixed"):
         loss.backward(); opt.step()
         if (step + 1) % (STEPS // 5) == 0:
             curve.append(round(psnr(nc, nf), 3))
-    print(f"{prec:7s} held-out PSNR: start {p0:.3f} dB -> {curve}", flush=True)
+    print(f"{prec:7s} {'(' + operands + ' operands)' if operands else '':16s} held-out PSNR: start {p0:.3f} dB -> {curve}", flush=True)
+npa.hip_backend.WGRAD_OPERANDS = "bf16"
