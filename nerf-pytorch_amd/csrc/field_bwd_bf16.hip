@@ -106,11 +106,17 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
     // every delta is written while the NEXT contraction runs, a quarter (32 stores) after each chunk acquire;
     // the following acquire<NQ> keeps those stores in flight (counted vmcnt, see WeightStreamT::acquire)
     constexpr int NQ = OUT16 ? STORES_PER_QUARTER3 / 2 : STORES_PER_QUARTER3;   // bf16 deltas leave as paired stores
-    const bool pair_valid = (p_raw & ~(size_t)1) < P;
+    // bf16 deltas: unconditional paired stores (field_device_bf16.h).  A wave whose tile lies beyond the padded point range
+    // (possible in the last workgroup only) writes to a dump tile instead: the `feat` region, which the folded datapaths
+    // never use (wave-uniform select of the base, no branch)
+    const bool tile_ok = __builtin_amdgcn_readfirstlane((int)(tile * 32 < pad32(P))) != 0;
+    auto out16 = [&](size_t region_off, int F) {
+        return reinterpret_cast<__bf16*>(a.delta + (tile_ok ? region_off : dl.feat)) + (tile_ok ? tile * (size_t)(F * 32) : (size_t)0);
+    };
     using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
     auto store_q = [&](auto part, size_t off) {
-        if (OUT16) store_tile3h_pair<2 * decltype(part)::value, 2>(reinterpret_cast<__bf16*>(a.delta + off) + tile * (W * 32), lane, pair_valid, d);
+        if (OUT16) store_tile3h_pair<2 * decltype(part)::value, 2>(out16(off, W), lane, d);
         else if (valid) store_tile3<2 * decltype(part)::value, 2>(a.delta + off + tile * (W * 32) + lslot, d);
     };
     using V0 = std::integral_constant<int, 0>; using V32 = std::integral_constant<int, 32>;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         load_alpha();           // acc = alpha_linear^T d_sigma; the view branch adds W'^T d_hv: delta of the trunk output
         {
             const float* cur = ws.acquire(FOLD_SKIP_CHUNKS_BWD_HI);
-            store_tile3h_pair<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32), lane, pair_valid, dhv);
+            store_tile3h_pair<0, 4>(out16(dl.hv, WV), lane, dhv);
             mma1_chunk<8, 8, 0, 0, 64>(acc, dhv, cur, lane);
         }
         apply_mask3<128>(d, acc, msk[D - 1]);
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         {
             const float* cur = ws.acquire();
             // 64 stores (paired bf16: 32)
-            if (OUT16) store_tile3h_pair<0, 4>(reinterpret_cast<__bf16*>(a.delta + dl.hv) + tile * (WV * 32), lane, pair_valid, dhv);
+            if (OUT16) store_tile3h_pair<0, 4>(out16(dl.hv, WV), lane, dhv);
             else if (valid) store_tile3<0, 4>(a.delta + dl.hv + tile * (WV * 32) + lslot, dhv);
             mma3_chunk<8, 4, 0, 64>(acc, dhv, cur, lane);
         }
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3_kernel(FieldBw
         }
     }
     // dl.h[0]
-    if (OUT16) store_tile3h_pair<0, 8>(reinterpret_cast<__bf16*>(a.delta) + tile * (W * 32), lane, pair_valid, d);
+    if (OUT16) store_tile3h_pair<0, 8>(out16(0, W), lane, d);
     else if (valid) store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);
 }
 

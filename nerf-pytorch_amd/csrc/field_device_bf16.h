@@ -176,11 +176,15 @@ __device__ inline void store_tile3h(__bf16* tp, const float (&v)[NV]) {
 // The same bf16 tiles written by lane PAIRS (adjacent points): both lanes pack their values (r, r+1) — adjacent rows of the
 // tile —, swap the word with the neighbour (DPP quad_perm [1,0,3,2]) and select with one v_perm_b32: the even lane holds
 // row R of both points, the odd lane row R+1, so one dword store carries two values, the 16 even lanes of a half write
-// the whole 64-byte row R, the odd lanes row R+1, and an instruction writes two full 128-byte lines.  Every lane of the
-// wave must take part (DPP); pair_valid = the pair's even point exists.  tile_base = region + tile * F * 32 (no lane
-// offset).  Half the store instructions of store_tile3h.
+// the whole 64-byte row R, the odd lanes row R+1, and an instruction writes two full 128-byte lines.  Half the store
+// instructions of store_tile3h.  Every lane of the wave takes part (DPP) and the stores are UNCONDITIONAL: a per-lane
+// predicate is an exec-mask branch — and a basic-block boundary for the scheduler — per store (measured: 6 % of the
+// dgrad kernel, also when only one branch per 16 stores is left).  The caller passes a tile that exists: padding
+// points of a ragged last tile are written (the weight-gradient GEMM masks points >= P), and a wave whose whole tile
+// lies beyond the padded point range is pointed at a dump tile (an unused region of the same buffer).
+// tile_base = region + tile * F * 32 (no lane offset).
 template <int OB0, int NOB, int NV>
-__device__ __forceinline__ void store_tile3h_pair(__bf16* tile_base, int lane, bool pair_valid, const float (&v)[NV]) {
+__device__ __forceinline__ void store_tile3h_pair(__bf16* tile_base, int lane, const float (&v)[NV]) {
     const unsigned odd = (unsigned)lane & 1u;
     const unsigned sel = odd ? 0x03020706u : 0x05040100u;
     unsigned* base = reinterpret_cast<unsigned*>(tile_base) + ((lane >> 5) * 4 + (int)odd) * 16 + ((lane & 31) >> 1);
@@ -190,8 +194,7 @@ __device__ __forceinline__ void store_tile3h_pair(__bf16* tile_base, int lane, b
         for (int r = 0; r < 16; r += 2) {
             const unsigned own = pack_bf16x2(v[16 * ob + r], v[16 * ob + r + 1]);
             const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
-            const unsigned word = __builtin_amdgcn_perm(nbr, own, sel);
-            if (pair_valid) nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word);
+            nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, __builtin_amdgcn_perm(nbr, own, sel));
         }
 }
 constexpr int STORES_PER_QUARTER3 = 32;      // store_tile3<2*PART, 2>: a quarter of a 256-feature row set (paired bf16: 16)

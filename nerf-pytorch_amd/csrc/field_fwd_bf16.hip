@@ -292,13 +292,18 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16_kernel(FieldFwd3
     const unsigned odd = (unsigned)lane & 1u;
     const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;      // v_perm_b32 bytes of {neighbour word, own word}
     const unsigned lane_pair_off = (unsigned)((2 * q + (int)odd) * 8 + ((lane & 15) >> 1));     // dwords: row16h(4q + r0 + odd) - 4*r0, point pair
-    const bool pair_valid = (p_raw & ~1L) < P;                       // the pair's even point exists (its partner may be padding)
+    // The stores are unconditional (a per-lane predicate is an exec-mask branch and a scheduling barrier per store):
+    // padding points of a ragged last tile are written (the weight-gradient GEMM masks points >= P), and a wave whose whole
+    // tile lies beyond the padded point range (last workgroup only) is pointed at a dump tile — the `feat` region, which
+    // the folded datapaths never use (wave-uniform select of the base).
+    const bool tile_ok = (size_t)tile16 * 16 < pad32((size_t)P);
     auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
         const unsigned own = pack_bf16x2(v0, v1);                                       // rows r0 (lo), r0 + 1 (hi) of this point
         const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
         const unsigned word = __builtin_amdgcn_perm(nbr, own, pair_sel);                // (point 2j, point 2j+1) of row r0 + odd
-        unsigned* tile_base = reinterpret_cast<unsigned*>(a.act + region) + (size_t)tile16 * (size_t)(F * 8);      // uniform
-        if (pair_valid) nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);       // r0 in {0, 2}: rows 0-7 / 8-15 of the block
+        unsigned* tile_base = reinterpret_cast<unsigned*>(a.act + (tile_ok ? region : al.feat))
+                              + (tile_ok ? (size_t)tile16 * (size_t)(F * 8) : (size_t)0);                          // uniform
+        nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);                        // r0 in {0, 2}: rows 0-7 / 8-15 of the block
     };
     if (SAVE) {
         al = act_layout3((size_t)P, (size_t)a.n_rays);

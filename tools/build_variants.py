@@ -26,6 +26,9 @@ VARIANTS = {
     "f16_nomask": lambda d: patch(os.path.join(d, "field_fwd_bf16.hip"), "        if (!SAVE) return;\n        unsigned w[4] = {0u, 0u, 0u, 0u};", "        return;\n        unsigned w[4] = {0u, 0u, 0u, 0u};"),
     # bf16 weight-gradient GEMM: operand DMA without the nt hint
     "wg1_plain": lambda d: patch(os.path.join(d, "field_bwd.hip"), '"global_load_lds_dwordx4 %1, %2 nt\\n\\t"', '"global_load_lds_dwordx4 %1, %2\\n\\t"'),
+    # paired bf16 stores without their per-lane predicate (exec-mask branch around every store): valid for P % 128 == 0 only
+    "nopred": lambda d: (patch(os.path.join(d, "field_fwd_bf16.hip"), "        if (pair_valid) nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);", "        nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);"),
+                         patch(os.path.join(d, "field_device_bf16.h"), "            if (pair_valid) nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word);", "            nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word);")),
     # dgrad: no delta stores
     "dgrad_nostore": lambda d: patch(os.path.join(d, "field_bwd_bf16.hip"), "    auto store_q = [&](auto part, size_t off) {\n        if (!valid) return;", "    auto store_q = [&](auto part, size_t off) {\n        return;"),
     # weight-gradient GEMM: the two waves of a SIMD in anti-phase (waves 0-3 MFMA then stage, waves 4-7 stage then MFMA)
