@@ -13,6 +13,7 @@
 //                        split over point chunks; per-chunk partial gradients are
 //                        written in canonical layout and summed by
 //   wgrad_reduce_kernel (deterministic, no atomics).
+#include <type_traits>
 #include "field_device_bf16.h"
 
 #include "launchers.h"
@@ -708,19 +709,49 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
         }
     };
 
+    // The common case — a full 128 x 64 wave tile, all 32 points of the stage exist — as straight-line code: all twelve
+    // fragment reads of a k-step are issued together, then its 8 MFMAs.  (compute() above decides per
+    // fragment whether its rows exist, whether the stage is ragged and whether bias sums are wanted: a branch, i.e. a
+    // scheduling barrier, between every pair of MFMAs, each pair waiting for its own ds_read_b128.)
+    auto compute_full = [&](int st, auto with_bias) {
+        const unsigned char* stage = sm1 + (st & 3) * WG1_STAGE_BYTES;
+        const unsigned char* sa = stage + (wave_n * 128) * 64;
+        const unsigned char* sb = stage + WG1_OP_BYTES + (wave_k * 64) * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {           // six reads, then eight MFMAs, per k-step (all twelve reads up front spill)
+            u32x4 bf[2], af[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * 64 + frag[t]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(sa + i * 32 * 64 + frag[t]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (decltype(with_bias)::value) rowsum[i] += sum_bf16x8(af[i]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[i], bf[j], acc[i][j]);
+            }
+        }
+    };
+    const bool full_tile = wave_has_work && ni == 4 && nj == 2;                 // wave-uniform
+    const int n_full = (nrows % WG1_STAGE_PTS == 0) ? n_st : n_st - 1;          // stages whose 32 points all exist
+
     // ring: stages st+1 .. st+3 are in flight while st is consumed.  vmcnt retires in order: "at most 4 * (younger
     // stages in flight) outstanding" = this wave's pieces of st have landed
 #pragma unroll
     for (int st = 0; st < WG1_STAGES - 1; ++st)
         if (st < n_st) issue(st);
-    for (int st = 0; st < n_st; ++st) {
+    auto enter = [&](int st) {
         if (st + 2 < n_st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (st + 1 < n_st) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();        // every wave's pieces landed; everybody is done with stage st-1, whose slot is reused now
         if (st + WG1_STAGES - 1 < n_st) issue(st + WG1_STAGES - 1);
-        compute(st);
-    }
+    };
+    // one loop per variant (wave-uniform choice): both bodies inside one loop cost 116 spilled VGPRs
+    int st = 0;
+    if (full_tile && want_bias) for (; st < n_full; ++st) { enter(st); compute_full(st, std::true_type{}); }
+    else if (full_tile) for (; st < n_full; ++st) { enter(st); compute_full(st, std::false_type{}); }
+    for (; st < n_st; ++st) { enter(st); compute(st); }
 
     // acc[i][j][r] at lane (col = lane&31, hf) = dW[wave_n*128 + 32*i + d32row(r, hf)][wave_k*64 + 32*j + col]
     float* out = a.partial + (size_t)chunk * N_PARAMS;
