@@ -840,10 +840,11 @@ __global__ void wgrad_fold_kernel(const float* __restrict__ params, const float*
 static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
     // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU).  fp32: 14 jobs x
     // 128 = 7 x 256 (the 8 full-width jobs x 128 = 4 x 256).  Split-bf16 (12 jobs: folded feature layer, alpha rides on
-    // the h7 job): 12 x 64 = 3 x 256; mixed (13 jobs): 13 x 59 = 767.  (Measured for the 12 jobs: 64 and 128 chunks run
+    // the h7 job): 12 x 64 = 3 x 256; bf16 operands (13 jobs): 13 x 39 = 507 = 2 x 256 - 5 (59 chunks = 3 rounds: GEMM +1 %,
+    // reduction 0.055 instead of 0.043 ms).  (Measured for the 12 jobs: 64 and 128 chunks run
     // the GEMM in the same time, 96 — a partial last round — is 10 % slower, and the partial-sum traffic of the
     // deterministic reduction halves with 64: 0.113 -> 0.057 ms per launch.)  Small inputs get >= 256-point chunks.
-    long n = n_jobs == 14 ? 128 : (n_jobs == 13 ? 59 : 64);
+    long n = n_jobs == 14 ? 128 : (n_jobs == 13 ? 39 : 64);
     const long cap = (P + 255) / 256;
     if (n > cap) n = cap;
     if (n < 1) n = 1;

@@ -123,22 +123,29 @@ __device__ inline unsigned short bf16_rne(float x) {
     return __builtin_bit_cast(unsigned short, (__bf16)x);
 }
 
-// W' = Wv[:, :256] Wf and b' = Wv[:, :256] bf + bv (nerf_common.h, folded feature layer): fp64 accumulation
+// W' = Wv[:, :256] Wf and b' = Wv[:, :256] bf + bv (nerf_common.h, folded feature layer): fp64 accumulation.  Eight lanes
+// share one output (contraction index i = part, part + 8, ...; fp64 shuffle reduction): 263 k threads with 32 dependent
+// loads each instead of 33 k threads with 256 (the kernel runs after every optimizer step: 21 -> ~4 us).
 __global__ void derive_folded_kernel(const float* __restrict__ p, float* __restrict__ derived) {
     constexpr Canon c = canon();
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N_DERIVED) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int part = tid & 7;
+    const int idx = min(tid >> 3, N_DERIVED - 1);        // (every lane takes part in the shuffles)
+    double acc = 0.0;
     if (idx < WV * W) {
         const int k = idx / W, j = idx % W;
-        double acc = 0.0;
-        for (int i = 0; i < W; ++i) acc += (double)p[c.wv + k * (W + IN_DIR) + i] * (double)p[c.wf + i * W + j];
-        derived[idx] = (float)acc;
+#pragma unroll 8
+        for (int i = part; i < W; i += 8) acc += (double)p[c.wv + k * (W + IN_DIR) + i] * (double)p[c.wf + i * W + j];
     } else {
         const int k = idx - WV * W;
-        double acc = (double)p[c.bv + k];
-        for (int i = 0; i < W; ++i) acc += (double)p[c.wv + k * (W + IN_DIR) + i] * (double)p[c.bf + i];
-        derived[idx] = (float)acc;
+#pragma unroll 8
+        for (int i = part; i < W; i += 8) acc += (double)p[c.wv + k * (W + IN_DIR) + i] * (double)p[c.bf + i];
+        if (part == 0) acc += (double)p[c.bv + k];
     }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (part == 0 && (tid >> 3) < N_DERIVED) derived[idx] = (float)acc;
 }
 __device__ inline float param_or_derived(const float* canon_params, const float* derived, int src) {
     return src < N_PARAMS ? canon_params[src] : derived[src - N_PARAMS];
@@ -239,7 +246,7 @@ __global__ void pack3_hi_only_kernel(float* __restrict__ packed) {
 hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream) {
     const int threads = 256;
     float* derived = packed + P3_DERIVED;
-    hipLaunchKernelGGL(derive_folded_kernel, dim3((N_DERIVED + threads - 1) / threads), dim3(threads), 0, stream, canon_params, derived);
+    hipLaunchKernelGGL(derive_folded_kernel, dim3((8 * N_DERIVED + threads - 1) / threads), dim3(threads), 0, stream, canon_params, derived);
     hipLaunchKernelGGL(pack3_params_kernel, dim3((2 * P3B_END + threads - 1) / threads), dim3(threads), 0, stream,
                        canon_params, (const float*)derived, reinterpret_cast<unsigned short*>(packed));
     hipLaunchKernelGGL(pack3_small_kernel, dim3((PACKED_FLOATS - SM_BIAS + threads - 1) / threads), dim3(threads), 0, stream,

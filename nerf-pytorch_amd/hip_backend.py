@@ -569,7 +569,7 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
         with _timed("wgrad_kernel(narrow jobs)", (FLOP_WGRAD_PER_POINT - FLOP_WGRAD_BIG_PER_POINT) * P, BYTES_WGRAD_SMALL_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 2, *tail), "nerf_field_wgrad_phase")
     # chunks of partial sums the reduction reads (csrc/field_bwd.hip, wgrad_chunks)
-    n_chunks = min(59 if bf16_gemm else (64 if b3 else 128), max(1, (P + 255) // 256))
+    n_chunks = min(39 if bf16_gemm else (64 if b3 else 128), max(1, (P + 255) // 256))
     with _timed("wgrad_reduce_kernel", 0.0, 4.0 * N_PARAMS * (n_chunks + 1)):
         _check(L.nerf_field_wgrad_phase(*args, 4, *tail), "nerf_field_wgrad_phase")
     return grad

@@ -29,6 +29,8 @@ VARIANTS = {
     # paired bf16 stores without their per-lane predicate (exec-mask branch around every store): valid for P % 128 == 0 only
     "nopred": lambda d: (patch(os.path.join(d, "field_fwd_bf16.hip"), "        if (pair_valid) nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);", "        nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);"),
                          patch(os.path.join(d, "field_device_bf16.h"), "            if (pair_valid) nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word);", "            nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word);")),
+    # bf16 weight-gradient GEMM: 39 instead of 59 point chunks (13 jobs x 39 = 507 workgroups = 2 rounds)
+    "wg1_39": lambda d: patch(os.path.join(d, "field_bwd.hip"), "(n_jobs == 13 ? 59 : 64)", "(n_jobs == 13 ? 39 : 64)"),
     # dgrad: no delta stores
     "dgrad_nostore": lambda d: patch(os.path.join(d, "field_bwd_bf16.hip"), "    auto store_q = [&](auto part, size_t off) {\n        if (!valid) return;", "    auto store_q = [&](auto part, size_t off) {\n        return;"),
     # weight-gradient GEMM: the two waves of a SIMD in anti-phase (waves 0-3 MFMA then stage, waves 4-7 stage then MFMA)
