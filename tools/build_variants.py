@@ -31,6 +31,8 @@ VARIANTS = {
                          patch(os.path.join(d, "field_device_bf16.h"), "            if (pair_valid) nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word);", "            nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word);")),
     # bf16 weight-gradient GEMM: 39 instead of 59 point chunks (13 jobs x 39 = 507 workgroups = 2 rounds)
     "wg1_39": lambda d: patch(os.path.join(d, "field_bwd.hip"), "(n_jobs == 13 ? 59 : 64)", "(n_jobs == 13 ? 39 : 64)"),
+    # field kernels without their weight DMA after the first chunks (WRONG results: timing only -- what the L2->LDS stream costs)
+    "nodma": lambda d: patch(os.path.join(d, "field_device.h"), "        if (nf > 0) dma_chunk<NWAVES>(next_src, lds + (buf ^ 1) * CHUNK_FLOATS, nf, wave, lane);", "        if (nf > 0 && c_next < 2) dma_chunk<NWAVES>(next_src, lds + (buf ^ 1) * CHUNK_FLOATS, nf, wave, lane);"),
     # dgrad: no delta stores
     "dgrad_nostore": lambda d: patch(os.path.join(d, "field_bwd_bf16.hip"), "    auto store_q = [&](auto part, size_t off) {\n        if (!valid) return;", "    auto store_q = [&](auto part, size_t off) {\n        return;"),
     # weight-gradient GEMM: the two waves of a SIMD in anti-phase (waves 0-3 MFMA then stage, waves 4-7 stage then MFMA)
