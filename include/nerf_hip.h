@@ -155,11 +155,12 @@ int nerf_field_fwd16_bf16x3(const float* packed3, const float* rays, int ray_str
 int nerf_debug_pack16_table(int* out_host);
 /* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  dgrad also leaves a tiled
  * copy of d_raw inside delta, which is what wgrad contracts with: nerf_field_wgrad_bf16x3 must be given the delta
- * buffer of nerf_field_dgrad_bf16x3 for the same d_raw (its own d_raw argument is not read).  All 14 weight-gradient
- * jobs, full-width and narrow, run on the split-bf16 MFMA kernel.
+ * buffer of nerf_field_dgrad_bf16x3 for the same d_raw (its own d_raw argument is not read).  All weight-gradient
+ * jobs, full-width and narrow, run on one tile kernel (12 after the folded feature layer and the alpha rider; 13 on bf16
+ * operands).
  * delta_bf16 != 0: the chain is computed exactly as with 0 (3-term products, fp32 deltas in registers), but the deltas
  * are WRITTEN rounded to bf16 (same tiles, 2-byte elements) for the bf16-operand weight-gradient GEMM: pair it with an
- * act buffer saved with bf16_save != 0 and with nerf_field_wgrad_phase(datapath = 2).  Only the operands of the
+ * act buffer saved with bf16_save != 0 and with nerf_field_wgrad_phase(datapath = 2 / 4).  Only the operands of the
  * weight-gradient contraction are rounded (zero-mean, averaged over all points), never the delta chain. */
 int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
                             float* delta, int delta_bf16, void* stream);
@@ -170,12 +171,13 @@ int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d
  * nerf_pack_params_bf16x3.  `feature` and its delta are therefore neither computed nor saved; the weight-gradient entry
  * points take the canonical parameter vector `params` (the one that was packed) and produce the gradients of Wf, bf and
  * Wv[:, :256] from G = delta_hv^T h7:  dWv[:, :256] = G Wf^T + dbv bf^T,  dWf = Wv[:, :256]^T G,  dbf = Wv[:, :256]^T dbv. */
-/* ---- mixed-precision training variant: the forward is the split-bf16 datapath unchanged (same raw, bit for bit), but
- * what it saves for the backward is rounded to bf16 (same tiles, 2-byte elements), and the backward runs on single
- * bf16 MFMA products with fp32 accumulation: dgrad = W_hi^T * delta_hi, wgrad = delta_bf16^T * x_bf16 streamed straight
- * from HBM into the MFMA (no conversion).  Halves the saved-activation traffic and cuts the backward's matrix work to
- * a third; rendered outputs are identical to bf16x3, gradients carry bf16 rounding noise (~2^-9 relative per element,
- * cosine to the fp64 gradient >= 0.999).  act / delta of one evaluation must stay within this variant. */
+/* ---- bf16 operand storage and the mixed-precision training variant.  nerf_field_fwd_mixed is the 32-point split-bf16
+ * forward (same raw as nerf_field_fwd_bf16x3, bit for bit) saving its rows rounded to bf16 (32-point tiles, 2-byte
+ * elements); nerf_field_wgrad_mixed contracts bf16 operands (delta_bf16^T * x_bf16, exact products, fp32 accumulation)
+ * streamed from HBM into the MFMA without conversion.  Together with nerf_field_dgrad_bf16x3(delta_bf16 = 1) — the
+ * unchanged 3-term delta chain writing bf16 deltas — that is the default split-bf16 training path of the host code.
+ * nerf_field_dgrad_mixed instead runs the delta chain itself on single bf16 products (W_hi^T * delta_hi): the
+ * mixed-precision option, whose gradients carry bf16 rounding noise (cosine to the fp64 gradient >= 0.999). */
 int nerf_field_fwd_mixed(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                          int n_samples, float* raw, float* act, void* stream);
 int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
@@ -183,7 +185,7 @@ int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* 
 int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate, const float* params, void* stream);
 /* nerf_field_wgrad / nerf_field_wgrad_bf16x3 split into their three launches so that a profiler can bracket each:
- * phases bit 0 = the eight full-width (256x256) jobs (bf16x3: all 14 jobs), bit 1 = the six narrow jobs (fp32 datapath
+ * phases bit 0 = the eight full-width (256x256) jobs (datapaths 1-4: all jobs), bit 1 = the six narrow jobs (fp32 datapath
  * only), bit 2 = reduction of the per-chunk partial gradients into grad.  Calling it with phases 1, 2, 4 in that order
  * equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
