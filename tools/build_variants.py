@@ -33,6 +33,8 @@ VARIANTS = {
     "wg1_39": lambda d: patch(os.path.join(d, "field_bwd.hip"), "(n_jobs == 13 ? 59 : 64)", "(n_jobs == 13 ? 39 : 64)"),
     # field kernels without their weight DMA after the first chunks (WRONG results: timing only -- what the L2->LDS stream costs)
     "nodma": lambda d: patch(os.path.join(d, "field_device.h"), "        if (nf > 0) dma_chunk<NWAVES>(next_src, lds + (buf ^ 1) * CHUNK_FLOATS, nf, wave, lane);", "        if (nf > 0 && c_next < 2) dma_chunk<NWAVES>(next_src, lds + (buf ^ 1) * CHUNK_FLOATS, nf, wave, lane);"),
+    # weight DMA without saving / restoring M0 around every 4 KiB (M0 declared clobbered instead)
+    "dma_m0": lambda d: dma_m0(d),
     # dgrad: no delta stores
     "dgrad_nostore": lambda d: patch(os.path.join(d, "field_bwd_bf16.hip"), "    auto store_q = [&](auto part, size_t off) {\n        if (!valid) return;", "    auto store_q = [&](auto part, size_t off) {\n        return;"),
     # weight-gradient GEMM: the two waves of a SIMD in anti-phase (waves 0-3 MFMA then stage, waves 4-7 stage then MFMA)
@@ -42,6 +44,25 @@ VARIANTS = {
     "wg_prio_mfma": lambda d: wg_prio(d, True),
     "wg_prio_stage": lambda d: wg_prio(d, False),
 }
+
+def dma_m0(d):
+    f = os.path.join(d, "field_device.h")
+    src = open(f).read()
+    old4 = src[src.index("__device__ inline void dma_4k("):src.index("// every wave copies one contiguous span of the chunk")]
+    new4 = '''__device__ inline void dma_4k(const float* gsrc_lane, unsigned lds_dst_uniform) {
+    asm volatile(
+        "s_mov_b32 m0, %1\\n\\t"
+        "s_nop 0\\n\\t"
+        "global_load_lds_dwordx4 %0, off\\n\\t"
+        "global_load_lds_dwordx4 %0, off offset:1024\\n\\t"
+        "global_load_lds_dwordx4 %0, off offset:2048\\n\\t"
+        "global_load_lds_dwordx4 %0, off offset:3072"
+        :
+        : "v"(gsrc_lane), "s"(lds_dst_uniform)
+        : "memory", "m0");
+}
+'''
+    open(f, "w").write(src.replace(old4, new4))
 
 def wg_anti(d, prio):
     # (an if/else with both orders spills 1.6k VGPRs; two predicated copies of the staging around one compute do not)
