@@ -22,8 +22,18 @@ Workloads (BASELINE.json `configs`; synthetic, seeded: workloads.py):
                    perturb=0) of a pose_spherical spiral; frames are dealt round-robin over the ranks, no collective
     --strong       (configs[3] as strong scaling): the GLOBAL batch is 32,768 rays, random draws made once for the
                    full batch from a shared seed and sliced per rank
+The default command (``python bench.py`` = 1 GPU, lego training step) also runs SHORT legs of the other single-GPU
+configurations -- fern training step, render_only frames, the 32,768-ray batch -- and reports them under `configs`, each
+with its own north-star gate (PSNR delta of our image vs the reference's image on that configuration's fixture).
 Inputs are resident in HBM before the timed region.  `value` is timed with the per-kernel event timer OFF; the per-kernel
 table (`kernels`, `roofline`) comes from a separate pass over the same steps.  Prints ONE JSON line (rank 0).
+
+`roofline`: `achieved` = ALGORITHMIC FLOP of the reference's layer stack (1,186,816 per point and forward
+evaluation: run_nerf_helpers.py:96-119) processed by one launch of the dominant kernel / its average launch time, `frac` =
+achieved / the dense MFMA peak of the arithmetic type the datapath computes in (bf16: 2.5 PFLOP/s; f32: 157.3 TFLOP/s).
+The split-bf16 datapath issues three bf16 MFMAs per product and executes one folded layer less than the reference; the
+fraction of the MFMA pipe its instructions occupy is reported next to it as `mfma_busy_frac` and is NOT the roofline
+fraction.
 """
 import argparse
 import json
@@ -38,15 +48,11 @@ if ROOT not in sys.path:
 N_RAND = 4096
 N_SAMPLES, N_IMPORTANCE = 64, 128
 POINTS_PER_RAY = N_SAMPLES + N_SAMPLES + N_IMPORTANCE
-FLOP_FWD_PER_RAY = 2 * 593408 * POINTS_PER_RAY                                   # 303.82 MFLOP
-FLOP_TRAIN_PER_RAY = 2 * (593408 + 557696 + 593408) * POINTS_PER_RAY             # 893.19 MFLOP
-# the split-bf16 / mixed datapaths EXECUTE one 256x256 layer less per kernel (feature_linear folded into the view branch,
-# csrc/nerf_common.h); MFMA-issue fractions are priced on the executed work, rays/s on the reference's step
-FOLD_FLOP = 2 * 256 * 256 * POINTS_PER_RAY
-EXEC_FWD_PER_RAY = {"fp32": FLOP_FWD_PER_RAY, "bf16x3": FLOP_FWD_PER_RAY - FOLD_FLOP, "mixed": FLOP_FWD_PER_RAY - FOLD_FLOP}
-EXEC_TRAIN_PER_RAY = {"fp32": FLOP_TRAIN_PER_RAY, "bf16x3": FLOP_TRAIN_PER_RAY - 3 * FOLD_FLOP, "mixed": FLOP_TRAIN_PER_RAY - 3 * FOLD_FLOP}
+MAC_FWD, MAC_DGRAD, MAC_WGRAD, MAC_FOLD = 593408, 557696, 593408, 65536        # per sample point
+FLOP_FWD_PER_RAY = 2 * MAC_FWD * POINTS_PER_RAY                                  # 303.82 MFLOP
+FLOP_TRAIN_PER_RAY = 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) * POINTS_PER_RAY      # 893.19 MFLOP
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = vector rate; exact-fp32 datapath
-PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA; the bf16x3 datapath issues 3 MFMA FLOPs per algorithmic FLOP
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (~6.3 TB/s achievable, MI355X_MICROARCH.md)
 DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products W_hi x_hi + W_hi x_lo + W_lo x_hi in the forward and the delta chain, f32 "
                                         "accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are stored as "
@@ -74,6 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--no-gate", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other single-GPU configurations")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no GPU work): used by the CPU test of the N > 1 launch path")
@@ -144,11 +151,12 @@ def cpu_baseline(cfg_name, n_rays=512):
                       f"{os.cpu_count()} host CPUs)"}
 
 
-def rocm_eager_baseline(cfg_name, dev, n_rays, steps=3):
+def rocm_eager_baseline(cfg_name, dev, n_rays, steps=5):
     """Baseline leg: the reference's own algorithm as eager PyTorch-ROCm ops on this GPU (the oracle's torch ops with CUDA
     tensors = what run_nerf.py executes after set_default_tensor_type('torch.cuda.FloatTensor'), run_nerf.py:876), same
     workload shape, training step and no_grad render.  It is the denominator of the north-star '>= 10x' target; like
-    cpu_baseline it is timed beside the product, never part of `value`."""
+    cpu_baseline it is timed beside the product, never part of `value`.  Every step is timed on its own (synchronised):
+    the rate is that of the MEDIAN step, and the spread is reported."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as orc
@@ -179,41 +187,65 @@ def rocm_eager_baseline(cfg_name, dev, n_rays, steps=3):
         with torch.no_grad():
             rays = orc.assemble_render_rays(cfg["H"], cfg["W"], K, batch[0], batch[1], cfg["ndc"], cfg["near"], cfg["far"])
             orc.trace_rays(rays, Pc, Pf, N_SAMPLES, N_IMPORTANCE, perturb=0.0, white_bkgd=cfg["white_bkgd"], retraw=True)
-    res = {}
+    res, spread = {}, {}
     for name, fn in (("train", train), ("infer", infer)):
         fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        times = []
         for _ in range(steps):
+            t0 = time.perf_counter()
             fn()
-        torch.cuda.synchronize()
-        res[name] = n_rays * steps / (time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        res[name] = n_rays / times[len(times) // 2]
+        spread[name] = {"fastest_step_rays_per_s": n_rays / times[0], "slowest_step_rays_per_s": n_rays / times[-1]}
     del Pc, Pf, opt
     torch.cuda.empty_cache()
     return {"train_rays_per_s": res["train"], "infer_rays_per_s": res["infer"], "unit": "rays/s", "steps": steps,
+            "rate_of": "median step", "spread": spread,
             "what": f"reference algorithm as eager PyTorch-ROCm ops on this GPU (oracle ops on cuda tensors), {n_rays} rays x (64+128), "
-                    f"{cfg_name} workload, torch {torch.__version__}"}
+                    f"{cfg_name} workload, torch {torch.__version__}, timed after the product legs (warm GPU)"}
 
 
 # --------------------------------------------------------------------------------------------- per-kernel table / roofline
-def kernel_table(kern, precision):
-    """per timed kernel: average launch time, algorithmic TFLOP/s and GB/s, and its fraction of both roofs"""
-    issued = 1.0 if precision == "fp32" else 3.0        # bf16x3 issues every algorithmic FLOP three times on the bf16 pipe
-    peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+def _kernel_class(name):
+    """(MFMAs issued per executed product, executed / algorithmic MAC ratio, arithmetic peak) of a timed kernel"""
+    fwd = name.startswith(("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd16r_kernel"))
+    if name.startswith(("field_fwd_kernel", "field_dgrad_kernel", "wgrad256_kernel", "wgrad_kernel")):
+        return 1.0, 1.0, PEAK_FP32_MFMA_TFLOPS                                  # exact-fp32 datapath
+    if fwd:
+        return 3.0, (MAC_FWD - MAC_FOLD) / MAC_FWD, PEAK_BF16_MFMA_TFLOPS
+    if name.startswith("field_dgrad3_kernel"):
+        return (1.0 if "<mixed>" in name else 3.0), (MAC_DGRAD - MAC_FOLD) / MAC_DGRAD, PEAK_BF16_MFMA_TFLOPS
+    if name.startswith("wgrad1_kernel"):
+        return 1.0, (MAC_WGRAD - MAC_FOLD) / MAC_WGRAD, PEAK_BF16_MFMA_TFLOPS
+    if name.startswith("wgrad3_256_kernel"):
+        return 3.0, (MAC_WGRAD - MAC_FOLD) / MAC_WGRAD, PEAK_BF16_MFMA_TFLOPS
+    return 1.0, 1.0, PEAK_FP32_MFMA_TFLOPS
+
+
+def kernel_table(kern):
+    """per timed kernel: average launch time; ALGORITHMIC TFLOP/s (the reference's layer stack) and its fraction of the
+    arithmetic type's dense MFMA peak (`algorithmic_frac`, the roofline fraction of SURVEY 8d); the fraction of the MFMA
+    pipe its issued instructions occupy (`mfma_busy_frac`: executed work x MFMAs per product); algorithmic GB/s vs HBM"""
     out = {}
     for k, v in kern.items():
         sec = v["ms"] * 1e-3
-        fp32_kernel = precision == "fp32" or k.startswith(("wgrad_kernel", "wgrad_reduce"))
-        k_issued, k_peak = (1.0, PEAK_FP32_MFMA_TFLOPS) if fp32_kernel else (issued, peak)
-        if k.startswith(("field_dgrad3_kernel<mixed>", "wgrad1_kernel")):      # single bf16 MFMA per product
-            k_issued = 1.0
-        tfl = v["flops"] / sec / 1e12
+        issued, exec_ratio, peak = _kernel_class(k)
+        exec_tfl = v["flops"] / sec / 1e12                      # hip_backend passes the EXECUTED flops of the launch
+        alg_tfl = exec_tfl / exec_ratio
         gbs = v["bytes"] / sec / 1e9
         out[k] = {"launches": v["launches"], "avg_ms": v["ms"] / v["launches"], "total_ms": v["ms"],
-                  "algorithmic_tflops": tfl, "mfma_frac": tfl * k_issued / k_peak, "mfma_peak_tflops": k_peak,
-                  "mfma_flops_per_algorithmic_flop": k_issued,
+                  "algorithmic_tflops": alg_tfl, "algorithmic_frac": alg_tfl / peak, "mfma_peak_tflops": peak,
+                  "mfma_busy_frac": exec_tfl * issued / peak, "mfma_per_product": issued, "executed_over_algorithmic": exec_ratio,
                   "algorithmic_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBS}
     return out
+
+
+def _brief(tab):
+    return {k: {"avg_ms": v["avg_ms"], "algorithmic_frac": v["algorithmic_frac"], "mfma_busy_frac": v["mfma_busy_frac"],
+                "hbm_frac": v["hbm_frac"]} for k, v in tab.items()}
 
 
 def pmc_traffic(kernel_name, precision):
@@ -221,7 +253,7 @@ def pmc_traffic(kernel_name, precision):
     passes; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the
     process, so this is the profile of the same command committed under profiles/ (None if absent)."""
     tag = {"bf16x3": "bf16x3_", "mixed": "mixed_"}.get(precision, "")
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}pmc_summary.csv")
         if os.path.exists(path):
             break
@@ -237,7 +269,7 @@ def pmc_traffic(kernel_name, precision):
         tmpl = base.split("<")[1].split(">")[0] if "<" in base else ""
         if base.split("<")[0].split("(")[0] != key:
             continue
-        if key in ("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd_kernel"):
+        if key in ("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd16r_kernel", "field_fwd_kernel"):
             want = "2" if "<save bf16>" in kernel_name else ("1" if "<save" in kernel_name else "0")
             if {"false": "0", "true": "1", "": "0"}.get(tmpl, tmpl) != want:
                 continue
@@ -255,18 +287,19 @@ def pmc_traffic(kernel_name, precision):
 
 
 def roofline_of(table):
-    """roofline object of the dominant kernel (largest share of the timed region), bound = the roof it sits closer to"""
+    """roofline object of the dominant kernel (largest share of the timed region): bound = the roof it sits closer to.
+    `frac` is ALGORITHMIC work / peak (module docstring); the pipe occupancy of the issued MFMAs is `mfma_busy_frac`."""
     if not table:
         return None
     name, k = max(table.items(), key=lambda kv: kv[1]["total_ms"])
-    if k["hbm_frac"] > k["mfma_frac"]:
+    if k["hbm_frac"] > k["mfma_busy_frac"]:
         return {"bound": "hbm", "kernel": name, "achieved": k["algorithmic_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": k["hbm_frac"], "traffic": None, "avg_launch_ms": k["avg_ms"],
-                "also": {"mfma_frac": k["mfma_frac"], "algorithmic_tflops": k["algorithmic_tflops"]}}
-    return {"bound": "mfma", "kernel": name, "achieved": k["algorithmic_tflops"] * k["mfma_flops_per_algorithmic_flop"],
-            "peak": k["mfma_peak_tflops"], "unit": "TFLOP/s", "frac": k["mfma_frac"], "traffic": None,
-            "algorithmic_tflops": k["algorithmic_tflops"],
-            "mfma_flops_per_algorithmic_flop": k["mfma_flops_per_algorithmic_flop"], "avg_launch_ms": k["avg_ms"],
+                "also": {"algorithmic_tflops": k["algorithmic_tflops"], "mfma_busy_frac": k["mfma_busy_frac"]}}
+    return {"bound": "mfma", "kernel": name, "achieved": k["algorithmic_tflops"], "peak": k["mfma_peak_tflops"], "unit": "TFLOP/s",
+            "frac": k["algorithmic_frac"], "traffic": None, "avg_launch_ms": k["avg_ms"],
+            "mfma_busy_frac": k["mfma_busy_frac"], "mfma_per_product": k["mfma_per_product"],
+            "executed_over_algorithmic": k["executed_over_algorithmic"],
             "also": {"hbm_frac": k["hbm_frac"], "algorithmic_GBps": k["algorithmic_GBps"]}}
 
 
@@ -281,8 +314,10 @@ def rccl_version():
 
 # --------------------------------------------------------------------------------------------- main
 def dry_run(args):
-    """Launcher / process-group plumbing without GPU work (CPU test of the N > 1 path): rendezvous, sharding arithmetic,
-    one all-reduce over a flat bucket of the gradient's size, max-over-ranks timing, rank-0 JSON line."""
+    """Launcher / process-group plumbing without GPU work (CPU test of the N > 1 path): rendezvous, sharding arithmetic
+    (weak: N_rand per rank; strong: 32768 / world; render_only: 40 frames dealt round-robin), one all-reduce over a flat
+    bucket of the gradient's size, the rank census and parameter-hash check of the real run, max-over-ranks timing,
+    rank-0 JSON line."""
     import torch
     import torch.distributed as dist
     from nerf_pytorch_amd import parallel
@@ -291,6 +326,7 @@ def dry_run(args):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
     n_global = 32768 if args.strong else args.rays * world
     lo, hi = parallel.shard_slice(n_global, rank, world)
+    frames = parallel.frames_of_rank(40, rank, world)
     bucket = torch.full((595844,), float(rank + 1))
     t0 = time.perf_counter()
     if world > 1:
@@ -301,14 +337,174 @@ def dry_run(args):
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     assert float(bucket[0]) == world * (world + 1) / 2
+    seen = parallel.ranks_seen()
+    same = parallel.ranks_identical([torch.arange(8.0)])
+    counts = [None] * world
+    if world > 1:
+        dist.all_gather_object(counts, (hi - lo, len(frames)))
+    else:
+        counts = [(hi - lo, len(frames))]
     if rank == 0:
         print(json.dumps({"metric": "dry run (launcher plumbing only)", "value": None, "unit": "rays/s", "n_gpus": world,
                           "world_size": dist.get_world_size() if world > 1 else 1, "backend": args.backend or "gloo",
                           "scaling": "strong" if args.strong else "weak", "rays_per_rank": hi - lo,
-                          "global_batch_rays": n_global, "dry_run": True}))
+                          "global_batch_rays": n_global, "rays_of_all_ranks": sum(c[0] for c in counts),
+                          "frames_of_all_ranks": sum(c[1] for c in counts), "rccl_ranks_seen": seen, "ranks_identical": same,
+                          "dry_run": True}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class Session:
+    """Everything one configuration needs: the two networks on the scene's weights, the fused optimizer, the render kwargs
+    create_nerf builds (run_nerf.py:237-259), a pool of HBM-resident ray batches, and the step functions."""
+
+    def __init__(self, config, args, rank, world, dev, n, strong):
+        import numpy as np
+        import torch
+        import nerf_pytorch_amd as npa
+        import workloads as wl
+        from nerf_pytorch_amd import parallel
+        self.npa, self.torch, self.wl, self.np = npa, torch, wl, np
+        self.config, self.args, self.rank, self.world, self.dev, self.strong = config, args, rank, world, dev, strong
+        cfg = self.cfg = wl.LEGO if config == "lego" else wl.FERN
+        self.H, self.W, self.K = cfg["H"], cfg["W"], wl.intrinsics(cfg)
+        if strong:
+            self.n_global = 32768
+            self.lo, self.hi = parallel.shard_slice(self.n_global, rank, world)
+            self.n = self.hi - self.lo
+        else:
+            self.n = n
+            self.n_global = n * world
+            self.lo, self.hi = rank * n, (rank + 1) * n
+        self.Pc, self.Pf = wl.scene_params()
+        self.kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        self.net_c, self.net_f = npa.NeRF(**self.kw).to(dev), npa.NeRF(**self.kw).to(dev)
+        self.net_c.load_state_dict(self.Pc)
+        self.net_f.load_state_dict(self.Pf)
+        parallel.broadcast_parameters([self.net_c, self.net_f])
+        # torch.optim.Adam semantics (run_nerf.py:207), fused over the two flat parameter vectors (state_dict compatible)
+        self.optimizer = npa.FlatAdam(list(self.net_c.parameters()) + list(self.net_f.parameters()), lr=5e-4, betas=(0.9, 0.999))
+        self.kwargs_train = dict(network_query_fn=None, perturb=1.0, N_importance=N_IMPORTANCE, network_fine=self.net_f,
+                                 N_samples=N_SAMPLES, network_fn=self.net_c, use_viewdirs=True, white_bkgd=cfg["white_bkgd"],
+                                 raw_noise_std=cfg["raw_noise_std"], ndc=cfg["ndc"], lindisp=False, near=cfg["near"], far=cfg["far"])
+        self.kwargs_test = dict(self.kwargs_train, perturb=False, raw_noise_std=0.)
+        # synthetic data, resident in HBM: a pool of ray batches + targets.  weak: rank-dependent seeds; strong: one global
+        # batch per pool slot, every rank takes its slice (and the random draws are made once for the full batch, below)
+        self.pool = pool = 8 if not strong else 4
+        make = wl.lego_batch if config == "lego" else wl.fern_batch
+        if strong:
+            self.batches = [make(self.n_global, seed=100 + i)[:, self.lo:self.hi].contiguous().to(dev) for i in range(pool)]
+            self.targets = [torch.rand(self.n_global, 3, generator=torch.Generator().manual_seed(77 + i))[self.lo:self.hi].to(dev)
+                            for i in range(pool)]
+        else:
+            self.batches = [make(self.n, seed=1000 * rank + i).to(dev) for i in range(pool)]
+            gen = torch.Generator().manual_seed(77 + rank)
+            self.targets = [torch.rand(self.n, 3, generator=gen).to(dev) for _ in range(pool)]
+        self.strong_gen = torch.Generator(device=dev).manual_seed(4242) if strong else None
+        self.sync = parallel.GradientSync([self.net_c, self.net_f]) if world > 1 else None
+        # render_only (configs[4]): frames of a pose_spherical spiral (load_blender.py:75), dealt round-robin
+        self.fr = args.frame
+        fr_focal = cfg["focal"] * self.fr / cfg["W"]
+        self.Kf = np.array([[fr_focal, 0, 0.5 * self.fr], [0, fr_focal, 0.5 * self.fr], [0, 0, 1]])
+        self.spiral = [wl.pose_spherical(a, -30.0, 4.0) for a in np.linspace(-180, 180, 40 + 1)[:-1]]
+
+    def strong_randoms(self):
+        """random draws of the GLOBAL batch in the reference's order from a generator every rank seeds identically;
+        each rank keeps its slice, so the N-GPU step computes exactly the 1-GPU N_rand=32768 step (SURVEY 8d-4)"""
+        torch, cfg, dev, g = self.torch, self.cfg, self.dev, self.strong_gen
+        r = {"t_rand": torch.rand((self.n_global, N_SAMPLES), device=dev, generator=g)}
+        if cfg["raw_noise_std"] > 0:
+            r["noise_c"] = torch.randn((self.n_global, N_SAMPLES), device=dev, generator=g)
+        r["u"] = torch.rand((self.n_global, N_IMPORTANCE), device=dev, generator=g)
+        if cfg["raw_noise_std"] > 0:
+            r["noise_f"] = torch.randn((self.n_global, N_SAMPLES + N_IMPORTANCE), device=dev, generator=g)
+        return {k: v[self.lo:self.hi].contiguous() for k, v in r.items()}
+
+    def train_step(self, i):
+        npa = self.npa
+        batch_rays, target_s = self.batches[i % self.pool], self.targets[i % self.pool]
+        extra = {"randoms": self.strong_randoms()} if self.strong else {}
+        rgb, disp, acc, extras = npa.render(self.H, self.W, self.K, chunk=self.args.chunk, rays=batch_rays, verbose=False, retraw=True,
+                                            **self.kwargs_train, **extra)
+        self.optimizer.zero_grad()
+        loss = npa.img2mse(rgb, target_s) + npa.img2mse(extras["rgb0"], target_s)
+        loss.backward()       # (the coarse bucket's all-reduce starts inside, under the fine network's backward)
+        if self.sync is not None:
+            self.sync.finish()
+        self.optimizer.step()
+
+    def infer_step(self, i):
+        with self.torch.no_grad():
+            self.npa.render(self.H, self.W, self.K, chunk=self.args.chunk, rays=self.batches[i % self.pool], retraw=True, **self.kwargs_test)
+
+    def frame_step(self, i):
+        frame_id = (self.rank + i * self.world) % len(self.spiral)      # parallel.frames_of_rank dealing: frame f -> rank f mod G
+        with self.torch.no_grad():
+            self.npa.render(self.fr, self.fr, self.Kf, chunk=self.args.chunk, c2w=self.spiral[frame_id][:3, :4], **self.kwargs_test)
+
+    def step_fn(self, mode):
+        return {"train": self.train_step, "infer": self.infer_step, "render_only": self.frame_step}[mode]
+
+    def rays_per_step(self, mode):
+        return self.fr * self.fr if mode == "render_only" else self.n
+
+    def gate(self, precision, with_operands=True):
+        """the north-star acceptance gate measured in this run: our image vs the image the REAL reference rendered for the
+        same rays / weights (committed fixture tests/golden/gate_<config>.npz, generated by tests/golden/make_golden.py
+        --round2 from /root/reference), against a teacher-scene target"""
+        npa, torch, np, wl, dev = self.npa, self.torch, self.np, self.wl, self.dev
+        hb = npa.hip_backend
+        gpath = os.path.join(ROOT, "tests", "golden", f"gate_{self.config}.npz")
+        if not os.path.exists(gpath):
+            return None
+        gold = np.load(gpath)
+        gbatch = (wl.lego_batch(1024, seed=31) if self.config == "lego" else wl.fern_batch(1024, seed=32)).to(dev)
+        # the timed steps have trained net_c / net_f: the gate is evaluated on the fixture's weights
+        gate_nets = (npa.NeRF(**self.kw).to(dev), npa.NeRF(**self.kw).to(dev))
+        gate_nets[0].load_state_dict(self.Pc)
+        gate_nets[1].load_state_dict(self.Pf)
+        kwargs = dict(self.kwargs_test, network_fn=gate_nets[0], network_fine=gate_nets[1])
+        prev = npa.get_precision()
+        npa.set_precision(precision)
+        try:
+            with torch.no_grad():
+                rgb_g = npa.render(self.H, self.W, self.K, chunk=self.args.chunk, rays=gbatch, **kwargs)[0]
+            gate = wl.precision_gate(rgb_g, torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"]))
+            if with_operands and precision == "bf16x3" and hb.WGRAD_OPERANDS == "bf16":
+                # the one place this datapath stores less than fp32: the operands of the weight-gradient GEMM (bf16, RNE).
+                # Gradient of the training loss against the fixture's target, this storage vs fp32 storage (same kernels
+                # otherwise; tests/test_gpu_parity.py test_bf16_operand_storage_* hold the 4096-ray batch to <= 3e-4)
+                tgt = torch.tensor(gold["target"]).to(dev)
+
+                def grads_with(operands):
+                    before = hb.WGRAD_OPERANDS
+                    hb.WGRAD_OPERANDS = operands
+                    try:
+                        for m in gate_nets:
+                            m.zero_grad()
+                        rgb, _, _, ex = npa.render(self.H, self.W, self.K, chunk=self.args.chunk, rays=gbatch, **kwargs)
+                        (npa.img2mse(rgb, tgt) + npa.img2mse(ex["rgb0"], tgt)).backward()
+                        return torch.cat([gate_nets[0].last_flat_grad, gate_nets[1].last_flat_grad]).double()
+                    finally:
+                        hb.WGRAD_OPERANDS = before
+                g16, g32 = grads_with("bf16"), grads_with("fp32")
+                gate["wgrad_operands"] = {
+                    "stored_as": "bf16 (forward and delta chain: 3-term split-bf16 arithmetic, unchanged)",
+                    "gradient_rel_l2_vs_fp32_operand_storage": float((g16 - g32).norm() / g32.norm()),
+                    "gradient_cosine_deficit": 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm())), "rays": 1024}
+        finally:
+            npa.set_precision(prev)
+        gate.update(datapath=precision, rays=1024, bar_psnr_delta_db=0.01,
+                    passed=bool(gate["psnr_delta_db"] < 0.01 and gate["target_psnr_db"] >= 30.0),
+                    what="PSNR of our image vs the reference's image (real reference, CPU fp32, fixture gate_%s.npz) against a "
+                         "teacher-scene target at target_psnr_db; north_star: psnr_delta_db < 0.01" % self.config)
+        return gate
+
+    def close(self):
+        if self.sync is not None:
+            self.sync.close()
 
 
 def main():
@@ -317,11 +513,9 @@ def main():
     if args.dry_run:
         return dry_run(args)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     import nerf_pytorch_amd as npa
-    import workloads as wl
     from nerf_pytorch_amd import parallel
     hb = npa.hip_backend
 
@@ -334,89 +528,8 @@ def main():
                          f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` without a torchrun environment)")
     if torch.cuda.device_count() < (world if "LOCAL_RANK" in os.environ else 1) and os.environ.get("NERF_ALLOW_SHARED_GPU") != "1":
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
-
-    cfg = wl.LEGO if args.config == "lego" else wl.FERN
-    H, W, K = cfg["H"], cfg["W"], wl.intrinsics(cfg)
-    if args.strong:
-        n_global = 32768
-        lo, hi = parallel.shard_slice(n_global, rank, world)
-        n = hi - lo
-    else:
-        n = args.rays
-        n_global = n * world
-        lo, hi = rank * n, (rank + 1) * n
-
-    Pc, Pf = wl.scene_params()
-    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
-    net_c, net_f = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
-    net_c.load_state_dict(Pc)
-    net_f.load_state_dict(Pf)
-    parallel.broadcast_parameters([net_c, net_f])
-    # torch.optim.Adam semantics (run_nerf.py:207), fused over the two flat parameter vectors (state_dict compatible)
-    optimizer = npa.FlatAdam(list(net_c.parameters()) + list(net_f.parameters()), lr=5e-4, betas=(0.9, 0.999))
-    # the dict create_nerf builds (run_nerf.py:237-259) for this config
-    render_kwargs_train = dict(network_query_fn=None, perturb=1.0, N_importance=N_IMPORTANCE, network_fine=net_f,
-                               N_samples=N_SAMPLES, network_fn=net_c, use_viewdirs=True, white_bkgd=cfg["white_bkgd"],
-                               raw_noise_std=cfg["raw_noise_std"], ndc=cfg["ndc"], lindisp=False, near=cfg["near"], far=cfg["far"])
-    render_kwargs_test = dict(render_kwargs_train, perturb=False, raw_noise_std=0.)
-
-    # synthetic data, resident in HBM: a pool of ray batches + targets.  weak: rank-dependent seeds; strong: one global
-    # batch per pool slot, every rank takes its slice (and the random draws are made once for the full batch, below)
-    pool = 8
-    make = wl.lego_batch if args.config == "lego" else wl.fern_batch
-    if args.strong:
-        batches = [make(n_global, seed=100 + i)[:, lo:hi].contiguous().to(dev) for i in range(pool)]
-        targets = [torch.rand(n_global, 3, generator=torch.Generator().manual_seed(77 + i))[lo:hi].to(dev) for i in range(pool)]
-    else:
-        batches = [make(n, seed=1000 * rank + i).to(dev) for i in range(pool)]
-        gen = torch.Generator().manual_seed(77 + rank)
-        targets = [torch.rand(n, 3, generator=gen).to(dev) for _ in range(pool)]
-    strong_gen = torch.Generator(device=dev).manual_seed(4242) if args.strong else None
-
-    def strong_randoms():
-        """random draws of the GLOBAL batch in the reference's order from a generator every rank seeds identically;
-        each rank keeps its slice, so the N-GPU step computes exactly the 1-GPU N_rand=32768 step (SURVEY 8d-4)"""
-        r = {"t_rand": torch.rand((n_global, N_SAMPLES), device=dev, generator=strong_gen)}
-        if cfg["raw_noise_std"] > 0:
-            r["noise_c"] = torch.randn((n_global, N_SAMPLES), device=dev, generator=strong_gen)
-        r["u"] = torch.rand((n_global, N_IMPORTANCE), device=dev, generator=strong_gen)
-        if cfg["raw_noise_std"] > 0:
-            r["noise_f"] = torch.randn((n_global, N_SAMPLES + N_IMPORTANCE), device=dev, generator=strong_gen)
-        return {k: v[lo:hi].contiguous() for k, v in r.items()}
-
-    sync = parallel.GradientSync([net_c, net_f]) if world > 1 else None
-
-    def train_step(i):
-        batch_rays, target_s = batches[i % pool], targets[i % pool]
-        extra = {"randoms": strong_randoms()} if args.strong else {}
-        rgb, disp, acc, extras = npa.render(H, W, K, chunk=args.chunk, rays=batch_rays, verbose=False, retraw=True,
-                                            **render_kwargs_train, **extra)
-        optimizer.zero_grad()
-        loss = npa.img2mse(rgb, target_s) + npa.img2mse(extras["rgb0"], target_s)
-        loss.backward()       # (the coarse bucket's all-reduce starts inside, under the fine network's backward)
-        if sync is not None:
-            sync.finish()
-        optimizer.step()
-
-    def infer_step(i):
-        with torch.no_grad():
-            npa.render(H, W, K, chunk=args.chunk, rays=batches[i % pool], retraw=True, **render_kwargs_test)
-
-    # render_only (configs[4]): frames of a pose_spherical spiral (load_blender.py:75), dealt round-robin
-    fr = args.frame
-    fr_focal = cfg["focal"] * fr / cfg["W"]
-    Kf = np.array([[fr_focal, 0, 0.5 * fr], [0, fr_focal, 0.5 * fr], [0, 0, 1]])
-    spiral = [wl.pose_spherical(a, -30.0, 4.0) for a in np.linspace(-180, 180, 40 + 1)[:-1]]
-
-    def frame_step(i):
-        frame_id = (rank + i * world) % len(spiral)          # parallel.frames_of_rank dealing: frame f -> rank f mod G
-        with torch.no_grad():
-            npa.render(fr, fr, Kf, chunk=args.chunk, c2w=spiral[frame_id][:3, :4], **render_kwargs_test)
-
     if args.mode == "render_only" and args.config != "lego":
         raise SystemExit("bench.py: --mode render_only is BASELINE configs[4] (lego spiral); use --config lego")
-    step = {"train": train_step, "infer": infer_step, "render_only": frame_step}[args.mode]
-    rays_per_step = fr * fr if args.mode == "render_only" else n
 
     def barrier():
         if world > 1:
@@ -450,84 +563,108 @@ def main():
             kern = timer.summary()
         return el, kern
 
+    ses = Session(args.config, args, rank, world, dev, args.rays, args.strong)
+    n, n_global = ses.n, ses.n_global
+    step = ses.step_fn(args.mode)
+    rays_per_step = ses.rays_per_step(args.mode)
     elapsed, kern = measure(args.precision, args.steps, args.warmup, step, with_kernels=True)
 
+    # ---- N > 1: what the exchange costs alone, whether it was overlapped, and whether the ranks still agree
+    multi = None
+    if world > 1 and args.mode == "train":
+        bufs = [torch.zeros(hb.N_PARAMS, device=dev) for _ in range(2)]
+        for b in bufs:
+            dist.all_reduce(b)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            for b in bufs:
+                dist.all_reduce(b)
+        barrier()
+        multi = {"allreduce_ms": 1e3 * (time.perf_counter() - t0) / reps,
+                 "allreduce_what": "2 x 2.38 MB fp32 all-reduce (both networks' buckets), back to back, nothing else on the GPU",
+                 "overlap_started": ses.sync.started,
+                 "overlap_started_what": f"exchanges started under the backward over {args.warmup + args.steps + max(2, min(args.steps, 6))} "
+                                         "steps (one per step = the coarse bucket; the fine bucket is exchanged in finish())",
+                 "ranks_identical": parallel.ranks_identical([ses.net_c.flat_params(), ses.net_f.flat_params()]),
+                 "rccl_ranks_seen": parallel.ranks_seen()}
+    elif world > 1:
+        multi = {"rccl_ranks_seen": parallel.ranks_seen()}
+
     # ---- secondary numbers of the same run (never the headline)
-    other_infer = second = second_mixed = None
+    other_infer = second = second_mixed = fp32_operands = None
     if args.mode == "train":
         k_inf = max(5, args.steps // 2)
-        el_i, _ = measure(args.precision, k_inf, 2, infer_step, with_kernels=False)
+        el_i, _ = measure(args.precision, k_inf, 2, ses.infer_step, with_kernels=False)
         other_infer = n * world * k_inf / el_i
     if not args.single_datapath and args.mode != "render_only":
         p2 = "bf16x3" if args.precision == "fp32" else "fp32"
         k2 = max(4, args.steps // 4)
         el2, kern2 = measure(p2, k2, 2, step, with_kernels=True)
-        tab2 = kernel_table(kern2, p2)
+        tab2 = kernel_table(kern2)
         second = {"dtype": DTYPE_NAME[p2].split(" ")[0], "value": n * world * k2 / el2, "unit": "rays/s",
-                  "steps": k2, "ms_per_step": 1e3 * el2 / k2, "roofline": roofline_of(tab2),
-                  "kernels": {k: {"avg_ms": v["avg_ms"], "mfma_frac": v["mfma_frac"], "hbm_frac": v["hbm_frac"]}
-                              for k, v in tab2.items()}}
+                  "steps": k2, "ms_per_step": 1e3 * el2 / k2, "roofline": roofline_of(tab2), "kernels": _brief(tab2)}
         if args.mode == "train" and args.precision != "mixed":
             k3 = max(4, args.steps // 2)
             el3, kern3 = measure("mixed", k3, 2, step, with_kernels=True)
-            tab3 = kernel_table(kern3, "mixed")
             second_mixed = {"dtype": "bf16x3 forward (outputs identical to the bf16x3 datapath) + bf16 backward (saved activations / "
                                      "deltas rounded to bf16, one bf16 MFMA per product, f32 accumulate); gradients are NOT fp32-class",
                             "value": n * world * k3 / el3, "unit": "rays/s", "steps": k3, "ms_per_step": 1e3 * el3 / k3,
-                            "kernels": {k: {"avg_ms": v["avg_ms"], "mfma_frac": v["mfma_frac"], "hbm_frac": v["hbm_frac"]}
-                                        for k, v in tab3.items()}}
+                            "kernels": _brief(kernel_table(kern3))}
+        if args.mode == "train" and args.precision == "bf16x3" and hb.WGRAD_OPERANDS == "bf16":
+            # the same datapath with the operands of the weight-gradient GEMM stored as fp32 (every gradient fp32-class)
+            hb.WGRAD_OPERANDS = "fp32"
+            try:
+                k4 = max(4, args.steps // 2)
+                el4, kern4 = measure("bf16x3", k4, 2, step, with_kernels=True)
+            finally:
+                hb.WGRAD_OPERANDS = "bf16"
+            fp32_operands = {"dtype": "bf16x3 with NERF_WGRAD_OPERANDS=fp32 (saved activations and deltas fp32, split by the weight-gradient GEMM)",
+                             "value": n * world * k4 / el4, "unit": "rays/s", "steps": k4, "ms_per_step": 1e3 * el4 / k4,
+                             "kernels": _brief(kernel_table(kern4))}
     npa.set_precision(args.precision)
 
-    # ---- the north-star acceptance gate of the headline datapath, measured in this run: our image vs the image the
-    # REAL reference rendered for the same rays / weights (committed fixture tests/golden/gate_<config>.npz,
-    # generated by tests/golden/make_golden.py --round2 from /root/reference), against a teacher-scene target
     gate = None
     if not args.no_gate and rank == 0:
-        gpath = os.path.join(ROOT, "tests", "golden", f"gate_{args.config}.npz")
-        if os.path.exists(gpath):
-            gold = np.load(gpath)
-            gbatch = (wl.lego_batch(1024, seed=31) if args.config == "lego" else wl.fern_batch(1024, seed=32)).to(dev)
-            # the timed steps have trained net_c / net_f: the gate is evaluated on the fixture's weights
-            gate_nets = (npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev))
-            gate_nets[0].load_state_dict(Pc)
-            gate_nets[1].load_state_dict(Pf)
-            with torch.no_grad():
-                rgb_g = npa.render(H, W, K, chunk=args.chunk, rays=gbatch,
-                                   **dict(render_kwargs_test, network_fn=gate_nets[0], network_fine=gate_nets[1]))[0]
-            gate = wl.precision_gate(rgb_g, torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"]))
-            if args.precision == "bf16x3" and hb.WGRAD_OPERANDS == "bf16":
-                # the one place this datapath stores less than fp32: the operands of the weight-gradient GEMM (bf16, RNE).
-                # Gradient of the training loss against the fixture's target, this storage vs fp32 storage (same kernels
-                # otherwise; tests/test_gpu_parity.py test_bf16_operand_storage_* hold the 4096-ray batch to <= 3e-4)
-                tgt = torch.tensor(gold["target"]).to(dev)
+        gate = ses.gate(args.precision)
 
-                def grads_with(operands):
-                    prev = hb.WGRAD_OPERANDS
-                    hb.WGRAD_OPERANDS = operands
-                    try:
-                        for m in gate_nets:
-                            m.zero_grad()
-                        rgb, _, _, ex = npa.render(H, W, K, chunk=args.chunk, rays=gbatch,
-                                                   **dict(render_kwargs_test, network_fn=gate_nets[0], network_fine=gate_nets[1]))
-                        (npa.img2mse(rgb, tgt) + npa.img2mse(ex["rgb0"], tgt)).backward()
-                        return torch.cat([gate_nets[0].last_flat_grad, gate_nets[1].last_flat_grad]).double()
-                    finally:
-                        hb.WGRAD_OPERANDS = prev
-                g16, g32 = grads_with("bf16"), grads_with("fp32")
-                gate["wgrad_operands"] = {
-                    "stored_as": "bf16 (forward and delta chain: 3-term split-bf16 arithmetic, unchanged)",
-                    "gradient_rel_l2_vs_fp32_operand_storage": float((g16 - g32).norm() / g32.norm()),
-                    "gradient_cosine_deficit": 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm())), "rays": 1024}
-            gate.update(datapath=args.precision, rays=1024, bar_psnr_delta_db=0.01,
-                        passed=bool(gate["psnr_delta_db"] < 0.01 and gate["target_psnr_db"] >= 30.0),
-                        what="PSNR of our image vs the reference's image (real reference, CPU fp32, fixture gate_%s.npz) against a "
-                             "teacher-scene target at target_psnr_db; north_star: psnr_delta_db < 0.01" % args.config)
+    # ---- short legs of the other single-GPU configurations (BASELINE configs[2], [4] and the 32,768-ray batch of [3])
+    legs = None
+    default_run = (world == 1 and args.mode == "train" and args.config == "lego" and not args.strong and not args.no_configs
+                   and args.rays == N_RAND)
+    if default_run:
+        legs = {}
+        lego_gate = None if gate is None else {k: gate[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed") if k in gate}
+        fern = Session("fern", args, rank, world, dev, N_RAND, False)
+        el, _ = measure(args.precision, 5, 2, fern.train_step, with_kernels=False)
+        g = None if args.no_gate else fern.gate(args.precision, with_operands=False)
+        legs["fern_train"] = {"workload": "BASELINE configs[2]: fern-like 504x378, NDC rays near=0 far=1, raw_noise_std=1, N_rand=4096 x (64+128), training step",
+                              "value": N_RAND * 5 / el, "unit": "rays/s", "steps": 5, "ms_per_step": 1e3 * el / 5,
+                              "precision_gate": None if g is None else {k: g[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed")}}
+        fern.close()
+        del fern
+        el, _ = measure(args.precision, 2, 1, ses.frame_step, with_kernels=False)
+        legs["render_only"] = {"workload": f"BASELINE configs[4] on one GPU: {args.frame}x{args.frame} frames of the lego spiral, no_grad render(c2w=...), chunks of {args.chunk}",
+                               "value": args.frame * args.frame * 2 / el, "unit": "rays/s", "steps": 2, "s_per_frame": el / 2,
+                               "precision_gate": lego_gate}
+        big = Session("lego", args, rank, world, dev, N_RAND, True)
+        el, _ = measure(args.precision, 2, 1, big.train_step, with_kernels=False)
+        legs["batch_32768"] = {"workload": "the 32,768-ray global batch of BASELINE configs[3] on ONE GPU (lego 64+128, training step; the backward "
+                                           "recomputes the forward in sub-chunks above the 48 GiB save budget)",
+                               "value": 32768 * 2 / el, "unit": "rays/s", "steps": 2, "ms_per_step": 1e3 * el / 2,
+                               "precision_gate": lego_gate}
+        big.close()
+        del big
+        hb.WORKSPACE.clear()
+        torch.cuda.empty_cache()
 
     if rank == 0:
+        cfg, H, W = ses.cfg, ses.H, ses.W
+        fr = args.frame
         total_rays = rays_per_step * world * args.steps
         value = total_rays / elapsed
-        flop_per_ray = (EXEC_TRAIN_PER_RAY if args.mode == "train" else EXEC_FWD_PER_RAY)[args.precision]
-        kernels = kernel_table(kern, args.precision)
+        kernels = kernel_table(kern)
         roofline = roofline_of(kernels)
         if roofline is not None:
             tr, src = pmc_traffic(roofline["kernel"], args.precision)
@@ -538,17 +675,13 @@ def main():
                                             f"command): 2*FETCH_SIZE + WRITE_SIZE; algorithmic bytes per launch here: "
                                             f"{k['algorithmic_GBps'] * 1e9 * k['avg_ms'] * 1e-3:.4g}")
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-            # MFMA FLOPs issued per executed FLOP: fp32 1; split-bf16 3 — except a weight-gradient GEMM on bf16-stored
-            # operands (1 MFMA per product): bf16x3 with bf16 operand storage (default) and mixed (whose dgrad is 1 too)
-            issued_flop = flop_per_ray * (1.0 if args.precision == "fp32" else 3.0)
-            if args.mode == "train" and args.precision != "fp32":
-                third = (FLOP_TRAIN_PER_RAY - 3 * FOLD_FLOP) * (593408 - 65536) / (593408 + 557696 + 593408 - 3 * 65536)   # wgrad share
-                dg = (FLOP_TRAIN_PER_RAY - 3 * FOLD_FLOP) * (557696 - 65536) / (593408 + 557696 + 593408 - 3 * 65536)      # dgrad share
-                if args.precision == "mixed":
-                    issued_flop -= 2.0 * (third + dg)
-                elif hb.WGRAD_OPERANDS == "bf16":
-                    issued_flop -= 2.0 * third
-            roofline["whole_step_mfma_frac"] = value * issued_flop / world / 1e12 / peak
+            alg_per_ray = FLOP_TRAIN_PER_RAY if args.mode == "train" else FLOP_FWD_PER_RAY
+            roofline["step_algorithmic_frac"] = value * alg_per_ray / world / 1e12 / peak
+            roofline["step_algorithmic_tflops"] = value * alg_per_ray / world / 1e12
+            timed_ms = sum(v["total_ms"] for v in kernels.values())
+            if timed_ms > 0:        # pipe occupancy of the whole step: sum over the timed kernels of busy_frac x their time / step time
+                passes = max(2, min(args.steps, 6))
+                roofline["step_mfma_busy_frac"] = sum(v["mfma_busy_frac"] * v["total_ms"] for v in kernels.values()) / passes / (1e3 * elapsed / args.steps)
         workload = {
             "train": f"{args.config}-like {W}x{H}, N_rand={n} rays/GPU x (64 coarse + 128 fine) samples, two 8x256 networks, perturb=1, "
                      + ("white_bkgd" if cfg["white_bkgd"] else f"NDC rays near=0 far=1, raw_noise_std={cfg['raw_noise_std']}")
@@ -574,12 +707,18 @@ def main():
                            if world > 1 and args.mode == "train" else None),
             "precision_gate": gate, "roofline": roofline, "kernels": kernels,
         }
+        if multi is not None:
+            line["multi_gpu"] = multi
+        if legs is not None:
+            line["configs"] = legs
         if other_infer is not None:
             line["inference_rays_per_s"] = other_infer
         if second is not None:
             line["other_datapath"] = second
         if second_mixed is not None:
             line["mixed_precision_training"] = second_mixed
+        if fp32_operands is not None:
+            line["fp32_operand_storage"] = fp32_operands
         if world == 1 and not args.no_eager_baseline and args.mode != "render_only":
             eb = rocm_eager_baseline(args.config, dev, n)
             line["rocm_eager_baseline"] = eb
@@ -587,11 +726,14 @@ def main():
             line["speedup_vs_rocm_eager"] = {"headline": value / ref}
             if second is not None:
                 line["speedup_vs_rocm_eager"][second["dtype"]] = second["value"] / ref
+            if fp32_operands is not None:
+                line["speedup_vs_rocm_eager"]["fp32_operands"] = fp32_operands["value"] / ref
             if other_infer is not None:
                 line["speedup_vs_rocm_eager"]["inference"] = other_infer / eb["infer_rays_per_s"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(line))
+    ses.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -152,6 +152,14 @@ int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_strid
  * nerf_debug_pack16_table: host gather table of its fragment stream (tests). */
 int nerf_field_fwd16_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                             int n_samples, float* raw, float* act, int bf16_save, void* stream);
+/* nerf_field_fwd16_bf16x3 on the weight RING (csrc/field_ring.h): a 17-slot LDS ring of 8 KiB fragment units instead of
+ * two 64 KiB buffers, one barrier per 64 KiB placed inside the chunk, fragments requested one unit ahead, the L2 -> LDS
+ * DMA issued in 2 KiB parts behind the MFMAs.  Same fragment stream, same summation order: raw and everything saved are
+ * BIT-IDENTICAL to nerf_field_fwd16_bf16x3(bf16_save = 1) (act != NULL: bf16 rows, datapath 4 of nerf_field_wgrad_phase)
+ * or to its inference form (act NULL).  Replaces run_nerf.py:37-51 + run_nerf_helpers.py:15-45, :96-119 like the other
+ * forwards. */
+int nerf_field_fwd16r_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                             int n_samples, float* raw, float* act, void* stream);
 int nerf_debug_pack16_table(int* out_host);
 /* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  dgrad also leaves a tiled
  * copy of d_raw inside delta, which is what wgrad contracts with: nerf_field_wgrad_bf16x3 must be given the delta

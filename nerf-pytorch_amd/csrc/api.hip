@@ -272,6 +272,17 @@ int nerf_field_fwd16_bf16x3(const float* packed3, const float* rays, int ray_str
                                                    bf16_save, (hipStream_t)stream));
 }
 
+int nerf_field_fwd16r_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                             int n_samples, float* raw, float* act, void* stream) {
+    REQUIRE(packed3 && rays && z_vals && raw, "null pointer");
+    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
+    return done(__func__, nerf::launch_field_fwd16r(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act,
+                                                    (hipStream_t)stream));
+}
+
 int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream) {
     REQUIRE(params && packed3, "null pointer");
     return done(__func__, nerf::launch_pack3(params, packed3, (hipStream_t)stream));

@@ -65,6 +65,20 @@ __device__ inline void dma_4k(const float* gsrc_lane, unsigned lds_dst_uniform) 
         : "v"(gsrc_lane), "s"(lds_dst_uniform)
         : "memory");
 }
+// two consecutive 1 KiB pieces under one M0 set-up (weight ring, field_ring.h)
+__device__ inline void dma_2k(const float* gsrc_lane, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc_lane), "s"(lds_dst_uniform)
+        : "memory");
+}
 // every wave copies one contiguous span of the chunk (nfloats / NWAVES, a multiple of 256 floats) in 4 KiB and 1 KiB steps
 template <int NWAVES>
 __device__ inline void dma_chunk(const float* gsrc, float* lbuf, int nfloats, int wave, int lane) {

@@ -68,5 +68,7 @@ hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_st
                              int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
 hipError_t launch_field_fwd16(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                               int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
+hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
+                               int n_rays, int S, float* raw, float* act, hipStream_t stream);
 
 }  // namespace nerf

@@ -57,6 +57,7 @@ def _declare(lib):
         "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p, p]),
         "nerf_field_fwd_mixed": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_field_fwd16_bf16x3": (i, [p, p, i, p, i, i, p, p, i, p]),
+        "nerf_field_fwd16r_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_debug_pack16_table": (i, [p]),
         "nerf_field_dgrad_mixed": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p, p]),
@@ -74,7 +75,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
-           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_debug_pack16_table",
+           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_field_fwd16r_bf16x3", "nerf_debug_pack16_table",
            "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step"]
 
 
@@ -254,7 +255,10 @@ def _bf16_operands(precision):
 
 # the bf16x3 / mixed forward runs the 16-point-per-wave kernel (2 waves / SIMD); "0" selects the 32-point kernel
 # (1 wave / SIMD), which writes the same save buffer and agrees to rounding
-FWD_16PT = __import__("os").environ.get("NERF_FWD16", "1") != "0"
+FWD_16PT = __import__("os").environ.get("NERF_FWD16", "ring") != "0"
+# ... and, unless NERF_FWD16=1, its weight-RING form (csrc/field_ring.h: 17-slot LDS ring, fragments requested one unit
+# ahead, DMA behind the MFMAs; bit-identical results) for inference and for bf16 rows; fp32 rows stay on the double-buffered kernel
+FWD_RING = __import__("os").environ.get("NERF_FWD16", "ring") == "ring"
 
 
 def _small_offset():
@@ -434,11 +438,16 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
         nbytes = BYTES_ACT3_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in ("bf16x3", "mixed") and FWD_16PT:
         bf16_save = int(b16)
-        label = "field_fwd16_kernel" + (("<save bf16>" if bf16_save else "<save>") if save_act else "")
+        ring = FWD_RING and (bf16_save or not save_act)
+        label = ("field_fwd16r_kernel" if ring else "field_fwd16_kernel") + (("<save bf16>" if bf16_save else "<save>") if save_act else "")
         with _timed(label, FLOP_FWD3_PER_POINT * n * S, BYTES_ACT3_BF16_PER_POINT * n * S if bf16_save and save_act else nbytes):
-            _check(lib().nerf_field_fwd16_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
-                                                 n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
-                   "nerf_field_fwd16_bf16x3")
+            if ring:
+                _check(lib().nerf_field_fwd16r_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                                      n, S, _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd16r_bf16x3")
+            else:
+                _check(lib().nerf_field_fwd16_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                                     n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
+                       "nerf_field_fwd16_bf16x3")
         if act is not None:
             act.nerf_tile16 = True      # rows in 16-point tiles (fp32: row16 order, bf16: row16h order): the GEMM must know
             act.nerf_bf16 = bool(bf16_save)

@@ -34,6 +34,7 @@ def init_distributed(backend=None):
     if use_cuda:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this host driver
@@ -42,8 +43,52 @@ def init_distributed(backend=None):
             backend = "nccl" if use_cuda else "gloo"
         if backend == "nccl":
             kw["device_id"] = device
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        timeout = datetime.timedelta(seconds=float(os.environ.get("NERF_DIST_TIMEOUT_S", "180")))
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout, **kw)
+            # first collective right here, so that a broken fabric / IPC setup fails at a known place with the environment
+            # in the message instead of hanging inside the first training step
+            probe = torch.ones(1, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise RuntimeError(f"probe all-reduce returned {probe.item()} on a world of {world}")
+        except Exception as e:
+            env = {k: v for k, v in os.environ.items()
+                   if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_", "ROCR_", "MASTER_", "GLOO_")) or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+            raise RuntimeError(
+                f"nerf-pytorch_amd: process group init failed on rank {rank}/{world} (backend {backend}, device {device}, "
+                f"{torch.cuda.device_count() if use_cuda else 0} GPU(s) visible, timeout {timeout.total_seconds():.0f} s): "
+                f"{type(e).__name__}: {e}\nenvironment: {env}") from e
     return rank, world, device
+
+
+def ranks_seen(group=None):
+    """Sorted list of the ranks that answer a collective (all-gather of every rank's id): world_size entries 0..G-1 when
+    the communicator really spans every process."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [0]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    mine = torch.tensor([dist.get_rank(group)], dtype=torch.int64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, mine, group=group)
+    return sorted(int(t.item()) for t in out)
+
+
+def ranks_identical(tensors, group=None):
+    """True when every rank holds bit-identical copies of `tensors` (all-gather of a 64-bit checksum of their bytes): the
+    data-parallel invariant after broadcast + identical Adam steps on averaged gradients."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return True
+    sums = []
+    for t in tensors:
+        b = t.detach().contiguous().view(torch.uint8).to(torch.int64)
+        w = torch.arange(1, b.numel() + 1, dtype=torch.int64, device=b.device) % 65521
+        sums.append((b * w).sum().reshape(1))
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    mine = torch.cat(sums).to(dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, mine, group=group)
+    return all(torch.equal(o, out[0]) for o in out)
 
 
 def world_size():
@@ -115,6 +160,9 @@ def allreduce_gradients(models, group=None):
             off += g.numel()
 
 
+_LIVE_SYNCS = []        # weak references to the GradientSync objects whose hook is installed
+
+
 class GradientSync:
     """Gradient averaging overlapped with the backward pass.
 
@@ -126,28 +174,67 @@ class GradientSync:
     not started (networks whose .grad already existed — accumulation reads the bucket — or that did not come through
     the hook) the plain way, and applies the 1/G.
 
-        sync = GradientSync([model, model_fine])      # once
-        ...
+    A network may report MORE than one bucket inside one loss.backward() (render(chunk < N_rand): one _RenderRays node
+    per chunk; two render() calls before one backward; repeated query_points).  Autograd then SUMS the buckets out of
+    place, i.e. it reads bucket #1 — whose in-place exchange was started early.  The second report therefore waits for
+    that exchange, turns the bucket back into a per-rank share (x 1/G: every rank now holds sum/G, and the shares still
+    add up to the sum), starts nothing more for this network, and finish() exchanges its final .grad the plain way.
+
+        sync = GradientSync([model, model_fine])      # once (a context manager; a second one for the same networks
+        ...                                           #       retires the first)
         loss.backward(); sync.finish(); optimizer.step()
     """
 
     def __init__(self, models, group=None):
+        import weakref
         from .render import GRAD_READY_HOOKS
         self.models = [m for m in models if m is not None]
         self.group = group
-        self.pending = {}           # id(model) -> (flat, work)
+        self.pending = {}           # id(model) -> (flat, work) of the exchange started under the backward
+        self.multi = set()          # id(model) of networks that reported a second bucket in this backward
         self._hooks = GRAD_READY_HOOKS
+        # one hook per network: a forgotten GradientSync (created per step / per run without close()) must not leave a
+        # second all-reduce of the same bucket behind
+        for ref in list(_LIVE_SYNCS):
+            other = ref()
+            if other is None or any(a is b for a in other.models for b in self.models):
+                if other is not None:
+                    other.close()
+                if ref in _LIVE_SYNCS:
+                    _LIVE_SYNCS.remove(ref)
         self._hooks.append(self._on_ready)
+        self._ref = weakref.ref(self)
+        _LIVE_SYNCS.append(self._ref)
         self.started = 0            # exchanges started under the backward (for tests / reporting)
 
     def close(self):
         if self._on_ready in self._hooks:
             self._hooks.remove(self._on_ready)
+        if getattr(self, "_ref", None) in _LIVE_SYNCS:
+            _LIVE_SYNCS.remove(self._ref)
+        self.pending.clear()
+        self.multi.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _on_ready(self, model, flat):
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
-        if not any(model is m for m in self.models) or id(model) in self.pending:
+        if not any(model is m for m in self.models) or id(model) in self.multi:
+            return
+        earlier = self.pending.pop(id(model), None)
+        if earlier is not None:
+            # a second bucket of this network (or a bucket left over from a backward whose finish() never ran): autograd is
+            # about to read the first one.  Finish its exchange and make it a share again (class docstring).
+            first, work = earlier
+            work.wait()
+            first.mul_(1.0 / dist.get_world_size(self.group))
+            self.multi.add(id(model))
             return
         if any(p.grad is not None for p in model.parameters()):
             return      # autograd will ADD the bucket into the existing .grad: it must not change under that read
@@ -158,21 +245,27 @@ class GradientSync:
     def finish(self):
         world_ = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world_ == 1:
+            self.pending.clear()
+            self.multi.clear()
             return
-        rest = []
-        for m in self.models:
-            started = self.pending.pop(id(m), None)
-            if started is None:
-                rest.append(m)
-                continue
-            flat, work = started
-            work.wait()
-            flat.mul_(1.0 / world_)
-            if _flat_grad_of(m) is not flat:    # autograd copied instead of adopting the views: hand the averages over
-                from .render import _grad_views
-                for p, g in zip(m.param_list(), _grad_views(m, flat)):
-                    p.grad.copy_(g)
-        allreduce_gradients(rest, group=self.group)
+        try:
+            rest = []
+            for m in self.models:
+                started = self.pending.pop(id(m), None)
+                if started is None:
+                    rest.append(m)
+                    continue
+                flat, work = started
+                work.wait()
+                flat.mul_(1.0 / world_)
+                if _flat_grad_of(m) is not flat:    # autograd copied instead of adopting the views: hand the averages over
+                    from .render import _grad_views
+                    for p, g in zip(m.param_list(), _grad_views(m, flat)):
+                        p.grad.copy_(g)
+            allreduce_gradients(rest, group=self.group)
+        finally:
+            self.pending.clear()
+            self.multi.clear()
 
 
 def broadcast_parameters(models, src=0, group=None):

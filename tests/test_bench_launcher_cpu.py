@@ -36,6 +36,43 @@ def test_bench_strong_mode_splits_the_global_batch():
     assert line["scaling"] == "strong" and line["global_batch_rays"] == 32768 and line["rays_per_rank"] == 16384
 
 
+@pytest.mark.timeout(600)
+def test_bench_eight_gloo_ranks_dry_run():
+    """The driver's 8-GPU command shape under gloo: rendezvous of 8 ranks, the strong split 8 x 4096 of the 32,768-ray
+    batch, the 40 spiral frames dealt 5 per rank, every rank answering the census, identical-parameter check."""
+    res = _run("--gpus", "8", "--dry-run", "--backend", "gloo", "--strong", timeout=540)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 8 and line["world_size"] == 8
+    assert line["rays_per_rank"] == 4096 and line["rays_of_all_ranks"] == 32768 and line["frames_of_all_ranks"] == 40
+    assert line["rccl_ranks_seen"] == list(range(8)) and line["ranks_identical"] is True
+    res = _run("--gpus", "8", "--dry-run", "--backend", "gloo", timeout=540)        # weak: N_rand per rank
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert line["rays_per_rank"] == 4096 and line["global_batch_rays"] == 32768 and line["scaling"] == "weak"
+
+
+def test_init_failure_names_the_environment(monkeypatch):
+    """A process group that cannot form must fail with the backend, the device and the NCCL/HSA environment in the
+    message (the 8-GPU run happens on a box nobody watches), not hang."""
+    sys.path.insert(0, ROOT)
+    import nerf_pytorch_amd  # noqa: F401
+    from nerf_pytorch_amd import parallel
+    import torch.distributed as dist
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("NCCL_DEBUG", "WARN")
+
+    def boom(**kw):
+        raise RuntimeError("simulated fabric failure")
+    monkeypatch.setattr(dist, "init_process_group", boom)
+    with pytest.raises(RuntimeError) as ei:
+        parallel.init_distributed(backend="gloo")
+    msg = str(ei.value)
+    assert "process group init failed on rank 0/2" in msg and "simulated fabric failure" in msg and "NCCL_DEBUG" in msg
+
+
 def test_bench_refuses_more_gpus_than_the_box_has():
     import torch
     if torch.cuda.device_count() >= 2:

@@ -358,3 +358,28 @@ def test_workspace_size_query_and_lease_pool():
     assert big.numel() == 10_000_000
     w.give(big)
     assert w.take(1000, "cpu").data_ptr() == a.data_ptr()
+
+
+def test_batchify_rays_slices_injected_randoms(monkeypatch):
+    """render(chunk < N) with injected randoms: every chunk must consume ITS rows of the random tensors
+    (run_nerf.py:54-66 slices the rays; the draws of a chunk belong to its rays)."""
+    import sys
+    import torch
+    import nerf_pytorch_amd  # noqa: F401
+    render = sys.modules["nerf_pytorch_amd.render"]
+    seen = []
+
+    def fake_render_rays(ray_batch, **kw):
+        seen.append((ray_batch.clone(), {k: v.clone() for k, v in kw["randoms"].items()}))
+        return {"rgb_map": ray_batch[:, :3]}
+    monkeypatch.setattr(render, "render_rays", fake_render_rays)
+    rays = torch.arange(10 * 11, dtype=torch.float32).reshape(10, 11)
+    rnd = {"t_rand": torch.arange(10 * 4, dtype=torch.float32).reshape(10, 4), "u": torch.arange(10 * 6, dtype=torch.float32).reshape(10, 6)}
+    out = render.batchify_rays(rays, chunk=4, randoms=rnd)
+    assert [r.shape[0] for r, _ in seen] == [4, 4, 2]
+    for i, (r, kw) in enumerate(seen):
+        assert torch.equal(kw["t_rand"], rnd["t_rand"][4 * i:4 * i + 4]) and torch.equal(kw["u"], rnd["u"][4 * i:4 * i + 4])
+    assert torch.equal(out["rgb_map"], rays[:, :3])
+    import pytest
+    with pytest.raises(ValueError):
+        render.batchify_rays(rays, chunk=4, randoms={"t_rand": rnd["t_rand"][:7]})

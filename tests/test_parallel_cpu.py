@@ -89,6 +89,29 @@ def _worker(rank, world, port, q):
     for i in range(3):          # mean over the two ranks of 10(i+1) + rank
         want = 10.0 * (i + 1) + 0.5
         assert all(bool((p.grad == want).all()) for p in nets[i].parameters()), i
+    # a network that reports TWO buckets in one backward (render(chunk < N_rand): one autograd node per chunk): autograd
+    # sums them out of place, i.e. it reads bucket #1 whose exchange was started early -- the averaged .grad must still be
+    # the mean over ranks of (b1 + b2), and a GradientSync created for the same networks retires the forgotten one
+    forgotten = parallel.GradientSync(nets)
+    sync2 = parallel.GradientSync(nets)
+    assert len(render.GRAD_READY_HOOKS) == 1, "a second GradientSync for the same networks must retire the first"
+    for nn in nets:
+        for pp in nn.parameters():
+            pp.grad = None
+    b1 = torch.full((npa.hip_backend.N_PARAMS,), 1.0 + rank)
+    b2 = torch.full((npa.hip_backend.N_PARAMS,), 100.0 + 10 * rank)
+    render._grad_ready(nets[0], b1)
+    assert sync2.started == 1
+    render._grad_ready(nets[0], b2)                 # second report: exchange of b1 finished and turned back into a share
+    assert id(nets[0]) in sync2.multi and not sync2.pending
+    for nm, off, shape in table:                    # what autograd does with two contributions: an out-of-place sum
+        n_el = int(np.prod(shape))
+        dict(nets[0].named_parameters())[nm].grad = b1[off:off + n_el].view(shape) + b2[off:off + n_el].view(shape)
+    with sync2:
+        sync2.finish()
+    assert render.GRAD_READY_HOOKS == [] and not sync2.multi
+    want = (1.0 + 2.0) / 2 + (100.0 + 110.0) / 2
+    assert all(bool(((p.grad - want).abs() < 1e-4).all()) for p in nets[0].parameters())
     frames = parallel.frames_of_rank(7)
     got = parallel.gather_frames([np.full((2, 2), i) for i in frames], frames, 7)
     q.put((rank, flat.numpy().copy(), net.flat_params().detach().numpy().copy(), {k: v.numpy().copy() for k, v in P0.items()},

@@ -1,5 +1,8 @@
+#!/bin/bash
+# scratch driver of the experiment of the moment (gpurun): tools/gpu_exp.sh <script> [args] ; more scripts separated by --
 mkdir -p gpurun_out
-{ timeout 100 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-  timeout 60 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --single-datapath 2>&1 | tail -1 > gpurun_out/b.json; cut -c1-200 gpurun_out/b.json
-} > gpurun_out/exp.log 2>&1
-cat gpurun_out/exp.log
+args=()
+for a in "$@"; do
+  if [ "$a" == "--" ]; then timeout 300 python "${args[@]}" 2>&1 | tail -60; args=(); else args+=("$a"); fi
+done
+[ ${#args[@]} -gt 0 ] && timeout 300 python "${args[@]}" 2>&1 | tail -60
