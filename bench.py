@@ -216,7 +216,7 @@ def _kernel_class(name):
         return 1.0, 1.0, PEAK_FP32_MFMA_TFLOPS                                  # exact-fp32 datapath
     if fwd:
         return 3.0, (MAC_FWD - MAC_FOLD) / MAC_FWD, PEAK_BF16_MFMA_TFLOPS
-    if name.startswith("field_dgrad3_kernel"):
+    if name.startswith(("field_dgrad3_kernel", "field_dgrad3r_kernel")):
         return (1.0 if "<mixed>" in name else 3.0), (MAC_DGRAD - MAC_FOLD) / MAC_DGRAD, PEAK_BF16_MFMA_TFLOPS
     if name.startswith("wgrad1_kernel"):
         return 1.0, (MAC_WGRAD - MAC_FOLD) / MAC_WGRAD, PEAK_BF16_MFMA_TFLOPS
@@ -273,7 +273,7 @@ def pmc_traffic(kernel_name, precision):
             want = "2" if "<save bf16>" in kernel_name else ("1" if "<save" in kernel_name else "0")
             if {"false": "0", "true": "1", "": "0"}.get(tmpl, tmpl) != want:
                 continue
-        if key == "field_dgrad3_kernel":
+        if key in ("field_dgrad3_kernel", "field_dgrad3r_kernel"):
             want = "1" if "<mixed>" in kernel_name else ("2" if "<bf16 out>" in kernel_name else "0")
             if {"false": "0", "true": "1", "": "0"}.get(tmpl, tmpl) != want:
                 continue

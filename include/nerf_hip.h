@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 4
+#define NERF_ABI_VERSION 5
 #define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
 
@@ -174,6 +174,12 @@ int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float*
                             float* delta, int delta_bf16, void* stream);
 int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                             float* partial, float* grad, int accumulate, const float* params, void* stream);
+/* nerf_field_dgrad_bf16x3 on the weight RING (csrc/field_ring.h, field_bwd_ring.hip): every MFMA carries one fragment
+ * request / a piece of the operand split / a row store in its shadow and the L2 -> LDS DMA leaves in 4 KiB parts, instead of
+ * barrier + DMA burst + LDS latency + store burst after every 64 KiB chunk.  Same transposed stream, same summation order:
+ * the deltas written are BIT-IDENTICAL to nerf_field_dgrad_bf16x3 with the same delta_bf16. */
+int nerf_field_dgrad3r_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
+                              float* delta, int delta_bf16, void* stream);
 /* The split-bf16 and mixed datapaths evaluate feature_linear and the feature columns of views_linears.0 as ONE layer
  * (helpers:111-115: no activation between them): W' = Wv[:, :256] Wf, b' = Wv[:, :256] bf + bv are derived by
  * nerf_pack_params_bf16x3.  `feature` and its delta are therefore neither computed nor saved; the weight-gradient entry
@@ -192,19 +198,64 @@ int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* 
                            float* delta, void* stream);
 int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate, const float* params, void* stream);
+/* ---- which layout a scratch buffer holds.  The save buffer of a forward exists in five layouts and the delta buffer of a
+ * dgrad in three (csrc/nerf_common.h); the entry point that writes a buffer decides, and the entry points that read it must
+ * agree.  The library remembers per buffer ADDRESS what its own entry points last wrote there (host-side table only;
+ * nothing is stored on the device and no pointer is dereferenced later) and
+ *   - every dgrad / weight-gradient entry point returns NERF_E_BADARG when given a buffer of the wrong family, of another
+ *     ray / sample count, or an (act, delta) pair that no datapath contracts -- instead of computing garbage;
+ *   - nerf_field_wgrad_phase(datapath = -1) takes the datapath from the record.
+ * Buffers the library has not written (copies, foreign producers) are not checked.
+ * nerf_buffer_layout: the recorded kind, or -1 for an unknown buffer.  act: 0 fp32 point-major rows (nerf_field_fwd),
+ * 1 / 2 = 32-point tiles fp32 / bf16 (nerf_field_fwd_bf16x3 / _mixed), 3 / 4 = rows in 16-point tiles fp32 / bf16
+ * (nerf_field_fwd16_bf16x3, nerf_field_fwd16r_bf16x3); delta (*is_delta = 1): 0 fp32 rows, 1 / 2 = 32-point tiles fp32 / bf16. */
+int nerf_buffer_layout(const float* buf, int* is_delta, int* n_rays, int* n_samples);
 /* nerf_field_wgrad / nerf_field_wgrad_bf16x3 split into their three launches so that a profiler can bracket each:
  * phases bit 0 = the eight full-width (256x256) jobs (datapaths 1-4: all jobs), bit 1 = the six narrow jobs (fp32 datapath
  * only), bit 2 = reduction of the per-chunk partial gradients into grad.  Calling it with phases 1, 2, 4 in that order
  * equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate,
-                           int datapath /* 0 fp32; 1 fp32 operands split by the GEMM, act saved by nerf_field_fwd_bf16x3
+                           int datapath /* -1 as recorded for act / delta (above); 0 fp32; 1 fp32 operands split by the GEMM, act saved by nerf_field_fwd_bf16x3
                                            (32-point tiles); 3 the same, act saved by nerf_field_fwd16_bf16x3 (rows in
                                            16-point tiles); 2 bf16 operands (act from nerf_field_fwd_mixed, delta from
                                            nerf_field_dgrad_mixed or nerf_field_dgrad_bf16x3(delta_bf16 = 1)); 4 the
                                            same, act saved by nerf_field_fwd16_bf16x3(bf16_save = 1) (16-point tiles) */,
                            int phases, const float* params /* canonical parameters; may be NULL for datapath 0 */,
                            void* stream);
+/* ---- render_rays in one call (run_nerf.py:308-418 and its autograd): the whole of a ray batch's forward, and the whole of
+ * its backward, as ONE entry point each.  They chain the launches above in C -- coarse depths -> field -> raw2outputs
+ * [-> sample_pdf + sort -> field -> raw2outputs]; raw2outputs' adjoint -> delta chain -> weight gradients per pass -- in the
+ * order the in-repo binding issues them, so the results are bit-identical to it.  What a host provides: the ray records, the
+ * random draws in the reference's order (NULL where the reference draws nothing), the packed and canonical parameters, the
+ * outputs, and ONE scratch buffer of nerf_render_workspace_floats() floats that lives from the forward to its backward
+ * (depths, coarse raw, compositing weights; when training also the saved activations, deltas and partial gradients: ~23 KB
+ * per sample point on the default datapath -- split larger ray batches, the reference's `chunk` argument does exactly that).
+ *   precision 0: exact fp32 datapath; 1: split-bf16 (wgrad_operands_bf16 selects the storage of the weight-gradient GEMM's
+ *   operands, 1 = the default of the binding); 2: mixed-precision training option.
+ *   packed_f / params_f / grad_f NULL (or packed_f == packed_c): the fine pass uses the coarse network (network_fine None).
+ *   Outputs as the reference's dict: rgb/disp/acc/raw = the last pass (rgb_map, disp_map, acc_map, raw [n, n_coarse + n_fine, 4]);
+ *   rgb0/disp0/acc0/z_std = the coarse pass and the std of the fine samples (n_fine > 0 only).
+ *   Backward: upstream gradients of the same outputs (any may be NULL; d_raw_out = gradient of `raw`), the forward's `raw`,
+ *   noise draws and workspace; the parameter gradients are written (accumulate = 0) or added into grad_c / grad_f. */
+typedef struct NerfRenderCfg {
+    int n_coarse, n_fine;          /* N_samples, N_importance */
+    int lindisp, white_bkgd;
+    float raw_noise_std;
+    int precision;                 /* 0 fp32, 1 split-bf16, 2 mixed */
+    int wgrad_operands_bf16;       /* precision 1: operands of the weight-gradient GEMM stored as bf16 (1) or fp32 (0) */
+} NerfRenderCfg;
+size_t nerf_render_workspace_floats(const NerfRenderCfg* cfg, int n_rays, int training);
+int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const float* packed_f, const float* rays, int ray_stride,
+                         int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
+                         float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
+                         float* workspace, int training, void* stream);
+int nerf_render_rays_bwd(const NerfRenderCfg* cfg, const float* packed_c, const float* packed_f, const float* params_c,
+                         const float* params_f, const float* rays, int ray_stride, int n_rays, const float* noise_c,
+                         const float* noise_f, const float* raw, const float* d_rgb, const float* d_disp, const float* d_acc,
+                         const float* d_raw_out, const float* d_rgb0, const float* d_disp0, const float* d_acc0,
+                         float* workspace, float* grad_c, float* grad_f, int accumulate, void* stream);
+
 /* ---- optimizer.step() of run_nerf.py:776 for torch.optim.Adam(lr, betas=(beta1, beta2), eps) (run_nerf.py:207), fused over
  * a flat vector: params / grads / exp_avg / exp_avg_sq [n]; step = 1-based step count (bias correction). */
 int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,

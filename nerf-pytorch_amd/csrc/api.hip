@@ -2,23 +2,61 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
+#include <unordered_map>
 #include "nerf_common.h"
-#include "../../include/nerf_hip.h"
+#include "api_util.h"
 
 #include "launchers.h"
 
-static thread_local char g_err[256] = "";
+using nerf_api::done;
+using nerf_api::fail_arg;
 
-static int fail_arg(const char* fn, const char* what) {
-    snprintf(g_err, sizeof(g_err), "%s: %s", fn, what);
-    return NERF_E_BADARG;
+namespace nerf_api {
+
+static std::mutex g_tag_mutex;
+static std::unordered_map<const void*, BufTag> g_tags;
+
+void tag_record(const void* buf, int is_delta, int kind, int n_rays, int n_samples) {
+    if (!buf) return;
+    std::lock_guard<std::mutex> lock(g_tag_mutex);
+    if (g_tags.size() > 4096) g_tags.clear();       // a training loop re-uses a handful of buffers; this only bounds leaks
+    g_tags[buf] = BufTag{is_delta, kind, n_rays, n_samples};
 }
-static int done(const char* fn, hipError_t e) {
-    if (e == hipSuccess) return 0;
-    snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", fn, (int)e, hipGetErrorString(e));
-    return (int)e;
+bool tag_lookup(const void* buf, BufTag* out) {
+    std::lock_guard<std::mutex> lock(g_tag_mutex);
+    auto it = g_tags.find(buf);
+    if (it == g_tags.end()) return false;
+    *out = it->second;
+    return true;
 }
-#define REQUIRE(cond, what) do { if (!(cond)) return fail_arg(__func__, what); } while (0)
+int datapath_of(int act_kind, int delta_kind) {
+    if (act_kind == ACT_ROWS_F32 && delta_kind == DELTA_ROWS_F32) return 0;
+    if (act_kind == ACT_TILE32_F32 && delta_kind == DELTA_TILE32_F32) return 1;
+    if (act_kind == ACT_TILE32_BF16 && delta_kind == DELTA_TILE32_BF16) return 2;
+    if (act_kind == ACT_TILE16_F32 && delta_kind == DELTA_TILE32_F32) return 3;
+    if (act_kind == ACT_TILE16_BF16 && delta_kind == DELTA_TILE32_BF16) return 4;
+    return -1;
+}
+
+// the save buffer a dgrad is about to read: written by a forward of the same family (fp32 rows vs split-bf16 tiles: the
+// ReLU bitmasks differ) for the same point count?  0 = fine / unknown buffer
+static int check_act_for_dgrad(const char* fn, const void* act, bool split_bf16, int n_rays, int n_samples) {
+    BufTag t;
+    if (!tag_lookup(act, &t)) return 0;
+    if (t.is_delta) return fail_arg(fn, "`act` is a buffer this library last wrote DELTAS into");
+    if ((t.kind != ACT_ROWS_F32) != split_bf16)
+        return fail_arg(fn, split_bf16 ? "`act` was saved by the exact-fp32 forward (point-major rows, fp32 bitmask order): not readable by the split-bf16 dgrad"
+                                       : "`act` was saved by a split-bf16 forward (tiles, bf16x3 bitmask order): not readable by the fp32 dgrad");
+    if (t.n_rays != n_rays || t.n_samples != n_samples) {
+        snprintf(g_err, sizeof(g_err), "%s: `act` was saved for %d rays x %d samples, this call says %d x %d", fn, t.n_rays, t.n_samples, n_rays, n_samples);
+        return NERF_E_BADARG;
+    }
+    return 0;
+}
+
+}  // namespace nerf_api
+using namespace nerf_api;
 
 extern "C" {
 
@@ -116,6 +154,15 @@ size_t nerf_workspace_floats(int n_rays, int n_coarse, int n_fine, int training)
            nerf_delta_floats(n_rays, s_big) + nerf_wgrad_partial_floats(n_rays, s_big);
 }
 
+int nerf_buffer_layout(const float* buf, int* is_delta, int* n_rays, int* n_samples) {
+    BufTag t;
+    if (!buf || !tag_lookup(buf, &t)) return -1;
+    if (is_delta) *is_delta = t.is_delta;
+    if (n_rays) *n_rays = t.n_rays;
+    if (n_samples) *n_samples = t.n_samples;
+    return t.kind;
+}
+
 int nerf_field_fwd(const float* packed, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                    int n_samples, float* raw, float* act, void* stream) {
     REQUIRE(packed && rays && z_vals && raw, "null pointer");
@@ -123,6 +170,7 @@ int nerf_field_fwd(const float* packed, const float* rays, int ray_stride, const
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
+    if (act) tag_record(act, 0, ACT_ROWS_F32, n_rays, n_samples);
     return done(__func__, nerf::launch_field_fwd(packed, rays, ray_stride, z_vals, n_rays, n_samples, raw, act,
                                                  (hipStream_t)stream));
 }
@@ -177,6 +225,8 @@ int nerf_field_bwd(const float* packed, const float* act, const float* d_raw, in
     REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
             "packed/act/d_raw/delta must be 16-byte aligned");
+    if (int rc = check_act_for_dgrad(__func__, act, false, n_rays, n_samples)) return rc;
+    tag_record(delta, 1, DELTA_ROWS_F32, n_rays, n_samples);
     return done(__func__, nerf::launch_field_bwd(packed, act, d_raw, n_rays, n_samples, delta, partial, grad, accumulate,
                                                  (hipStream_t)stream));
 }
@@ -188,6 +238,8 @@ int nerf_field_dgrad(const float* packed, const float* act, const float* d_raw, 
     REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
             "packed/act/d_raw/delta must be 16-byte aligned");
+    if (int rc = check_act_for_dgrad(__func__, act, false, n_rays, n_samples)) return rc;
+    tag_record(delta, 1, DELTA_ROWS_F32, n_rays, n_samples);
     return done(__func__, nerf::launch_field_dgrad(packed, act, d_raw, n_rays, n_samples, delta, (hipStream_t)stream));
 }
 
@@ -199,15 +251,48 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
                                                    (hipStream_t)stream, nullptr));
 }
 
+// the datapath the (act, delta) pair of a weight-gradient call needs, from what the library wrote into them; -1 = unknown
+// buffers.  *rc != 0: the pair is known and impossible (or of another point count): refused.
+static int datapath_from_tags(const char* fn, const void* act, const void* delta, int n_rays, int n_samples, int* rc) {
+    BufTag ta, td;
+    *rc = 0;
+    const bool ka = tag_lookup(act, &ta), kd = tag_lookup(delta, &td);
+    if (ka && ta.is_delta) { *rc = fail_arg(fn, "`act` is a buffer this library last wrote deltas into"); return -1; }
+    if (kd && !td.is_delta) { *rc = fail_arg(fn, "`delta` is a buffer this library last wrote saved activations into"); return -1; }
+    if ((ka && (ta.n_rays != n_rays || ta.n_samples != n_samples)) || (kd && (td.n_rays != n_rays || td.n_samples != n_samples))) {
+        *rc = fail_arg(fn, "act / delta were written for another ray or sample count than this call's");
+        return -1;
+    }
+    if (!(ka && kd)) return -1;
+    const int dp = datapath_of(ta.kind, td.kind);
+    if (dp < 0) {
+        snprintf(g_err, sizeof(g_err), "%s: act layout %d (0 fp32 rows, 1/2 32-point tiles fp32/bf16, 3/4 16-point tiles fp32/bf16) cannot be "
+                 "contracted with delta kind %d (0 fp32 rows, 1/2 tiles fp32/bf16): the forward and the dgrad that wrote them belong to different datapaths",
+                 fn, ta.kind, td.kind);
+        *rc = NERF_E_BADARG;
+    }
+    return dp;
+}
+
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate, int datapath, int phases, const float* params,
                            void* stream) {
-    const int bf16x3 = datapath;
-    REQUIRE(datapath == 0 || params, "the split-bf16 / mixed datapaths need the canonical parameters (folded feature layer)");
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && bf16x3 >= 0 && bf16x3 <= 4, "bad size");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && datapath >= -1 && datapath <= 4, "bad size");
+    int rc;
+    const int recorded = datapath_from_tags(__func__, act, delta, n_rays, n_samples, &rc);
+    if (rc) return rc;
+    if (datapath < 0) {
+        REQUIRE(recorded >= 0, "datapath = -1 (as recorded) needs act and delta written by this library's forward / dgrad entry points");
+        datapath = recorded;
+    } else if (recorded >= 0 && recorded != datapath) {
+        snprintf(g_err, sizeof(g_err), "%s: datapath %d requested, but act / delta were written for datapath %d (the tiling and element type of "
+                 "the saved rows and deltas follow from the forward and dgrad entry points that produced them)", __func__, datapath, recorded);
+        return NERF_E_BADARG;
+    }
+    REQUIRE(datapath == 0 || params, "the split-bf16 / mixed datapaths need the canonical parameters (folded feature layer)");
     return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate,
-                                                   bf16x3, phases, (hipStream_t)stream, params));
+                                                   datapath, phases, (hipStream_t)stream, params));
 }
 
 int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
@@ -217,7 +302,21 @@ int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float*
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
             "packed/act/d_raw/delta must be 16-byte aligned");
+    if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
+    tag_record(delta, 1, delta_bf16 ? DELTA_TILE32_BF16 : DELTA_TILE32_F32, n_rays, n_samples);
     return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, delta_bf16 ? 2 : 0, (hipStream_t)stream));
+}
+
+int nerf_field_dgrad3r_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
+                              float* delta, int delta_bf16, void* stream) {
+    REQUIRE(packed3 && act && d_raw && delta, "null pointer");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
+            "packed/act/d_raw/delta must be 16-byte aligned");
+    if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
+    tag_record(delta, 1, delta_bf16 ? DELTA_TILE32_BF16 : DELTA_TILE32_F32, n_rays, n_samples);
+    return done(__func__, nerf::launch_field_dgrad3r(packed3, act, d_raw, n_rays, n_samples, delta, delta_bf16, (hipStream_t)stream));
 }
 
 int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
@@ -227,6 +326,8 @@ int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* 
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
             "packed/act/d_raw/delta must be 16-byte aligned");
+    if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
+    tag_record(delta, 1, DELTA_TILE32_BF16, n_rays, n_samples);
     return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, 1, (hipStream_t)stream));
 }
 
@@ -268,6 +369,7 @@ int nerf_field_fwd16_bf16x3(const float* packed3, const float* rays, int ray_str
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
+    if (act) tag_record(act, 0, bf16_save ? ACT_TILE16_BF16 : ACT_TILE16_F32, n_rays, n_samples);
     return done(__func__, nerf::launch_field_fwd16(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act,
                                                    bf16_save, (hipStream_t)stream));
 }
@@ -279,6 +381,7 @@ int nerf_field_fwd16r_bf16x3(const float* packed3, const float* rays, int ray_st
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
+    if (act) tag_record(act, 0, ACT_TILE16_BF16, n_rays, n_samples);
     return done(__func__, nerf::launch_field_fwd16r(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act,
                                                     (hipStream_t)stream));
 }
@@ -295,6 +398,7 @@ int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_strid
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
+    if (act) tag_record(act, 0, ACT_TILE32_F32, n_rays, n_samples);
     return done(__func__, nerf::launch_field_fwd3(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, 0,
                                                   (hipStream_t)stream));
 }
@@ -306,6 +410,7 @@ int nerf_field_fwd_mixed(const float* packed3, const float* rays, int ray_stride
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
+    tag_record(act, 0, ACT_TILE32_BF16, n_rays, n_samples);
     return done(__func__, nerf::launch_field_fwd3(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, 1,
                                                   (hipStream_t)stream));
 }

@@ -1,0 +1,204 @@
+// field_dgrad3r_kernel: the split-bf16 delta chain (field_dgrad3_kernel of field_bwd_bf16.hip: d_raw -> dL/d(pre-activation)
+// of every layer; the autograd of run_nerf_helpers.py:96-119) on the weight RING of field_ring.h.  32 points per wave on
+// v_mfma_f32_32x32x16_bf16, 4 waves, one per SIMD -- the shape of the double-buffered kernel -- but a wave alone on its
+// SIMD has nobody to cover what it does between MFMAs, and the double-buffered kernel spends that time after every
+// 64 KiB chunk: barrier, 16 DMA pieces per wave issued back to back, LDS latency of the first fragments, 32 row stores in
+// a burst (MFMA-busy 0.53 in the round-2 profile).  Here every MFMA (32 cycles of pipe) carries its own share of that work
+// in its shadow: one fragment request 8 MFMAs ahead of its use, a piece of the next k-step's operand split, one row
+// store, and behind each of four units per chunk a 4 KiB DMA part (field_ring.h: unit_pipelined, WeightRingT<4>).
+// Same transposed fragment stream (P3B), same MFMA order per accumulator, same masks: every delta written is
+// BIT-IDENTICAL to field_dgrad3_kernel<MODE> (tests/test_gpu_round3.py::test_ring_dgrad_bit_identical).
+// MODE 0: fp32 deltas (operands of wgrad3_256_kernel); MODE 2: the same chain, deltas written as bf16 (wgrad1_kernel).
+// The mixed-precision chain (MODE 1) stays on field_dgrad3_kernel<1>.
+#include <type_traits>
+#include "field_ring.h"
+#include "launchers.h"
+
+namespace nerf {
+
+struct FieldBwdRingArgs {
+    const float* packed3;
+    const float* act;       // saved by the forward (ReLU bitmasks in the bf16x3 lane order)
+    const float* d_raw;     // [P][4]
+    float* delta;           // delta_layout3(P): 32-point feature-major tiles
+    int n_rays, S;
+};
+
+// units of the transposed stream (P3B) in consumption order: W'^T 8 k-steps x 2 | (feature_linear^T 32: skipped) | L7^T .. L1^T 7 x 32
+constexpr int BWD3_UNITS_VIEWS = 16;
+constexpr int BWD3_UNITS_SKIP = 32;
+constexpr int BWD3_UNITS = BWD3_UNITS_VIEWS + 7 * 32;
+static_assert((BWD3_UNITS_VIEWS + BWD3_UNITS_SKIP) * UNIT_WORDS == P3B_L7 - P3B_VIEWS, "unit arithmetic vs nerf_common.h");
+static_assert(BWD3_UNITS_VIEWS % CHUNK_UNITS == 0, "the trunk starts on a chunk boundary");
+
+template <int NV>
+__device__ inline void apply_mask3r(float (&d)[NV], const f32x16* acc, u32x4 m) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned bit = (m[i >> 5] >> (i & 31)) & 1u;
+        d[i] = bit ? acc[i >> 4][i & 15] : 0.0f;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldBwdRingArgs a) {
+    static_assert(MODE == 0 || MODE == 2, "3-term chain; fp32 or bf16 deltas");
+    constexpr bool OUT16 = MODE == 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const size_t P = (size_t)a.n_rays * a.S;
+    const size_t p_raw = ((size_t)blockIdx.x * FIELD3_WAVES + wave) * PTS_PER_WAVE3 + (lane & 31);
+    const bool valid = p_raw < P;
+    const size_t p = valid ? p_raw : P - 1;
+
+    WeightRingT<FIELD3_WAVES> ring;
+    ring.start(a.packed3 + P3B_VIEWS, lds, wave, lane, BWD3_UNITS_VIEWS, BWD3_UNITS_SKIP, BWD3_UNITS);
+    stage_small_ring(a.packed3 + P3_SMALL, lds, FIELD3_WAVES * 64);
+
+    const ActLayout3 al = act_layout3(P, (size_t)a.n_rays);
+    const DeltaLayout3 dl = delta_layout3(P);
+    const size_t tile = (size_t)blockIdx.x * FIELD3_WAVES + wave;          // this wave's tile of every delta region
+    const int lslot = half * 128 + (lane & 31);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);       // (d_rgb3, d_sigma)
+    if (valid) {        // tile-major copy of d_raw: the A operand of the rgb_linear / alpha_linear weight gradients
+        const size_t goff = tile * (4 * 32) + half * 64 + (lane & 31);
+        if (OUT16) {
+            __bf16* gt = reinterpret_cast<__bf16*>(a.delta + dl.graw) + goff;
+            nt_store(gt, (__bf16)(half ? g[2] : g[0]));
+            nt_store(gt + 32, (__bf16)(half ? g[3] : g[1]));
+        } else {
+            float* gt = a.delta + dl.graw + goff;
+            nt_store(gt, half ? g[2] : g[0]);
+            nt_store(gt + 32, half ? g[3] : g[1]);
+        }
+    }
+    u32x4 msk[D + 1];
+    {
+        const u32x4* mp = reinterpret_cast<const u32x4*>(a.act + al.mask) + p * 2 + half;
+#pragma unroll
+        for (int l = 0; l <= D; ++l) msk[l] = mp[(size_t)l * P * 2];
+    }
+    ring.ready();           // small parameters staged, chunks 0 and 1 landed
+
+    // ---- rgb_linear^T (VALU) + ReLU mask of the view branch: lane value i = feature 32*(i>>4) + d32row(i&15, half)
+    float dhv[64];
+    {
+        const float* wr = ring_small_ptr(lds, SM_WRGB);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = 32 * ob + 8 * q4 + 4 * half;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + col);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + WV + col);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 2 * WV + col);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ob + 4 * q4 + r;
+                    const float v = g[0] * w0[r] + g[1] * w1[r] + g[2] * w2[r];
+                    dhv[i] = ((msk[D][i >> 5] >> (i & 31)) & 1u) ? v : 0.0f;
+                }
+            }
+    }
+
+    f32x16 acc[8];
+    float d[128];
+    // bf16 deltas: unconditional paired stores (field_device_bf16.h, store_tile3h_pair).  A wave whose tile lies beyond the
+    // padded point range (last workgroup only) writes to a dump tile: the unused `feat` region.
+    const bool tile_ok = __builtin_amdgcn_readfirstlane((int)(tile * 32 < pad32(P))) != 0;
+    const unsigned odd = (unsigned)lane & 1u;
+    const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;
+    const int pair_off = ((lane >> 5) * 4 + (int)odd) * 16 + ((lane & 31) >> 1);      // dwords inside the tile
+    // one paired bf16 store: rows (r, r + 1) of 32-feature block ob of a F-wide region (the element order of
+    // store_tile3h_pair), values v0 / v1 of this lane's point
+    auto store_pair16 = [&](size_t region_off, int F, int ob, int r, float v0, float v1) __attribute__((always_inline)) {
+        const unsigned own = pack_bf16x2(v0, v1);
+        const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
+        unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.delta + (tile_ok ? region_off : dl.feat))
+                                                     + (tile_ok ? tile * (size_t)(F * 32) : (size_t)0)) + pair_off;
+        nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, __builtin_amdgcn_perm(nbr, own, pair_sel));
+    };
+    auto store_f32 = [&](size_t region_off, int F, int ob, int r, float v) __attribute__((always_inline)) {
+        if (valid) nt_store(a.delta + region_off + tile * (size_t)(F * 32) + lslot + (32 * ob + (r & 3) + 8 * (r >> 2)) * 32, v);
+    };
+    // the deltas in `v` (value 16 ob + r) leave while the next contraction consumes them: unit i of NU writes its share
+    // (NV / NU values: bf16 pairs or single fp32 rows)
+    size_t store_region = 0;
+    constexpr int NP = OUT16 ? 8 : 0;       // row stores guaranteed behind the last fetch part (two per unit, positions 3..6)
+
+    // ---- view branch folded with feature_linear (nerf_common.h): delta of the trunk output =
+    //      (alpha_linear^T d_sigma + W'^T d_hv) * relu'(h7); the feature_linear^T units of the stream are skipped
+    {
+        const float* wa = ring_small_ptr(lds, SM_WALPHA);
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wa + 32 * ob + 8 * q4 + 4 * half);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ob][4 * q4 + r] = g[3] * w[r];
+            }
+    }
+    Frag fa, fb, fl;
+    ring.request_first(fa);
+    store_region = dl.hv;
+    ring_units<16, 2, 0, true, 0>(ring, fa, fb, fl, acc, dhv, [&](auto kk, auto gg) __attribute__((always_inline)) {
+        constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;            // unit 0..15: 64 values -> 4 per unit
+#pragma unroll
+        for (int t = 0; t < (OUT16 ? 2 : 4); ++t) {
+            const int q = (OUT16 ? 2 : 4) * i + t;
+            if (OUT16) store_pair16(store_region, WV, q / 8, 2 * (q % 8), dhv[16 * (q / 8) + 2 * (q % 8)], dhv[16 * (q / 8) + 2 * (q % 8) + 1]);
+            else store_f32(store_region, WV, q / 16, q % 16, dhv[q]);
+        }
+    });
+    apply_mask3r<128>(d, acc, msk[D - 1]);
+
+    // ---- trunk: delta_{l-1} = (W_l^T delta_l) * relu'(h_{l-1}),  l = 7 .. 1
+#pragma unroll 1
+    for (int l = D - 1; l >= 1; --l) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+        store_region = (size_t)l * pad32(P) * W;                            // dl.h[l]: delta of layer l = input of this step
+        ring_units<32, 2, 0, false, NP>(ring, fa, fb, fl, acc, d, [&](auto kk, auto gg) __attribute__((always_inline)) {
+            constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;        // unit 0..31: 128 values -> 4 per unit
+#pragma unroll
+            for (int t = 0; t < (OUT16 ? 2 : 4); ++t) {
+                const int q = (OUT16 ? 2 : 4) * i + t;
+                if (OUT16) store_pair16(store_region, W, q / 8, 2 * (q % 8), d[16 * (q / 8) + 2 * (q % 8)], d[16 * (q / 8) + 2 * (q % 8) + 1]);
+                else store_f32(store_region, W, q / 16, q % 16, d[q]);
+            }
+        });
+        u32x4 m = msk[0];                   // ReLU bitmask of h_{l-1} (static indices only: msk stays in registers)
+#pragma unroll
+        for (int t = 1; t < D; ++t) if (t == l - 1) m = msk[t];
+        apply_mask3r<128>(d, acc, m);
+    }
+    // dl.h[0]
+    if (OUT16) store_tile3h_pair<0, 8>(reinterpret_cast<__bf16*>(a.delta + (tile_ok ? (size_t)0 : dl.feat)) + (tile_ok ? tile * (size_t)(W * 32) : (size_t)0), lane, d);
+    else if (valid) store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);
+}
+
+hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
+                                float* delta, int bf16_out, hipStream_t stream) {
+    const long P = (long)n_rays * S;
+    if (P <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)field_dgrad3r_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    FieldBwdRingArgs ba{packed3, act, d_raw, delta, n_rays, S};
+    const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
+    if (bf16_out) hipLaunchKernelGGL(field_dgrad3r_kernel<2>, dim3(blocks), dim3(FIELD3_WAVES * 64), RING_LDS_FLOATS * 4, stream, ba);
+    else hipLaunchKernelGGL(field_dgrad3r_kernel<0>, dim3(blocks), dim3(FIELD3_WAVES * 64), RING_LDS_FLOATS * 4, stream, ba);
+    return hipGetLastError();
+}
+
+}  // namespace nerf

@@ -120,8 +120,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
 
     ring.ready();
     Frag fa, fb, fl;
-    if constexpr (RING_PINGPONG) { if (wave >= 4) __syncthreads(); }       // waves 4-7 run one barrier behind
-    else ring.request_first(fa);
+    ring.request_first(fa);
 
     // ---- layer 0: 63 -> 256 (2 k-steps of the xyz encoding)
     load_bias<16>(acc, bias, q);
@@ -179,7 +178,6 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
         };
         ring_units<16, 2, 0, false, NP>(ring, fa, fb, fl, av, h, store_rows_v);
         ring_units<2, 2, 0, false, 0>(ring, fa, fb, fl, av, dv, no_store);
-        if constexpr (RING_PINGPONG) { if (wave < 4) __syncthreads(); }     // pairs with the last barrier of waves 4-7
     }
     float hv[32];
 #pragma unroll

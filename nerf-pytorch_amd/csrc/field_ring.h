@@ -28,15 +28,6 @@ constexpr int UNIT_WORDS = 4 * 2 * 64 * 4;                  // 2048 words = 8 Ki
 constexpr int RING_FLOATS = RING_UNITS * UNIT_WORDS;        // 136 KiB
 constexpr int RING_LDS_FLOATS = RING_FLOATS + SMALL_FLOATS;
 constexpr int CHUNK_UNITS = 8;
-// Schedule of the two waves that share a SIMD (waves w and w + 4 of the 512-thread workgroup):
-//   false: both run the same pipelined stream (unit_pipelined) and meet at one barrier per chunk;
-//   true:  PING-PONG.  Every unit is split into a load phase L (request its fragments, operand split, row store, DMA
-//          part) and a matrix phase M (12 MFMAs at s_setprio 1), each closed by a workgroup barrier, and waves 4-7 run ONE
-//          barrier behind waves 0-3: between two barriers one wave of every SIMD issues nothing but MFMAs while the
-//          other does everything else (cdna_hip_programming.md T3/T5: setprio and a second wave only pay when the two
-//          waves are in different roles; in lockstep the second wave covers nothing).
-constexpr bool RING_PINGPONG = false;
-
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -56,7 +47,11 @@ __device__ inline const float* ring_small_ptr(const float* lds, int sm_offset) {
 
 // Stream description: unit u of the consumed sequence lives at word offset (u < skip_at ? u : u + skip_units) * UNIT_WORDS
 // of `src` (the folded feature layer's units stay in the packed stream and are jumped over); n_units in total.
-struct WeightRing {
+// NWAVES waves share the ring; each fetches 8 / NWAVES consecutive units of every chunk (8 waves: the 16-point kernels, one
+// unit each; 4 waves: the 32-point kernels, two units each).
+template <int NWAVES>
+struct WeightRingT {
+    static constexpr int UPW = CHUNK_UNITS / NWAVES;    // units per wave and chunk
     const float* src;
     const u32x4* lane_ptr;      // LDS: ring base + lane (u32x4 units)
     unsigned ring_base;         // LDS byte address of the ring
@@ -64,15 +59,21 @@ struct WeightRing {
     int skip_at, skip_units, n_units;
     int slot;                   // ring slot of the next unit to REQUEST (wave-uniform)
     int dma_chunk;              // next chunk to fetch
-    int dma_slot;               // ring slot of unit 8 * dma_chunk + wave
+    int dma_slot;               // ring slot of the first unit of this wave's span of chunk dma_chunk
 
-    // part K (0..3, 2 KiB each) of this wave's unit of chunk c
+    // part K (0..3) of this wave's span of chunk c: 2 KiB of its unit (8 waves) or 4 KiB = half a unit (4 waves)
     template <int K>
     __device__ __forceinline__ void fetch_part(int c) {
-        const int uu = CHUNK_UNITS * c + wave;
+        static_assert(UPW == 1 || UPW == 2, "8 or 4 waves");
+        const int uu = CHUNK_UNITS * c + wave * UPW + (UPW == 2 ? K / 2 : 0);
         if (uu < n_units) {
-            const float* g = src + (size_t)(uu < skip_at ? uu : uu + skip_units) * UNIT_WORDS + K * 512 + lane * 4;
-            dma_2k(g, ring_base + (unsigned)dma_slot * (UNIT_WORDS * 4u) + K * 2048u);
+            int sl = dma_slot + (UPW == 2 ? K / 2 : 0);
+            if (sl >= RING_UNITS) sl -= RING_UNITS;
+            const int within = UPW == 2 ? (K % 2) * 1024 : K * 512;         // words inside the unit
+            const float* g = src + (size_t)(uu < skip_at ? uu : uu + skip_units) * UNIT_WORDS + within + lane * 4;
+            const unsigned dst = ring_base + (unsigned)sl * (UNIT_WORDS * 4u) + (unsigned)within * 4u;
+            if (UPW == 2) dma_4k(g, dst);
+            else dma_2k(g, dst);
         }
     }
     __device__ __forceinline__ void fetch_unit(int c) { fetch_part<0>(c); fetch_part<1>(c); fetch_part<2>(c); fetch_part<3>(c); }
@@ -87,9 +88,9 @@ struct WeightRing {
         ring_base = __builtin_amdgcn_readfirstlane(lds_addr(lds));
         lane_ptr = reinterpret_cast<const u32x4*>(lds) + lane;
         slot = 0;
-        dma_chunk = 0; dma_slot = wave;
+        dma_chunk = 0; dma_slot = wave * UPW;
         fetch_unit(0); advance_dma();
-        fetch_unit(1); advance_dma();           // dma_slot = (16 + wave) mod 17
+        fetch_unit(1); advance_dma();           // dma_slot = (16 + wave * UPW) mod 17
     }
     __device__ __forceinline__ void ready() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -100,17 +101,6 @@ struct WeightRing {
         p = lane_ptr + slot * (UNIT_WORDS / 4);
         slot = slot + 1 == RING_UNITS ? 0 : slot + 1;
         pn = lane_ptr + slot * (UNIT_WORDS / 4);
-    }
-    // ping-pong schedule: LDS address of the next unit (advances the ring position)
-    __device__ __forceinline__ const u32x4* unit_ptr() {
-        const u32x4* p = lane_ptr + slot * (UNIT_WORDS / 4);
-        slot = slot + 1 == RING_UNITS ? 0 : slot + 1;
-        return p;
-    }
-    template <int NPEND>
-    __device__ __forceinline__ void wait_fetch() {
-        if (NPEND > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPEND) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // the hi fragments of the very first unit (slot stays on that unit)
     __device__ __forceinline__ void request_first(Frag& hi) {
@@ -135,6 +125,7 @@ struct WeightRing {
         if constexpr (K == 3) advance_dma();
     }
 };
+using WeightRing = WeightRingT<8>;
 
 // one (hi, lo) word pair of a B operand: values (v0, v1) -> bf16x2 hi word, bf16x2 word of the remainders (split8, one pair)
 __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
@@ -143,33 +134,36 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
     lo = pack_bf16x2(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
 }
 
+__device__ __forceinline__ f32x4 mfma_acc(u32x4 a, u32x4 b, f32x4 c) { return mfma16_bf16(a, b, c); }      // 16 points / wave
+__device__ __forceinline__ f32x16 mfma_acc(u32x4 a, u32x4 b, f32x16 c) { return mfma_bf16(a, b, c); }     // 32 points / wave
+
 // ONE UNIT, instruction by instruction (sched_barrier(0) pins the order; hipcc's own schedule of the same work is
 // [8 requests][operand split][12 MFMAs], and because the two waves of a SIMD run the same stream in lockstep, a phase
 // without MFMAs is a phase in which that SIMD's matrix pipe idles -- measured on the phased kernel: removing the
 // requests / the split / the DMA gained their full issue time, the second wave covered none of it).  Every MFMA is
 // followed by at most one LDS request or a few VALU operations, which issue in its 16-cycle shadow:
-//     hi[i] * bhi   + request lo[i] of THIS unit        (used 8 MFMAs later)
+//     hi[i] * bhi   + request lo[i] of THIS unit        (used 8 MFMAs later)   [16x16x32 or 32x32x16 MFMAs: mfma_acc]
 //     hi[i] * blo   + request hi[i] of the NEXT unit    (used 8 MFMAs later, in the next unit)
 //     lo[i] * bhi   + `tail(i)`: a quarter of the next k-step's operand split, the unit's row store
 // The order per accumulator (hi*hi, hi*lo, lo*hi) is the order of mma16_group: results stay bit-identical.
-template <int NB, typename Tail>
-__device__ __forceinline__ void unit_pipelined(f32x4 (&acc)[NB], int g4, const Frag& cur, Frag& lo, Frag& nxt, const u32x4* p, const u32x4* pn,
+template <int NB, typename Acc, typename Tail>
+__device__ __forceinline__ void unit_pipelined(Acc (&acc)[NB], int g4, const Frag& cur, Frag& lo, Frag& nxt, const u32x4* p, const u32x4* pn,
                                                const u32x4 bhi, const u32x4 blo, Tail tail) {
     static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        acc[g4 + i] = mfma16_bf16(cur.w[i], bhi, acc[g4 + i]);
+        acc[g4 + i] = mfma_acc(cur.w[i], bhi, acc[g4 + i]);
         lo.w[i] = p[(2 * i + 1) * 64];
         __builtin_amdgcn_sched_barrier(0);
     });
     static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        acc[g4 + i] = mfma16_bf16(cur.w[i], blo, acc[g4 + i]);
+        acc[g4 + i] = mfma_acc(cur.w[i], blo, acc[g4 + i]);
         nxt.w[i] = pn[(2 * i) * 64];
         __builtin_amdgcn_sched_barrier(0);
     });
     static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        acc[g4 + i] = mfma16_bf16(lo.w[i], bhi, acc[g4 + i]);
+        acc[g4 + i] = mfma_acc(lo.w[i], bhi, acc[g4 + i]);
         tail(ic);
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -181,54 +175,10 @@ __device__ __forceinline__ void unit_pipelined(f32x4 (&acc)[NB], int g4, const F
 // (row stores).  NPEND: see WeightRing::barrier (the row stores of positions 3..6 follow the last part of a fetch: 4 when
 // one per unit).  fa holds the hi fragments of the first unit on entry and of the unit after the last one on exit (NU is
 // even); fb is the second hi set, fl the lo set of the unit in progress.
-template <int NU, int G, int VOFF, bool FIRST, int NPEND, int NB, int NV, typename After>
-__device__ __forceinline__ void ring_units(WeightRing& ring, Frag& fa, Frag& fb, Frag& fl, f32x4 (&acc)[NB], const float (&v)[NV], After after) {
+template <int NU, int G, int VOFF, bool FIRST, int NPEND, int NW, typename Acc, int NB, int NV, typename After>
+__device__ __forceinline__ void ring_units(WeightRingT<NW>& ring, Frag& fa, Frag& fb, Frag& fl, Acc (&acc)[NB], const float (&v)[NV], After after) {
     static_assert(NU % 2 == 0, "fragment sets alternate");
     static_assert(G == 4 || G == 2, "units per k-step");
-    if constexpr (RING_PINGPONG) {
-        u32x4 bhi, blo, nhi, nlo;
-        split8(&v[VOFF], nhi, nlo);
-        static_for<0, NU>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int s = i / G, g = i % G, pos = i % CHUNK_UNITS;
-            constexpr bool more = (s + 1) * G < NU;
-            // ---- L: fragments of this unit, a share of the next k-step's operand split, the row store, a DMA part
-            if constexpr (g == 0) { bhi = nhi; blo = nlo; }
-            const u32x4* p = ring.unit_ptr();
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { fa.w[k] = p[(2 * k) * 64]; fl.w[k] = p[(2 * k + 1) * 64]; }
-            if constexpr (more) {
-                constexpr int per = 4 / G;
-#pragma unroll
-                for (int t = 0; t < per; ++t) {
-                    const int j = per * g + t;
-                    unsigned wh, wl;
-                    split_pair(v[VOFF + 8 * (s + 1) + 2 * j], v[VOFF + 8 * (s + 1) + 2 * j + 1], wh, wl);
-                    nhi[j] = wh;
-                    nlo[j] = wl;
-                }
-            }
-            after(std::integral_constant<int, s>{}, std::integral_constant<int, g>{});
-            if constexpr (pos < 4 && !(FIRST && i < 4)) {
-                ring.template fetch_part<pos>(ring.dma_chunk);
-                if constexpr (pos == 3) ring.advance_dma();
-            }
-            if constexpr (pos == CHUNK_UNITS - 1) ring.template wait_fetch<NPEND>();
-            __syncthreads();
-            // ---- M
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[4 * g + k] = mfma16_bf16(fa.w[k], bhi, acc[4 * g + k]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[4 * g + k] = mfma16_bf16(fa.w[k], blo, acc[4 * g + k]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[4 * g + k] = mfma16_bf16(fl.w[k], bhi, acc[4 * g + k]);
-            __builtin_amdgcn_s_setprio(0);
-            if constexpr (pos == CHUNK_UNITS - 1) ring.template wait_fetch<NPEND>();
-            __syncthreads();
-        });
-        return;
-    }
     // B operand (hi, lo) of the k-step in progress and of the next one: the split of k-step s+1 is spread over the units
     // of k-step s (4 / G word pairs each), in the shadow of their last MFMAs
     u32x4 bhi, blo, nhi, nlo;
@@ -244,7 +194,7 @@ __device__ __forceinline__ void ring_units(WeightRing& ring, Frag& fa, Frag& fb,
         const u32x4 *p, *pn;
         ring.unit_ptrs(p, pn);
         __builtin_amdgcn_sched_barrier(0);
-        unit_pipelined<NB>(acc, 4 * g, cur, fl, nxt, p, pn, bhi, blo, [&](auto tc) __attribute__((always_inline)) {
+        unit_pipelined(acc, 4 * g, cur, fl, nxt, p, pn, bhi, blo, [&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
             if constexpr (more && ((G == 4 && t == 0) || (G == 2 && t < 2))) {
                 constexpr int j = G == 4 ? g : 2 * g + t;

@@ -70,5 +70,7 @@ hipError_t launch_field_fwd16(const float* packed3, const float* rays, int ray_s
                               int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
 hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                                int n_rays, int S, float* raw, float* act, hipStream_t stream);
+hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
+                                float* delta, int bf16_out, hipStream_t stream);
 
 }  // namespace nerf

@@ -15,7 +15,7 @@ from . import build as _build
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
-ABI_VERSION = 4        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
+ABI_VERSION = 5        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
 
 
 class NerfHipError(RuntimeError):
@@ -36,6 +36,7 @@ def _declare(lib):
         "nerf_sample_coarse": (i, [p, i, i, p, i, i, p, p, p]),
         "nerf_make_rays": (i, [i, i, p, p, p, i, f, f, p, i, p]),
         "nerf_assemble_rays": (i, [p, p, l, i, i, i, f, f, f, p, i, p]),
+        "nerf_buffer_layout": (i, [p, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(i)]),
         "nerf_act_floats": (sz, [i, i]),
         "nerf_workspace_floats": (sz, [i, i, i, i]),
         "nerf_field_fwd": (i, [p, p, i, p, i, i, p, p, p]),
@@ -53,6 +54,7 @@ def _declare(lib):
         "nerf_field_fwd_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_debug_pack3_table": (i, [p]),
         "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, i, p]),
+        "nerf_field_dgrad3r_bf16x3": (i, [p, p, p, i, i, p, i, p]),
         "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p, p]),
         "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p, p]),
         "nerf_field_fwd_mixed": (i, [p, p, i, p, i, i, p, p, p]),
@@ -62,6 +64,9 @@ def _declare(lib):
         "nerf_field_dgrad_mixed": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p, p]),
         "nerf_adam_step": (i, [p, p, p, p, i, f, f, f, f, i, p]),
+        "nerf_render_workspace_floats": (sz, [p, i, i]),
+        "nerf_render_rays_fwd": (i, [p, p, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p, i, p]),
+        "nerf_render_rays_bwd": (i, [p, p, p, p, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p, i, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
@@ -71,12 +76,13 @@ def _declare(lib):
 
 
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
-           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
+           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_buffer_layout", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
-           "nerf_field_dgrad_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_field_fwd16r_bf16x3", "nerf_debug_pack16_table",
-           "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step"]
+           "nerf_field_dgrad_bf16x3", "nerf_field_dgrad3r_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_field_fwd16r_bf16x3", "nerf_debug_pack16_table",
+           "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step",
+           "nerf_render_workspace_floats", "nerf_render_rays_fwd", "nerf_render_rays_bwd"]
 
 
 def lib():
@@ -261,6 +267,11 @@ FWD_16PT = __import__("os").environ.get("NERF_FWD16", "ring") != "0"
 FWD_RING = __import__("os").environ.get("NERF_FWD16", "ring") == "ring"
 
 
+# the split-bf16 delta chain on the weight ring (csrc/field_bwd_ring.hip; bit-identical deltas); NERF_DGRAD=stream selects
+# the double-buffered kernel
+DGRAD_RING = __import__("os").environ.get("NERF_DGRAD", "ring") == "ring"
+
+
 def _small_offset():
     # SM_BIAS of csrc/nerf_common.h = first word after the fp32 forward + backward weight streams
     return 593408 + 557056
@@ -380,6 +391,23 @@ def max_saved_rays(n_coarse, n_fine):
     return max(1, SAVE_BUDGET_BYTES // max(per_1024, 1)) * 1024
 
 
+class NerfRenderCfg(ctypes.Structure):
+    """include/nerf_hip.h NerfRenderCfg (render_rays in one call)"""
+    _fields_ = [("n_coarse", ctypes.c_int), ("n_fine", ctypes.c_int), ("lindisp", ctypes.c_int), ("white_bkgd", ctypes.c_int),
+                ("raw_noise_std", ctypes.c_float), ("precision", ctypes.c_int), ("wgrad_operands_bf16", ctypes.c_int)]
+
+
+ACT_LAYOUTS = {0: "fp32 rows", 1: "tile32 fp32", 2: "tile32 bf16", 3: "tile16 fp32", 4: "tile16 bf16"}
+
+
+def buffer_layout(buf):
+    """What the library recorded for a scratch buffer it wrote (nerf_buffer_layout): (kind, is_delta, n_rays, n_samples),
+    kind -1 = unknown.  act kinds: ACT_LAYOUTS; delta kinds: 0 fp32 rows, 1 / 2 tiles fp32 / bf16."""
+    d, n, s_ = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    kind = lib().nerf_buffer_layout(buf.data_ptr(), ctypes.byref(d), ctypes.byref(n), ctypes.byref(s_))
+    return kind, bool(d.value), n.value, s_.value
+
+
 def _row16(f):
     """csrc/nerf_common.h row16(): row of feature f inside a 16-point tile (numpy / torch integer arrays or ints)."""
     return (f & ~15) + 8 * ((f >> 3) & 1) + 2 * (f & 3) + ((f >> 2) & 1)
@@ -400,10 +428,11 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
     2-byte elements (mixed; bf16x3 with WGRAD_OPERANDS == "bf16"; default: what field_fwd recorded) in 32-point tiles,
     or — rows saved by the 16-point forward, tile16=True — in 16-point tiles with the row16h row order."""
     tiled = precision in ("bf16x3", "mixed")
+    kind = buffer_layout(buf)[0] if buf.is_cuda else -1
     if tile16 is None:
-        tile16 = getattr(buf, "nerf_tile16", False)
+        tile16 = kind in (3, 4)
     if bf16 is None:
-        bf16 = precision == "mixed" or bool(getattr(buf, "nerf_bf16", False))
+        bf16 = precision == "mixed" or kind in (2, 4)
     Pa = (P + 31) // 32 * 32 if tiled else P
     widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
     off = 0
@@ -429,9 +458,6 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     S = z_vals.shape[1]
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
     act = WORKSPACE.take(act_floats(n, S), rays.device) if save_act else None
-    if act is not None:
-        act.nerf_tile16 = False
-        act.nerf_bf16 = False
     b16 = _bf16_operands(precision)
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in ("bf16x3", "mixed"):
@@ -448,12 +474,8 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
                 _check(lib().nerf_field_fwd16_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                                      n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
                        "nerf_field_fwd16_bf16x3")
-        if act is not None:
-            act.nerf_tile16 = True      # rows in 16-point tiles (fp32: row16 order, bf16: row16h order): the GEMM must know
-            act.nerf_bf16 = bool(bf16_save)
         return raw, act
     if b16 and save_act:
-        act.nerf_bf16 = True
         with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD3_PER_POINT * n * S, BYTES_ACT3_BF16_PER_POINT * n * S):
             _check(lib().nerf_field_fwd_mixed(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                               n, S, _ptr(raw), _ptr(act, "act"), _stream()), "nerf_field_fwd_mixed")
@@ -542,24 +564,29 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32", params=Non
 def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S, params):
     b3 = precision == "bf16x3"
     mx = precision == "mixed"
-    b16 = b3 and bool(getattr(act, "nerf_bf16", False))        # bf16x3 chain, bf16-stored GEMM operands (WGRAD_OPERANDS)
+    # what the forward wrote into `act` (the library's own record, nerf_buffer_layout): bf16 rows => bf16 deltas + the bf16
+    # streaming GEMM; the weight-gradient call below passes datapath = -1 ("as recorded"), and a mismatched pairing is
+    # refused by the library (NERF_E_BADARG)
+    kind = buffer_layout(act)[0]
+    b16 = b3 and kind in (2, 4)        # bf16x3 chain, bf16-stored GEMM operands (WGRAD_OPERANDS)
     P = n * S
     if mx:
         with _timed("field_dgrad3_kernel<mixed>", FLOP_DGRAD3_PER_POINT * P, BYTES_DELTA3_BF16_PER_POINT * P):
             _check(L.nerf_field_dgrad_mixed(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
                                             _ptr(delta), _stream()), "nerf_field_dgrad_mixed")
     elif b3:
-        with _timed("field_dgrad3_kernel<bf16 out>" if b16 else "field_dgrad3_kernel", FLOP_DGRAD3_PER_POINT * P,
+        base = "field_dgrad3r_kernel" if DGRAD_RING else "field_dgrad3_kernel"
+        with _timed(base + ("<bf16 out>" if b16 else ""), FLOP_DGRAD3_PER_POINT * P,
                     (BYTES_DELTA3_BF16_PER_POINT if b16 else BYTES_DELTA3_PER_POINT) * P):
-            _check(L.nerf_field_dgrad_bf16x3(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
-                                             _ptr(delta), int(b16), _stream()), "nerf_field_dgrad_bf16x3")
+            fn = L.nerf_field_dgrad3r_bf16x3 if DGRAD_RING else L.nerf_field_dgrad_bf16x3
+            _check(fn(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta), int(b16), _stream()),
+                   "nerf_field_dgrad3r_bf16x3" if DGRAD_RING else "nerf_field_dgrad_bf16x3")
     else:
         with _timed("field_dgrad_kernel", FLOP_DGRAD_PER_POINT * P, BYTES_DELTA_PER_POINT * P):
             _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
                                       _stream()), "nerf_field_dgrad")
     bf16_gemm = mx or b16
-    t16 = bool(getattr(act, "nerf_tile16", False))
-    datapath = (4 if t16 else 2) if bf16_gemm else ((3 if t16 else 1) if b3 else 0)
+    datapath = -1
     args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),
             int(bool(accumulate)), datapath)
     tail = (_ptr(params, "params", True), _stream())

@@ -743,7 +743,7 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S, monkeypatch):
         _, act32 = npa.hip_backend.field_fwd(nf.packed_params("bf16x3"), rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
     finally:
         npa.hip_backend.FWD_16PT = True
-    assert not getattr(act32, "nerf_tile16", False)
+    assert npa.hip_backend.buffer_layout(act32)[0] == 1       # 32-point tiles, fp32
     act32 = act32.cpu()
     check_masks(act32, False)
     for region in [f"h{l}" for l in range(8)] + ["hv", "enc"]:
@@ -775,8 +775,8 @@ def test_field_backward_bf16x3(npa, dev, nets, n_rays, S, fwd16, operands, monke
     monkeypatch.setattr(npa.hip_backend, "FWD_16PT", fwd16)
     monkeypatch.setattr(npa.hip_backend, "WGRAD_OPERANDS", operands)
     raw, act = npa.hip_backend.field_fwd(packed3, rays.to(dev), z.to(dev), save_act=True, precision="bf16x3")
-    assert bool(getattr(act, "nerf_tile16", False)) == fwd16
-    assert bool(getattr(act, "nerf_bf16", False)) == (operands == "bf16")
+    kind = npa.hip_backend.buffer_layout(act)[0]              # the library's own record of what it wrote (nerf_buffer_layout)
+    assert kind == {(True, "bf16"): 4, (True, "fp32"): 3, (False, "bf16"): 2, (False, "fp32"): 1}[(fwd16, operands)]
     grad = torch.full((595844,), float("nan"), device=dev)
     npa.hip_backend.field_bwd(packed3, act, d_raw.to(dev), grad, accumulate=False, precision="bf16x3", params=nf.flat_params())
     # accumulate=True adds (also through the fold kernel that produces dWf, dbf and dWv[:, :256])
@@ -924,7 +924,7 @@ def test_mixed_forward_is_bf16x3_and_saves_bf16(npa, dev, nets, n_rays, S, monke
     raw_b, act_b = hb.field_fwd(nf.packed_params("bf16x3"), orc.synthetic_rays(n_rays, seed=S + 5).to(dev),
                                 torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0].to(dev),
                                 save_act=True, precision="bf16x3")
-    assert hb.WGRAD_OPERANDS == "bf16" and act_b.nerf_bf16 and act_b.nerf_tile16      # bf16 rows in 16-point tiles
+    assert hb.WGRAD_OPERANDS == "bf16" and hb.buffer_layout(act_b)[0] == 4      # bf16 rows in 16-point tiles
     monkeypatch.setattr(hb, "WGRAD_OPERANDS", "fp32")
     rays = orc.synthetic_rays(n_rays, seed=S + 5).to(dev)
     z = torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0].to(dev)
@@ -945,7 +945,7 @@ def test_mixed_forward_is_bf16x3_and_saves_bf16(npa, dev, nets, n_rays, S, monke
     # the 32-point forward writes the same values into 32-point bf16 tiles
     monkeypatch.setattr(hb, "FWD_16PT", False)
     raw32, actm32 = hb.field_fwd(packed3, rays, z, save_act=True, precision="mixed")
-    assert actm32.nerf_bf16 and not actm32.nerf_tile16
+    assert hb.buffer_layout(actm32)[0] == 2
     for region in [f"h{l}" for l in range(8)] + ["hv"]:
         a, b = hb.saved_rows(actm32, P, region, "mixed"), hb.saved_rows(actm, P, region, "mixed")
         assert maxdiff(a, b) <= 1e-2 * max(1.0, float(b.abs().max())), region      # same rows to bf16 rounding of ~1e-5 differences

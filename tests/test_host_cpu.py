@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/nerf_hip.h but not exported"
     assert declared == set(npa.hip_backend.EXPORTS), declared ^ set(npa.hip_backend.EXPORTS)
     L = npa.hip_backend.lib()
-    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 4 and L.nerf_param_count() == 595844
+    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 5 and L.nerf_param_count() == 595844
     assert L.nerf_packed_floats() % 4 == 0
 
 
@@ -383,3 +383,43 @@ def test_batchify_rays_slices_injected_randoms(monkeypatch):
     import pytest
     with pytest.raises(ValueError):
         render.batchify_rays(rays, chunk=4, randoms={"t_rand": rnd["t_rand"][:7]})
+
+
+def test_buffer_tags_refuse_mismatched_pairings():
+    """C ABI: the library records which layout its forward / dgrad entry points wrote into a scratch buffer and refuses a
+    dgrad or weight-gradient call that pairs buffers of different datapaths (NERF_E_BADARG) instead of computing garbage.
+    Host-only: with n_rays = 0 no kernel is launched and no pointer is dereferenced, so fake (aligned) addresses do."""
+    import ctypes
+    import nerf_pytorch_amd as npa
+    hb = npa.hip_backend
+    L = hb.lib()
+    packed, rays, z, raw, act, act2, delta, d_raw, partial, grad, params = (0x10000 * (k + 1) for k in range(11))
+    kind = lambda buf: L.nerf_buffer_layout(buf, None, None, None)
+    assert kind(act) == -1                                                   # unknown buffer
+    assert L.nerf_field_fwd16r_bf16x3(packed, rays, 11, z, 0, 64, raw, act, None) == 0
+    assert kind(act) == 4                                                    # rows in 16-point bf16 tiles
+    assert L.nerf_field_fwd(packed, rays, 11, z, 0, 64, raw, act2, None) == 0
+    assert kind(act2) == 0                                                   # fp32 point-major rows
+    # a split-bf16 dgrad on the fp32 forward's save buffer (other bitmask order, other layout): refused
+    assert L.nerf_field_dgrad3r_bf16x3(packed, act2, d_raw, 0, 64, delta, 1, None) == -1
+    assert b"exact-fp32 forward" in L.nerf_last_error()
+    assert L.nerf_field_dgrad(packed, act, d_raw, 0, 64, delta, None) == -1
+    # other sample count than the forward's: refused
+    assert L.nerf_field_dgrad3r_bf16x3(packed, act, d_raw, 0, 32, delta, 1, None) == -1
+    # bf16 rows + fp32 deltas: no weight-gradient datapath contracts that pair
+    assert L.nerf_field_dgrad3r_bf16x3(packed, act, d_raw, 0, 64, delta, 0, None) == 0
+    is_delta = ctypes.c_int(0)
+    assert L.nerf_buffer_layout(delta, ctypes.byref(is_delta), None, None) == 1 and is_delta.value == 1
+    assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, -1, 7, params, None) == -1
+    assert b"different datapaths" in L.nerf_last_error()
+    # the matching pair: datapath -1 resolves to 4; an explicit other datapath is refused
+    assert L.nerf_field_dgrad3r_bf16x3(packed, act, d_raw, 0, 64, delta, 1, None) == 0
+    assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, -1, 7, params, None) == 0
+    assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, 4, 7, params, None) == 0
+    assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, 2, 7, params, None) == -1
+    assert b"datapath 2 requested" in L.nerf_last_error()
+    # act and delta swapped
+    assert L.nerf_field_wgrad_phase(delta, act, d_raw, 0, 64, partial, grad, 0, -1, 7, params, None) == -1
+    # buffers the library never wrote are not checked (datapath must then be given)
+    assert L.nerf_field_wgrad_phase(0x900000, 0xA00000, d_raw, 0, 64, partial, grad, 0, 2, 7, params, None) == 0
+    assert L.nerf_field_wgrad_phase(0x900000, 0xA00000, d_raw, 0, 64, partial, grad, 0, -1, 7, params, None) == -1

@@ -22,7 +22,10 @@ raw = torch.empty(N, 192, 4, device=dev)
 act = torch.empty(hb.act_floats(N, 192), device=dev)
 only = sys.argv[1:]
 libs = sorted(glob.glob(os.path.join(ROOT, "nerf-pytorch_amd", "libexp_*.so")))
-print("variant          infer192  save192  infer64  save64   (ms, min of 2 x 10 launches)", flush=True)
+d_raw = torch.randn(N, 192, 4, device=dev)
+delta = torch.empty(hb.lib().nerf_delta_floats(N, 192), device=dev)
+hb.lib().nerf_field_fwd16r_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, zs[192].data_ptr(), N, 192, raw.data_ptr(), act.data_ptr(), s)
+print("variant          infer192  save192  infer64  save64  dgrad192(bf16 out)  (ms, min of 2 x 10 launches)", flush=True)
 for path in libs:
     name = os.path.basename(path)[7:-3]
     if only and name not in only:
@@ -45,4 +48,16 @@ for path in libs:
                 e1.record(); torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / 10)
             out.append(best)
-    print(f"{name:16s} {out[0]:8.4f} {out[1]:8.4f} {out[2]:8.4f} {out[3]:8.4f}", flush=True)
+    best = 1e9
+    assert L.nerf_field_fwd16r_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, zs[192].data_ptr(), N, 192, raw.data_ptr(), act.data_ptr(), s) == 0
+    assert L.nerf_field_dgrad3r_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), 1, s) == 0, L.nerf_last_error()
+    for rep in range(2):
+        for _ in range(2):
+            L.nerf_field_dgrad3r_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), 1, s)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            L.nerf_field_dgrad3r_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, 192, delta.data_ptr(), 1, s)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 10)
+    print(f"{name:16s} {out[0]:8.4f} {out[1]:8.4f} {out[2]:8.4f} {out[3]:8.4f} {best:8.4f}", flush=True)

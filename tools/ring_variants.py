@@ -29,7 +29,6 @@ def nobar(d):
 
 def nodma(d):
     patch(R(d), "        if constexpr (K < 4) fetch_part<K>(dma_chunk);", "        if constexpr (K < 4) { if (dma_chunk < -5) fetch_part<K>(dma_chunk); }")
-    patch(R(d), "                ring.template fetch_part<pos>(ring.dma_chunk);", "                if (ring.dma_chunk < -5) ring.template fetch_part<pos>(ring.dma_chunk);")
 
 
 def nolds(d):      # no fragment requests (the three sets keep the first unit's fragments)
@@ -47,6 +46,32 @@ def nosplit(d):
     patch(R(d), "            if constexpr (more && ((G == 4 && t == 0) || (G == 2 && t < 2))) {", "            if constexpr (false) {")
 
 
+B = lambda d: os.path.join(d, "field_bwd_ring.hip")
+
+
+def nostore(d):     # dgrad: no delta stores; forward: no row stores
+    patch(B(d), "        nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, __builtin_amdgcn_perm(nbr, own, pair_sel));",
+          "        if (own == 0x12345678u) nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, __builtin_amdgcn_perm(nbr, own, pair_sel));")
+    patch(F(d), "        nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);", "        if (word == 0x12345678u) nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);")
+
+
+def nolds_b(d):
+    nolds(d)
+    patch(B(d), "    Frag fa, fb, fl;\n    ring.request_first(fa);", "    Frag fa, fb, fl;\n    ring.request_first(fa); ring.request_first(fb); ring.request_first(fl);")
+
+
+def noepi(d):       # dgrad: no ReLU-mask arithmetic in the layer epilogue (acc copied as is); forward: no ReLU bitmask construction
+    patch(B(d), "        const unsigned bit = (m[i >> 5] >> (i & 31)) & 1u;\n        d[i] = bit ? acc[i >> 4][i & 15] : 0.0f;", "        d[i] = acc[i >> 4][i & 15];")
+    patch(F(d), "        if (!SAVE) return;\n        unsigned w[4] = {0u, 0u, 0u, 0u};\n#pragma unroll\n        for (int nb = 0; nb < 16; ++nb)", "        return;\n        unsigned w[4] = {0u, 0u, 0u, 0u};\n#pragma unroll\n        for (int nb = 0; nb < 16; ++nb)")
+
+
+W = lambda d: os.path.join(d, "field_bwd.hip")
+
+
+def wg_coarse(n):   # bf16 weight-gradient GEMM: n point chunks instead of 39 for launches below 400k points (13 jobs x 19 = one round)
+    return lambda d: patch(W(d), "(n_jobs == 13 ? 39 : 64)", "(n_jobs == 13 ? (P < 400000 ? %d : 39) : 64)" % n)
+
+
 def noenc(d):
     patch(DEV(d), "            sincosf(xv * pow2f(fr), &sn, &cs);\n            e[2 * m] = sn;", "            sn = xv * pow2f(fr); cs = sn * 0.5f;\n            e[2 * m] = sn;")
 
@@ -59,16 +84,6 @@ def prio_a(d):
     patch(F(d), "    ring.ready();\n", "    ring.ready();\n    if (wave < 4) __builtin_amdgcn_s_setprio(1);\n")
 
 
-def pingpong(d):
-    patch(R(d), "constexpr bool RING_PINGPONG = false;", "constexpr bool RING_PINGPONG = true;")
-
-
-def pp_noprio(d):
-    pingpong(d)
-    patch(R(d), "            __builtin_amdgcn_s_setprio(1);\n", "")
-    patch(R(d), "            __builtin_amdgcn_s_setprio(0);\n", "")
-
-
 def nosched(d):     # hipcc's own order inside a unit
     s = open(R(d)).read()
     a = s.index("template <int NB, typename Tail>")
@@ -78,10 +93,10 @@ def nosched(d):     # hipcc's own order inside a unit
 
 
 VARIANTS = {
-    "base": [], "nobar": [nobar], "nodma": [nodma], "nolds": [nolds], "halflds": [halflds], "nosplit": [nosplit], "noenc": [noenc],
+    "base": [], "nobar": [nobar], "nodma": [nodma], "nolds": [nolds_b], "halflds": [halflds], "nosplit": [nosplit], "noenc": [noenc],
     "prio_b": [prio_b], "prio_a": [prio_a], "nosched": [nosched],
-    "mfmaonly": [nobar, nodma, nolds, nosplit],
-    "pingpong": [pingpong], "pp_noprio": [pp_noprio], "pp_nodma": [pingpong, nodma],
+    "mfmaonly": [nobar, nodma, nolds_b, nosplit], "nostore": [nostore], "wg_c19": [wg_coarse(19)], "wg_c26": [wg_coarse(26)], "noepi": [noepi], "noepi_nostore": [noepi, nostore], "mfmaonly_nostore": [nobar, nodma, nolds_b, nosplit, nostore],
+
     "nobar_nodma": [nobar, nodma],
 }
 
