@@ -35,8 +35,11 @@ template <int NV>
 __device__ inline void apply_mask3r(float (&d)[NV], const f32x16* acc, u32x4 m) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const unsigned bit = (m[i >> 5] >> (i & 31)) & 1u;
-        d[i] = bit ? acc[i >> 4][i & 15] : 0.0f;
+        // sign-extended 1-bit field = all ones / zero (one v_bfe_i32), AND-ed onto the accumulator: bit ? acc : +0
+        // (asm: LLVM canonicalises `x & sext(bit)` back into and + compare + select, three operations)
+        unsigned keep;
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(m[i >> 5]), "n"(i & 31));
+        d[i] = __uint_as_float(__float_as_uint(acc[i >> 4][i & 15]) & keep);
     }
 }
 
@@ -113,8 +116,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     const int pair_off = ((lane >> 5) * 4 + (int)odd) * 16 + ((lane & 31) >> 1);      // dwords inside the tile
     // one paired bf16 store: rows (r, r + 1) of 32-feature block ob of a F-wide region (the element order of
     // store_tile3h_pair), values v0 / v1 of this lane's point
-    auto store_pair16 = [&](size_t region_off, int F, int ob, int r, float v0, float v1) __attribute__((always_inline)) {
-        const unsigned own = pack_bf16x2(v0, v1);
+    auto store_pair16 = [&](size_t region_off, int F, int ob, int r, unsigned own) __attribute__((always_inline)) {
         const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
         unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.delta + (tile_ok ? region_off : dl.feat))
                                                      + (tile_ok ? tile * (size_t)(F * 32) : (size_t)0)) + pair_off;
@@ -144,12 +146,14 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     Frag fa, fb, fl;
     ring.request_first(fa);
     store_region = dl.hv;
-    ring_units<16, 2, 0, true, 0>(ring, fa, fb, fl, acc, dhv, [&](auto kk, auto gg) __attribute__((always_inline)) {
+    // unit (k-step kk, group gg) writes values 8 kk + 4 gg .. + 3: as bf16 pairs they ARE words 2 gg, 2 gg + 1 of the k-step's
+    // hi fragment (value 2 q, 2 q + 1 = rows r = 2 (q % 8), r + 1 of block q / 8)
+    ring_units<16, 2, 0, true, 0>(ring, fa, fb, fl, acc, dhv, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
         constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;            // unit 0..15: 64 values -> 4 per unit
 #pragma unroll
         for (int t = 0; t < (OUT16 ? 2 : 4); ++t) {
             const int q = (OUT16 ? 2 : 4) * i + t;
-            if (OUT16) store_pair16(store_region, WV, q / 8, 2 * (q % 8), dhv[16 * (q / 8) + 2 * (q % 8)], dhv[16 * (q / 8) + 2 * (q % 8) + 1]);
+            if (OUT16) store_pair16(store_region, WV, q / 8, 2 * (q % 8), bhi[2 * decltype(gg)::value + t]);
             else store_f32(store_region, WV, q / 16, q % 16, dhv[q]);
         }
     });
@@ -163,12 +167,12 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
         store_region = (size_t)l * pad32(P) * W;                            // dl.h[l]: delta of layer l = input of this step
-        ring_units<32, 2, 0, false, NP>(ring, fa, fb, fl, acc, d, [&](auto kk, auto gg) __attribute__((always_inline)) {
+        ring_units<32, 2, 0, false, NP>(ring, fa, fb, fl, acc, d, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
             constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;        // unit 0..31: 128 values -> 4 per unit
 #pragma unroll
             for (int t = 0; t < (OUT16 ? 2 : 4); ++t) {
                 const int q = (OUT16 ? 2 : 4) * i + t;
-                if (OUT16) store_pair16(store_region, W, q / 8, 2 * (q % 8), d[16 * (q / 8) + 2 * (q % 8)], d[16 * (q / 8) + 2 * (q % 8) + 1]);
+                if (OUT16) store_pair16(store_region, W, q / 8, 2 * (q % 8), bhi[2 * decltype(gg)::value + t]);
                 else store_f32(store_region, W, q / 16, q % 16, d[q]);
             }
         });

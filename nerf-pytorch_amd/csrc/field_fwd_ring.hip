@@ -66,8 +66,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
     const bool tile_ok = (size_t)tile16 * 16 < pad32((size_t)P);
     // rows (r0, r0 + 1) of block nb of this lane's point, paired with the neighbour point: one dword store (unconditional;
     // a wave whose tile lies beyond the padded range writes to the unused `feat` region)
-    auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
-        const unsigned own = pack_bf16x2(v0, v1);
+    auto store_word = [&](size_t region, int F, int nb, int r0, unsigned own) __attribute__((always_inline)) {
         const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
         const unsigned word = __builtin_amdgcn_perm(nbr, own, pair_sel);
         unsigned* tile_base = reinterpret_cast<unsigned*>(a.act + (tile_ok ? region : al.feat))
@@ -107,15 +106,19 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
             nt_store(reinterpret_cast<u32x4*>(a.act + al.mask) + ((size_t)layer * P + p) * 2 + q, u32x4{w[0], w[1], w[2], w[3]});
     };
     constexpr int NP = SAVE ? 4 : 0;        // row stores guaranteed behind the last fetch part (one per unit, positions 3..6)
-    auto no_store = [](auto, auto) __attribute__((always_inline)) {};
+    auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
+        store_word(region, F, nb, r0, cvt_pk_bf16(v0, v1));
+    };
+    auto no_store = [](auto, auto, const u32x4&) __attribute__((always_inline)) {};
     // rows of the layer in h[] leave while the next contraction consumes them: unit (k-step kk, group gg) covers
     // block 2 kk + (gg >> 1), rows 2 (gg & 1), 2 (gg & 1) + 1 (the store pattern of field_fwd16_kernel<2>)
     size_t row_region = 0;
-    auto store_rows = [&](auto kk, auto gg) __attribute__((always_inline)) {
+    // (the bf16 values of rows (r0, r0 + 1) of block nb ARE word g of the B operand's hi fragment of k-step kk)
+    auto store_rows = [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
         if (!SAVE) return;
         constexpr int nb = 2 * decltype(kk)::value + (decltype(gg)::value >> 1);
         constexpr int r0 = 2 * (decltype(gg)::value & 1);
-        store_pair(row_region, W, nb, r0, h[4 * nb + r0], h[4 * nb + r0 + 1]);
+        store_word(row_region, W, nb, r0, bhi[decltype(gg)::value]);
     };
 
     ring.ready();
@@ -170,11 +173,11 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
     load_bias<8>(av, ring_small_ptr(lds, SM_BVIEWS), q);
     {   // layer 7's rows leave under the 16 units of the trunk part: k-step kk = blocks 2 kk, 2 kk + 1, half of them per unit
         row_region = (size_t)(D - 1) * layer_floats;
-        auto store_rows_v = [&](auto kk, auto gg) __attribute__((always_inline)) {
+        auto store_rows_v = [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
             if (!SAVE) return;
             constexpr int nb = 2 * decltype(kk)::value + decltype(gg)::value;
-            store_pair(row_region, W, nb, 0, h[4 * nb], h[4 * nb + 1]);
-            store_pair(row_region, W, nb, 2, h[4 * nb + 2], h[4 * nb + 3]);
+            store_word(row_region, W, nb, 0, bhi[2 * decltype(gg)::value]);
+            store_word(row_region, W, nb, 2, bhi[2 * decltype(gg)::value + 1]);
         };
         ring_units<16, 2, 0, false, NP>(ring, fa, fb, fl, av, h, store_rows_v);
         ring_units<2, 2, 0, false, 0>(ring, fa, fb, fl, av, dv, no_store);

@@ -60,27 +60,41 @@ struct WeightRingT {
     int slot;                   // ring slot of the next unit to REQUEST (wave-uniform)
     int dma_chunk;              // next chunk to fetch
     int dma_slot;               // ring slot of the first unit of this wave's span of chunk dma_chunk
+    int dma_live0, dma_live1;   // this wave's first / second unit of chunk dma_chunk exists (scalar: only the last chunk is ragged)
+    const float* dma_g;         // per-lane global address of the next part to fetch
+    unsigned dma_l, dma_l1;     // LDS byte address of the next part / of the span's second unit
 
-    // part K (0..3) of this wave's span of chunk c: 2 KiB of its unit (8 waves) or 4 KiB = half a unit (4 waves)
+    // part K (0..3) of this wave's span of the chunk being fetched: 2 KiB of its unit (8 waves) or 4 KiB = half a unit (4 waves).
+    // The global and LDS addresses of the next part are carried (dma_g, dma_l: one pointer add and one scalar add per part)
+    // instead of being rebuilt from the chunk and unit numbers each time.
     template <int K>
-    __device__ __forceinline__ void fetch_part(int c) {
+    __device__ __forceinline__ void fetch_part(int /*c*/) {
         static_assert(UPW == 1 || UPW == 2, "8 or 4 waves");
-        const int uu = CHUNK_UNITS * c + wave * UPW + (UPW == 2 ? K / 2 : 0);
-        if (uu < n_units) {
-            int sl = dma_slot + (UPW == 2 ? K / 2 : 0);
-            if (sl >= RING_UNITS) sl -= RING_UNITS;
-            const int within = UPW == 2 ? (K % 2) * 1024 : K * 512;         // words inside the unit
-            const float* g = src + (size_t)(uu < skip_at ? uu : uu + skip_units) * UNIT_WORDS + within + lane * 4;
-            const unsigned dst = ring_base + (unsigned)sl * (UNIT_WORDS * 4u) + (unsigned)within * 4u;
-            if (UPW == 2) dma_4k(g, dst);
-            else dma_2k(g, dst);
+        constexpr int part_words = UPW == 2 ? 1024 : 512;
+        if (UPW == 2 && K == 2) dma_l = dma_l1;                            // second unit of the span: its own ring slot (may wrap)
+        if ((UPW == 2 && K / 2 == 1) ? dma_live1 : dma_live0) {
+            if (UPW == 2) dma_4k(dma_g, dma_l);
+            else dma_2k(dma_g, dma_l);
         }
+        dma_g += part_words;
+        dma_l += part_words * 4u;
     }
     __device__ __forceinline__ void fetch_unit(int c) { fetch_part<0>(c); fetch_part<1>(c); fetch_part<2>(c); fetch_part<3>(c); }
+    // state of the chunk dma_chunk: which of this wave's units exist, where they come from and where they land
+    __device__ __forceinline__ void set_chunk() {
+        const int u0 = CHUNK_UNITS * dma_chunk + wave * UPW;
+        dma_live0 = __builtin_amdgcn_readfirstlane(u0 < n_units ? 1 : 0);
+        dma_live1 = __builtin_amdgcn_readfirstlane(u0 + 1 < n_units ? 1 : 0);
+        dma_g = src + (size_t)(u0 < skip_at ? u0 : u0 + skip_units) * UNIT_WORDS + lane * 4;      // (a span never straddles the skip)
+        dma_l = ring_base + (unsigned)dma_slot * (UNIT_WORDS * 4u);
+        const int s1 = dma_slot + 1 == RING_UNITS ? 0 : dma_slot + 1;
+        dma_l1 = ring_base + (unsigned)s1 * (UNIT_WORDS * 4u);
+    }
     __device__ __forceinline__ void advance_dma() {
         ++dma_chunk;
         dma_slot += CHUNK_UNITS;
         if (dma_slot >= RING_UNITS) dma_slot -= RING_UNITS;
+        set_chunk();
     }
     // chunks 0 and 1 (units 0..15 -> slots 0..15); finish with ready()
     __device__ inline void start(const float* src_, float* lds, int wave_, int lane_, int skip_at_, int skip_units_, int n_units_) {
@@ -89,6 +103,7 @@ struct WeightRingT {
         lane_ptr = reinterpret_cast<const u32x4*>(lds) + lane;
         slot = 0;
         dma_chunk = 0; dma_slot = wave * UPW;
+        set_chunk();
         fetch_unit(0); advance_dma();
         fetch_unit(1); advance_dma();           // dma_slot = (16 + wave * UPW) mod 17
     }
@@ -128,11 +143,28 @@ struct WeightRingT {
 using WeightRing = WeightRingT<8>;
 
 // one (hi, lo) word pair of a B operand: values (v0, v1) -> bf16x2 hi word, bf16x2 word of the remainders (split8, one pair)
-__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
-    const unsigned h = pack_bf16x2(v0, v1);
-    hi = h;
-    lo = pack_bf16x2(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
+// (the packed conversion is written as one v_cvt_pk_bf16_f32: from the C++ form hipcc derives the low half's float with a
+// second conversion of v0 alone -- one VALU operation more per pair; the values are those of split8 bit for bit)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
+    const unsigned h = cvt_pk_bf16(v0, v1);
+    hi = h;
+    lo = cvt_pk_bf16(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
+}
+__device__ __forceinline__ void split8_pk(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h, l;
+        split_pair(v[2 * i], v[2 * i + 1], h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+constexpr int lgkmcnt_only(int n) { return 0xC07F | (n << 8); }     // s_waitcnt immediate: lgkmcnt(n), vmcnt / expcnt not waited for
 
 __device__ __forceinline__ f32x4 mfma_acc(u32x4 a, u32x4 b, f32x4 c) { return mfma16_bf16(a, b, c); }      // 16 points / wave
 __device__ __forceinline__ f32x16 mfma_acc(u32x4 a, u32x4 b, f32x16 c) { return mfma_bf16(a, b, c); }     // 32 points / wave
@@ -149,6 +181,9 @@ __device__ __forceinline__ f32x16 mfma_acc(u32x4 a, u32x4 b, f32x16 c) { return 
 template <int NB, typename Acc, typename Tail>
 __device__ __forceinline__ void unit_pipelined(Acc (&acc)[NB], int g4, const Frag& cur, Frag& lo, Frag& nxt, const u32x4* p, const u32x4* pn,
                                                const u32x4 bhi, const u32x4 blo, Tail tail) {
+    // ONE wait for the four hi fragments (requested 8 MFMAs ago; hipcc otherwise waits in front of each MFMA: 8 s_waitcnt per
+    // unit, each an issue slot) ...
+    __builtin_amdgcn_s_waitcnt(lgkmcnt_only(0));
     static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         acc[g4 + i] = mfma_acc(cur.w[i], bhi, acc[g4 + i]);
@@ -161,6 +196,7 @@ __device__ __forceinline__ void unit_pipelined(Acc (&acc)[NB], int g4, const Fra
         nxt.w[i] = pn[(2 * i) * 64];
         __builtin_amdgcn_sched_barrier(0);
     });
+    __builtin_amdgcn_s_waitcnt(lgkmcnt_only(4));        // ... and one for the four lo fragments (the next unit's hi requests stay in flight)
     static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         acc[g4 + i] = mfma_acc(lo.w[i], bhi, acc[g4 + i]);
@@ -171,8 +207,8 @@ __device__ __forceinline__ void unit_pipelined(Acc (&acc)[NB], int g4, const Fra
 
 // NU units of one contraction: G groups (units) per k-step, B operand of k-step s = v[VOFF + 8 s ..+7].  The first
 // unit is at position 0 of its chunk (every contraction starts on a chunk boundary); FIRST = the very first units of
-// the kernel (no fetch in progress at positions 0..2).  `after(k-step, group)` runs behind the 10th MFMA of each unit
-// (row stores).  NPEND: see WeightRing::barrier (the row stores of positions 3..6 follow the last part of a fetch: 4 when
+// the kernel (no fetch in progress at positions 0..2).  `after(k-step, group, bhi)` runs behind the 10th MFMA of each
+// unit (row stores; bhi = the hi words of the k-step in progress, which ARE the bf16 values of its rows).  NPEND: see WeightRing::barrier (the row stores of positions 3..6 follow the last part of a fetch: 4 when
 // one per unit).  fa holds the hi fragments of the first unit on entry and of the unit after the last one on exit (NU is
 // even); fb is the second hi set, fl the lo set of the unit in progress.
 template <int NU, int G, int VOFF, bool FIRST, int NPEND, int NW, typename Acc, int NB, int NV, typename After>
@@ -181,8 +217,9 @@ __device__ __forceinline__ void ring_units(WeightRingT<NW>& ring, Frag& fa, Frag
     static_assert(G == 4 || G == 2, "units per k-step");
     // B operand (hi, lo) of the k-step in progress and of the next one: the split of k-step s+1 is spread over the units
     // of k-step s (4 / G word pairs each), in the shadow of their last MFMAs
-    u32x4 bhi, blo, nhi, nlo;
-    split8(&v[VOFF], nhi, nlo);
+    // (two operand sets, alternating by k-step parity: no register copies when a k-step begins)
+    u32x4 Bh[2], Bl[2];
+    split8_pk(&v[VOFF], Bh[0], Bl[0]);
     static_for<0, NU>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         constexpr int s = i / G, g = i % G, pos = i % CHUNK_UNITS;
@@ -190,7 +227,10 @@ __device__ __forceinline__ void ring_units(WeightRingT<NW>& ring, Frag& fa, Frag
         Frag& cur = (i & 1) ? fb : fa;
         Frag& nxt = (i & 1) ? fa : fb;
         if constexpr (pos == CHUNK_UNITS - 1) ring.template barrier<NPEND>();
-        if constexpr (g == 0) { bhi = nhi; blo = nlo; }
+        u32x4& bhi = Bh[s & 1];
+        u32x4& blo = Bl[s & 1];
+        u32x4& nhi = Bh[(s + 1) & 1];
+        u32x4& nlo = Bl[(s + 1) & 1];
         const u32x4 *p, *pn;
         ring.unit_ptrs(p, pn);
         __builtin_amdgcn_sched_barrier(0);
@@ -204,7 +244,7 @@ __device__ __forceinline__ void ring_units(WeightRingT<NW>& ring, Frag& fa, Frag
                 nhi[j] = wh;
                 nlo[j] = wl;
             }
-            if constexpr (t == 2) after(std::integral_constant<int, s>{}, std::integral_constant<int, g>{});
+            if constexpr (t == 2) after(std::integral_constant<int, s>{}, std::integral_constant<int, g>{}, bhi);
         });
         if constexpr (!(FIRST && i < 3)) ring.template fetch_after_unit<pos>();
     });
