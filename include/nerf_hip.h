@@ -141,6 +141,11 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
  * evaluation must use the same datapath. */
 int nerf_packed3_floats(void);
 int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream);
+/* the same, writing only the fragment streams the caller will read (one launch behind the derivation of the folded layer):
+ * streams = mask of 1: 16-point forward (nerf_field_fwd16*_bf16x3), 2: 32-point forward (nerf_field_fwd_bf16x3 / _mixed),
+ * 4: transposed streams of the delta chain (nerf_field_dgrad*_bf16x3), 8: their hi-only copy (nerf_field_dgrad_mixed).
+ * 15 = nerf_pack_params_bf16x3.  A kernel that reads a stream that was not written computes garbage: the caller chooses. */
+int nerf_pack_params_bf16x3_sel(const float* params, float* packed3, int streams, void* stream);
 int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                           int n_samples, float* raw, float* act, void* stream);
 /* the same forward on 16 points per wavefront at 2 waves / SIMD instead of 32 at 1 (same arithmetic class: 3 bf16

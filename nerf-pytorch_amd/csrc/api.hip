@@ -391,6 +391,12 @@ int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream) {
     return done(__func__, nerf::launch_pack3(params, packed3, (hipStream_t)stream));
 }
 
+int nerf_pack_params_bf16x3_sel(const float* params, float* packed3, int streams, void* stream) {
+    REQUIRE(params && packed3, "null pointer");
+    REQUIRE(streams >= 0 && streams <= 15, "streams is a mask of bits 0..3");
+    return done(__func__, nerf::launch_pack3_sel(params, packed3, streams, (hipStream_t)stream));
+}
+
 int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                           int n_samples, float* raw, float* act, void* stream) {
     REQUIRE(packed3 && rays && z_vals && raw, "null pointer");

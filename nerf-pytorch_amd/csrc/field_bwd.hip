@@ -844,7 +844,9 @@ static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
     // reduction 0.055 instead of 0.043 ms).  (Measured for the 12 jobs: 64 and 128 chunks run
     // the GEMM in the same time, 96 — a partial last round — is 10 % slower, and the partial-sum traffic of the
     // deterministic reduction halves with 64: 0.113 -> 0.057 ms per launch.)  Small inputs get >= 256-point chunks.
-    long n = n_jobs == 14 ? 128 : (n_jobs == 13 ? 39 : 64);
+    // (13 jobs, launches below 400 k points -- the coarse pass: 19 chunks = 247 workgroups = ONE round; the GEMM takes the same
+    // time (0.65 ms at 262 k points) and the deterministic reduction reads half the partial sums: 0.044 -> 0.032 ms)
+    long n = n_jobs == 14 ? 128 : (n_jobs == 13 ? (P < 400000 ? 19 : 39) : 64);
     const long cap = (P + 255) / 256;
     if (n > cap) n = cap;
     if (n < 1) n = 1;

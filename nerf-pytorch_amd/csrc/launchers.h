@@ -64,6 +64,7 @@ void pack_table_host(int* out);
 void pack3_table_host(int* out);
 void pack16_table_host(int* out);
 hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream);
+hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream);
 hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                              int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
 hipError_t launch_field_fwd16(const float* packed3, const float* rays, int ray_stride, const float* z_vals,

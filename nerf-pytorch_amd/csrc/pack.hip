@@ -151,31 +151,6 @@ __device__ inline float param_or_derived(const float* canon_params, const float*
     return src < N_PARAMS ? canon_params[src] : derived[src - N_PARAMS];
 }
 
-__global__ void pack3_params_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived,
-                                    unsigned short* __restrict__ packed16) {
-    const int e16 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e16 >= 2 * P3B_END) return;
-    int is_lo;
-    const int src = pack3_source(e16, &is_lo);
-    unsigned short v = 0;
-    if (src >= 0) {
-        const float x = param_or_derived(canon_params, derived, src);
-        const unsigned short hi = bf16_rne(x);
-        v = is_lo ? bf16_rne(x - __uint_as_float((unsigned)hi << 16)) : hi;
-    }
-    packed16[e16] = v;
-}
-
-__global__ void pack3_small_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived,
-                                   float* __restrict__ packed) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= PACKED_FLOATS - SM_BIAS) return;
-    const int idx = SM_BIAS + i;
-    if (idx >= SM_BVIEWS && idx < SM_WALPHA) { packed[P3_SMALL + i] = derived[WV * W + (idx - SM_BVIEWS)]; return; }     // b'
-    const int src = pack_source(idx);
-    packed[P3_SMALL + i] = src < 0 ? 0.0f : canon_params[src];
-}
-
 // 16-point-per-wave forward stream (nerf_common.h, P16F): canonical source of 16-bit element e16 of the region
 __host__ __device__ inline int pack16_source(int e16, int* is_lo) {
     constexpr Canon c = canon();
@@ -210,21 +185,6 @@ __host__ __device__ inline int pack16_source(int e16, int* is_lo) {
     return d < 0 ? -1 : c.wv + row * (W + IN_DIR) + W + d;
 }
 
-__global__ void pack16_params_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived,
-                                     unsigned short* __restrict__ region16) {
-    const int e16 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e16 >= 2 * P16F_WORDS) return;
-    int is_lo;
-    const int src = pack16_source(e16, &is_lo);
-    unsigned short v = 0;
-    if (src >= 0) {
-        const float x = param_or_derived(canon_params, derived, src);
-        const unsigned short hi = bf16_rne(x);
-        v = is_lo ? bf16_rne(x - __uint_as_float((unsigned)hi << 16)) : hi;
-    }
-    region16[e16] = v;
-}
-
 void pack16_table_host(int* out) {
     for (int e = 0; e < 2 * P16F_WORDS; ++e) { int lo; const int s = pack16_source(e, &lo); out[e] = s < 0 ? -1 : 2 * s + lo; }
 }
@@ -233,28 +193,77 @@ void pack3_table_host(int* out) {
     for (int e = 0; e < 2 * P3B_END; ++e) { int lo; const int s = pack3_source(e, &lo); out[e] = s < 0 ? -1 : 2 * s + lo; }
 }
 
-// hi-only copy of the transposed (hi, lo) streams: 16-byte fragment (k-step s, block nb, lane) of P3B -> P1B
-__global__ void pack3_hi_only_kernel(float* __restrict__ packed) {
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P1B_KSTEPS * 8 * 64) return;
-    const int s = idx >> 9, nb = (idx >> 6) & 7, lane = idx & 63;
-    const u32x4_t* src = reinterpret_cast<const u32x4_t*>(packed + P3B_VIEWS) + ((s * 16 + nb * 2) * 64 + lane);
-    reinterpret_cast<u32x4_t*>(packed + P1B)[idx] = *src;
+// ONE repack launch for everything a split-bf16 step reads (after derive_folded, which it depends on).  `streams` selects
+// the fragment streams to write: bit 0 = 16-point forward (P16F), bit 1 = 32-point forward (P3F), bit 2 = transposed (hi, lo)
+// streams of the delta chain (P3B), bit 3 = their hi-only copy (P1B, mixed-precision chain).  The small fp32 parameters
+// are always written.  The default configuration (16-point forward + split-bf16 chain) needs bits 0 | 2: 2.3 M of the
+// 4.1 M 16-bit elements, in one launch instead of four.
+__global__ void pack3_all_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived, float* __restrict__ packed,
+                                 int n16f, int n3f, int n3b, int n1b) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned short* p16 = reinterpret_cast<unsigned short*>(packed);
+    auto emit = [&](unsigned short* dst, int src, int is_lo) {
+        unsigned short v = 0;
+        if (src >= 0) {
+            const float x = param_or_derived(canon_params, derived, src);
+            const unsigned short hi = bf16_rne(x);
+            v = is_lo ? bf16_rne(x - __uint_as_float((unsigned)hi << 16)) : hi;
+        }
+        *dst = v;
+    };
+    if (idx < n16f) {                                        // 16-point forward stream
+        int lo;
+        const int src = pack16_source((int)idx, &lo);
+        emit(p16 + 2L * P16F + idx, src, lo);
+        return;
+    }
+    idx -= n16f;
+    if (idx < n3f) {                                         // 32-point forward stream
+        int lo;
+        const int src = pack3_source((int)idx, &lo);
+        emit(p16 + idx, src, lo);
+        return;
+    }
+    idx -= n3f;
+    if (idx < n3b) {                                         // transposed streams
+        const int e16 = 2 * P3F_END + (int)idx;
+        int lo;
+        const int src = pack3_source(e16, &lo);
+        emit(p16 + e16, src, lo);
+        return;
+    }
+    idx -= n3b;
+    if (idx < n1b) {                                         // hi-only copy of the transposed streams: element (s, nb, lane, j)
+        const int j = (int)idx & 7, lane = ((int)idx >> 3) & 63, nb = ((int)idx >> 9) & 7, ks = (int)idx >> 12;
+        const int e16 = 2 * P3B_VIEWS + (((ks * 16 + nb * 2) * 64 + lane) << 3) + j;
+        int lo;
+        const int src = pack3_source(e16, &lo);
+        emit(p16 + 2L * P1B + idx, src, 0);
+        return;
+    }
+    idx -= n1b;
+    if (idx < PACKED_FLOATS - SM_BIAS) {                     // small fp32 parameters (b' replaces the view-branch bias)
+        const int i = (int)idx, pidx = SM_BIAS + i;
+        if (pidx >= SM_BVIEWS && pidx < SM_WALPHA) { packed[P3_SMALL + i] = derived[WV * W + (pidx - SM_BVIEWS)]; return; }
+        const int src = pack_source(pidx);
+        packed[P3_SMALL + i] = src < 0 ? 0.0f : canon_params[src];
+    }
 }
 
-hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream) {
+hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream) {
     const int threads = 256;
     float* derived = packed + P3_DERIVED;
     hipLaunchKernelGGL(derive_folded_kernel, dim3((8 * N_DERIVED + threads - 1) / threads), dim3(threads), 0, stream, canon_params, derived);
-    hipLaunchKernelGGL(pack3_params_kernel, dim3((2 * P3B_END + threads - 1) / threads), dim3(threads), 0, stream,
-                       canon_params, (const float*)derived, reinterpret_cast<unsigned short*>(packed));
-    hipLaunchKernelGGL(pack3_small_kernel, dim3((PACKED_FLOATS - SM_BIAS + threads - 1) / threads), dim3(threads), 0, stream,
-                       canon_params, (const float*)derived, packed);
-    hipLaunchKernelGGL(pack3_hi_only_kernel, dim3((P1B_KSTEPS * 8 * 64 + threads - 1) / threads), dim3(threads), 0, stream, packed);
-    hipLaunchKernelGGL(pack16_params_kernel, dim3((2 * P16F_WORDS + threads - 1) / threads), dim3(threads), 0, stream,
-                       canon_params, (const float*)derived, reinterpret_cast<unsigned short*>(packed + P16F));
+    const int n16f = (streams & 1) ? 2 * P16F_WORDS : 0, n3f = (streams & 2) ? 2 * P3F_END : 0;
+    const int n3b = (streams & 4) ? 2 * (P3B_END - P3F_END) : 0, n1b = (streams & 8) ? 2 * P1B_KSTEPS * KSTEP1_W8 : 0;
+    const long total = (long)n16f + n3f + n3b + n1b + (PACKED_FLOATS - SM_BIAS);
+    hipLaunchKernelGGL(pack3_all_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, stream,
+                       canon_params, (const float*)derived, packed, n16f, n3f, n3b, n1b);
     return hipGetLastError();
+}
+
+hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream) {
+    return launch_pack3_sel(canon_params, packed, 15, stream);
 }
 
 // host copy of the gather table (CPU tests emulate the MFMA data flow with it)

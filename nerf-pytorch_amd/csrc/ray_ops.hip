@@ -203,18 +203,23 @@ __global__ __launch_bounds__(64) void sample_fine_kernel(FineArgs a) {
     for (int i = lane; i < nw; i += 64) part += w[i] + 1e-5f;
     const float wsum = wave_sum(part);
     __syncthreads();
-    // cdf = [0, cumsum(pdf)]: sequential like torch.cumsum so rounding follows the reference
+    // cdf = [0, cumsum(pdf)]: the ADDITIONS are sequential like torch.cumsum so rounding follows the reference; the divisions
+    // (independent) are done by all lanes first
+    for (int i = lane; i < nw; i += 64) cdf[i + 1] = (w[i] + 1e-5f) / wsum;
+    __syncthreads();
     if (lane == 0) {
         float c = 0.0f;
         cdf[0] = 0.0f;
-        for (int i = 0; i < nw; ++i) { c += (w[i] + 1e-5f) / wsum; cdf[i + 1] = c; }
+        for (int i = 0; i < nw; ++i) { c += cdf[i + 1]; cdf[i + 1] = c; }
     }
     __syncthreads();
     float s1 = 0.0f;
     for (int k = lane; k < Nf; k += 64) {
         const float u = a.u ? a.u[(size_t)ray * Nf + k] : a.u_lin[k];
-        int idx = 0;                                  // searchsorted(cdf, u, right=True)
-        for (int i = 0; i < nb; ++i) idx += (cdf[i] <= u) ? 1 : 0;
+        // searchsorted(cdf, u, right=True) = number of entries <= u: the cdf is non-decreasing, so a binary search counts them
+        int lo_ = 0, hi_ = nb;
+        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (cdf[mid] <= u) lo_ = mid + 1; else hi_ = mid; }
+        const int idx = lo_;
         const int below = max(idx - 1, 0), above = min(idx, nb - 1);
         const float c0 = cdf[below], c1 = cdf[above];
         float denom = c1 - c0;
@@ -234,15 +239,38 @@ __global__ __launch_bounds__(64) void sample_fine_kernel(FineArgs a) {
         if (lane == 0) a.z_std[ray] = sqrtf(s2 / (float)Nf);
     }
     if (!a.z_all) return;
-    // rank sort of the union (values only are used downstream, run_nerf.py:396)
-    for (int i = lane; i < tot; i += 64) {
-        const float x = vals[i];
-        int rank = 0;
-        for (int j = 0; j < tot; ++j) {
-            const float y = vals[j];
-            rank += (y < x || (y == x && j < i)) ? 1 : 0;
+    // sorted union (values only are used downstream, run_nerf.py:396: torch.sort(torch.cat([z_vals, z_samples]))).  The
+    // coarse depths are ascending already; the fine samples (unsorted when u is random) are sorted in LDS by a bitonic
+    // network over the next power of two (padding = +inf), then every element finds its place in the union by one binary
+    // search in the OTHER list (coarse before fine on ties: a stable merge).  O(n log^2 n) instead of the O(n^2) rank count;
+    // the output is the same sorted sequence.
+    float* fs = vals + Sc;
+    int np2 = 1;
+    while (np2 < Nf) np2 <<= 1;
+    for (int k = Nf + lane; k < np2; k += 64) fs[k] = __int_as_float(0x7f800000);
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (np2 >> 1); t += 64) {
+                const int i = ((t / stride) * (stride << 1)) + (t % stride), j = i + stride;
+                const bool up = ((i & size) == 0);
+                const float x = fs[i], y = fs[j];
+                if ((x > y) == up) { fs[i] = y; fs[j] = x; }
+            }
+            __syncthreads();
         }
-        a.z_all[(size_t)ray * tot + rank] = x;
+    float* zo = a.z_all + (size_t)ray * tot;
+    for (int i = lane; i < Sc; i += 64) {             // coarse element i: + number of fine samples strictly below it
+        const float x = vals[i];
+        int lo_ = 0, hi_ = Nf;
+        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (fs[mid] < x) lo_ = mid + 1; else hi_ = mid; }
+        zo[i + lo_] = x;
+    }
+    for (int k = lane; k < Nf; k += 64) {             // fine element k (sorted position): + number of coarse depths <= it
+        const float x = fs[k];
+        int lo_ = 0, hi_ = Sc;
+        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (vals[mid] <= x) lo_ = mid + 1; else hi_ = mid; }
+        zo[k + lo_] = x;
     }
 }
 
@@ -353,7 +381,9 @@ hipError_t launch_composite(const CompositeArgs& a, bool bwd, hipStream_t stream
 
 hipError_t launch_sample_fine(const FineArgs& a, hipStream_t stream) {
     if (a.n_rays <= 0) return hipSuccess;
-    const size_t lds = (size_t)(3 * a.n_in + a.Nf) * sizeof(float);
+    int np2 = 1;
+    while (np2 < a.Nf) np2 <<= 1;                        // the fine samples are sorted over the next power of two
+    const size_t lds = (size_t)(3 * a.n_in + np2) * sizeof(float);
     hipLaunchKernelGGL(sample_fine_kernel, dim3(a.n_rays), dim3(64), lds, stream, a);
     return hipGetLastError();
 }

@@ -51,6 +51,7 @@ def _declare(lib):
         "nerf_field_wgrad": (i, [p, p, p, i, i, p, p, i, p]),
         "nerf_packed3_floats": (i, []),
         "nerf_pack_params_bf16x3": (i, [p, p, p]),
+        "nerf_pack_params_bf16x3_sel": (i, [p, p, i, p]),
         "nerf_field_fwd_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_debug_pack3_table": (i, [p]),
         "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, i, p]),
@@ -79,7 +80,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_buffer_layout", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
-           "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
+           "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_pack_params_bf16x3_sel", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
            "nerf_field_dgrad_bf16x3", "nerf_field_dgrad3r_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_field_fwd16r_bf16x3", "nerf_debug_pack16_table",
            "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step",
            "nerf_render_workspace_floats", "nerf_render_rays_fwd", "nerf_render_rays_bwd"]
@@ -282,7 +283,10 @@ def pack_params(flat, out=None, precision="fp32"):
     if precision in ("bf16x3", "mixed"):
         if out is None:
             out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
-        _check(L.nerf_pack_params_bf16x3(_ptr(flat, "params"), _ptr(out, "packed"), _stream()), "nerf_pack_params_bf16x3")
+        # one launch for all four fragment streams (+ the derivation of the folded layer in front of it).  A host that knows
+        # which kernels it will run can pack less (nerf_pack_params_bf16x3_sel streams mask); this binding switches kernels
+        # on one packed buffer (tests, NERF_FWD16 / NERF_DGRAD), so it packs them all
+        _check(L.nerf_pack_params_bf16x3_sel(_ptr(flat, "params"), _ptr(out, "packed"), 15, _stream()), "nerf_pack_params_bf16x3_sel")
         return out
     if out is None:
         out = torch.empty(L.nerf_packed_floats(), dtype=torch.float32, device=flat.device)
@@ -605,7 +609,7 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
         with _timed("wgrad_kernel(narrow jobs)", (FLOP_WGRAD_PER_POINT - FLOP_WGRAD_BIG_PER_POINT) * P, BYTES_WGRAD_SMALL_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 2, *tail), "nerf_field_wgrad_phase")
     # chunks of partial sums the reduction reads (csrc/field_bwd.hip, wgrad_chunks)
-    n_chunks = min(39 if bf16_gemm else (64 if b3 else 128), max(1, (P + 255) // 256))
+    n_chunks = min((19 if P < 400000 else 39) if bf16_gemm else (64 if b3 else 128), max(1, (P + 255) // 256))
     with _timed("wgrad_reduce_kernel", 0.0, 4.0 * N_PARAMS * (n_chunks + 1)):
         _check(L.nerf_field_wgrad_phase(*args, 4, *tail), "nerf_field_wgrad_phase")
     return grad

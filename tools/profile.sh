@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$PREC
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eager-baseline --no-gate --single-datapath --precision $PREC $@"
+CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eager-baseline --no-gate --single-datapath --no-configs --precision $PREC $@"
 echo "# $CMD" > $OUT/command.txt
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1; echo "stats rc=$?"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum"; do
