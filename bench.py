@@ -81,6 +81,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--no-gate", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other single-GPU configurations")
+    ap.add_argument("--long", action="store_true",
+                    help="also fit a student to a teacher scene in every datapath (3 seeds x --long-steps Adam steps of 1024 rays, same "
+                         "initialisation, batches and draws) and report the held-out PSNR per datapath as mean +- spread "
+                         "(`precision_gate.training`): the training-equivalence evidence, ~1-2 min")
+    ap.add_argument("--long-steps", type=int, default=1000)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no GPU work): used by the CPU test of the N > 1 launch path")
@@ -356,6 +361,90 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024):
+    """Training equivalence of the datapaths, measured instead of argued: the same student (a different scene's weights)
+    is fitted to a teacher scene's images with the fused Adam for `steps` steps of `n_batch` rays, once per datapath and
+    seed, with identical initialisation, batch order and random draws; held-out PSNR (2048 rays, evaluated on the exact
+    fp32 datapath) after the last step.  Per datapath: mean and spread (max - min) over the seeds, and the largest
+    per-seed difference to the fp32 datapath.  `fp32_twin` is the fp32 datapath itself started one ulp away: training is
+    chaotic in the rounding, so a datapath is equivalent when it stays inside the twin's distance."""
+    import math
+    import torch
+    import nerf_pytorch_amd as npa
+    import workloads as wl
+    hb = npa.hip_backend
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+
+    def net(P):
+        m = npa.NeRF(**kw).to(dev)
+        m.load_state_dict(P)
+        return m
+    rk = dict(N_samples=64, N_importance=128, white_bkgd=True, raw_noise_std=0.)
+    prev_prec, prev_ops = npa.get_precision(), hb.WGRAD_OPERANDS
+    results = {}
+    try:
+        for seed in seeds:
+            # (teacher, student initialisation) = two different scenes; pairs whose teacher has structure along these rays
+            # (mean opacity 0.50 / 1.00 / 0.92: random networks can also come out empty or uniformly opaque)
+            t_seed, s_seed = ((5, 6), (0, 1), (7, 10))[seed % 3]
+            Tc, Tf = wl.scene_params(seed=t_seed)
+            Sc, Sf = wl.scene_params(seed=s_seed)
+            tc, tf = net(Tc), net(Tf)
+            pool = wl.synthetic_rays(n_batch * 16, seed=770 + seed).to(dev)
+            held = wl.synthetic_rays(2048, seed=780 + seed).to(dev)
+            npa.set_precision("fp32")
+            with torch.no_grad():
+                tgt_pool = torch.cat([npa.render_rays(pool[i:i + 4096], tc, None, network_fine=tf, perturb=0., **rk)["rgb_map"]
+                                      for i in range(0, pool.shape[0], 4096)])
+                tgt_held = npa.render_rays(held, tc, None, network_fine=tf, perturb=0., **rk)["rgb_map"]
+
+            def psnr(nc, nf):
+                npa.set_precision("fp32")
+                with torch.no_grad():
+                    out = npa.render_rays(held, nc, None, network_fine=nf, perturb=0., **rk)["rgb_map"]
+                mse = float(((out - tgt_held) ** 2).mean())
+                if not (mse > 0.0 and math.isfinite(mse)):
+                    raise RuntimeError(f"convergence_table: held-out mse {mse!r}; out [{float(out.min())}, {float(out.max())}] "
+                                       f"nan {int(torch.isnan(out).sum())}, target [{float(tgt_held.min())}, {float(tgt_held.max())}], "
+                                       f"same storage {out.data_ptr() == tgt_held.data_ptr()}")
+                return -10 * math.log10(mse)
+            for name, prec, operands in (("fp32", "fp32", None), ("fp32_twin", "fp32", None), ("bf16x3", "bf16x3", "bf16"),
+                                         ("bf16x3_fp32_operands", "bf16x3", "fp32"), ("mixed", "mixed", None)):
+                if operands is not None:
+                    hb.WGRAD_OPERANDS = operands
+                torch.manual_seed(seed)
+                nc, nf = net(Sc), net(Sf)
+                if name == "fp32_twin":
+                    # the yardstick: the SAME fp32 datapath started 1e-7 (relative, ~1 ulp) away -- how far two runs of one
+                    # datapath drift apart in this many steps
+                    gt = torch.Generator(device="cpu").manual_seed(5000 + seed)
+                    with torch.no_grad():
+                        for p in list(nc.parameters()) + list(nf.parameters()):
+                            p.mul_((1.0 + 1e-7 * torch.randn(p.shape, generator=gt)).to(dev))
+                opt = npa.FlatAdam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4, betas=(0.9, 0.999))
+                g = torch.Generator(device="cpu").manual_seed(1000 + seed)
+                for _ in range(steps):
+                    idx = torch.randint(0, pool.shape[0], (n_batch,), generator=g).to(dev)
+                    npa.set_precision(prec)
+                    opt.zero_grad()
+                    out = npa.render_rays(pool[idx], nc, None, network_fine=nf, perturb=1.0, **rk)
+                    (npa.img2mse(out["rgb_map"], tgt_pool[idx]) + npa.img2mse(out["rgb0"], tgt_pool[idx])).backward()
+                    opt.step()
+                results.setdefault(name, []).append(psnr(nc, nf))
+                hb.WGRAD_OPERANDS = prev_ops
+    finally:
+        npa.set_precision(prev_prec)
+        hb.WGRAD_OPERANDS = prev_ops
+    table = {}
+    for name, vals in results.items():
+        table[name] = {"psnr_db_per_seed": [round(v, 3) for v in vals], "mean_db": sum(vals) / len(vals), "spread_db": max(vals) - min(vals),
+                       "max_abs_diff_to_fp32_db": max(abs(a - b) for a, b in zip(vals, results["fp32"]))}
+    return {"steps": steps, "rays_per_step": n_batch, "seeds": list(seeds), "what":
+            "student (another scene's weights) fitted to a teacher scene, fused Adam lr 5e-4, same init / batches / draws per datapath; held-out PSNR "
+            "(2048 rays) after the last step; fp32_twin = the fp32 datapath with the initial parameters perturbed by 1e-7 relative",
+            "datapaths": table}
+
+
 class Session:
     """Everything one configuration needs: the two networks on the scene's weights, the fused optimizer, the render kwargs
     create_nerf builds (run_nerf.py:237-259), a pool of HBM-resident ray batches, and the step functions."""
@@ -628,6 +717,8 @@ def main():
     gate = None
     if not args.no_gate and rank == 0:
         gate = ses.gate(args.precision)
+        if args.long and gate is not None:
+            gate["training"] = convergence_table(dev, args.long_steps)
 
     # ---- short legs of the other single-GPU configurations (BASELINE configs[2], [4] and the 32,768-ray batch of [3])
     legs = None
