@@ -741,8 +741,8 @@ def main():
                                "precision_gate": lego_gate}
         big = Session("lego", args, rank, world, dev, N_RAND, True)
         el, _ = measure(args.precision, 2, 1, big.train_step, with_kernels=False)
-        legs["batch_32768"] = {"workload": "the 32,768-ray global batch of BASELINE configs[3] on ONE GPU (lego 64+128, training step; the backward "
-                                           "recomputes the forward in sub-chunks above the 48 GiB save budget)",
+        legs["batch_32768"] = {"workload": "the 32,768-ray global batch of BASELINE configs[3] on ONE GPU (lego 64+128, training step; rendered in 4 "
+                                           "sub-chunks of 8192 rays that all keep their saved activations: ~90 of the 288 GB)",
                                "value": 32768 * 2 / el, "unit": "rays/s", "steps": 2, "ms_per_step": 1e3 * el / 2,
                                "precision_gate": lego_gate}
         big.close()

@@ -349,7 +349,7 @@ class Workspace:
     a training loop of fixed shape re-uses the same device buffers every step -- same pointers, no allocation -- and a
     forward whose backward is still pending simply keeps its lease (a second forward leases another buffer).  A lease
     that is never returned (graph dropped without backward) is an ordinary tensor and is freed with its owner."""
-    MAX_FREE = 6
+    MAX_FREE = 16
 
     def __init__(self):
         self._free = {}
@@ -358,7 +358,9 @@ class Workspace:
         free = self._free.setdefault(str(device), [])
         best = None
         for i, t in enumerate(free):
-            if t.numel() >= n_floats and (best is None or t.numel() < free[best].numel()):
+            # best fit; among equally sized buffers the lowest address, so that the choice does not depend on the order
+            # in which earlier leases came back
+            if t.numel() >= n_floats and (best is None or (t.numel(), t.data_ptr()) < (free[best].numel(), free[best].data_ptr())):
                 best = i
         if best is not None and free[best].numel() <= 2 * n_floats + (1 << 20):
             return free.pop(best)
@@ -380,6 +382,9 @@ class Workspace:
 
 WORKSPACE = Workspace()
 SAVE_BUDGET_BYTES = int(float(os.environ.get("NERF_SAVE_BUDGET_GB", "48")) * (1 << 30))
+# what ONE render_rays call may keep alive for its backward in total (a ray chunk above SAVE_BUDGET_BYTES is rendered in
+# sub-chunks that each keep their own saved activations, as long as all of them fit here: 160 of the 288 GB of an MI355X)
+SAVE_TOTAL_BYTES = int(float(os.environ.get("NERF_SAVE_TOTAL_GB", "160")) * (1 << 30))
 
 
 def workspace_floats(n_rays, n_coarse, n_fine, training=True):
@@ -393,6 +398,11 @@ def max_saved_rays(n_coarse, n_fine):
     chunks are back-propagated in sub-chunks of this size with the forward recomputed (render._RenderRays)."""
     per_1024 = 4 * workspace_floats(1024, n_coarse, n_fine, True)
     return max(1, SAVE_BUDGET_BYTES // max(per_1024, 1)) * 1024
+
+
+def saved_bytes(n_rays, n_coarse, n_fine):
+    """bytes of saved activations (both passes) a training render_rays call over n_rays keeps until its backward"""
+    return 4 * (act_floats(n_rays, n_coarse) + (act_floats(n_rays, n_coarse + n_fine) if n_fine > 0 else 0))
 
 
 class NerfRenderCfg(ctypes.Structure):

@@ -150,12 +150,15 @@ def _release(r):
 class _RenderRays(torch.autograd.Function):
     """The whole of render_rays (run_nerf.py:308-418) as one autograd node.
 
-    Memory: the backward needs ~10.7 KB of saved activations per sample point (plus as much for the deltas).  Up to
+    Memory: the backward needs up to ~10.7 KB of saved activations per sample point (plus as much for the deltas).  Up to
     hb.max_saved_rays(...) rays per call (default budget 48 GiB: ~10k rays at 64+128 samples, i.e. every N_rand of the
     BASELINE configs) they are saved by the forward into buffers leased from hb.WORKSPACE (persistent across steps, no
-    per-step allocation).  Larger ray chunks (the reference's default chunk is 32768 rays = ~150 GB of activations) run
-    the forward WITHOUT saving and the backward re-runs it, with saving, one sub-chunk at a time (the kernels are
-    deterministic, so the recomputed pass is bit-identical to the first): bounded memory for +1 inference-speed forward."""
+    per-step allocation).  Larger ray chunks (the reference's default chunk is 32768 rays) are rendered in equal
+    sub-chunks.  If the saved activations of ALL sub-chunks fit hb.SAVE_TOTAL_BYTES (default 160 GiB of the 288 GB: the
+    32768-ray batch of configs[3] needs ~90 GB) every sub-chunk keeps its own lease and the backward walks them: no
+    recomputation, deltas and partial sums re-use one sub-chunk-sized scratch.  Beyond that the forward runs WITHOUT
+    saving and the backward re-runs it, with saving, one sub-chunk at a time (the kernels are deterministic, so the
+    recomputed pass is bit-identical to the first): bounded memory for +1 inference-speed forward."""
 
     @staticmethod
     def forward(ctx, cfg, rays, rnd, model_c, model_f, *params):
@@ -164,8 +167,22 @@ class _RenderRays(torch.autograd.Function):
         n = rays.shape[0]
         sub = hb.max_saved_rays(cfg["N_samples"], n_f) if need else n
         ctx.checkpoint = bool(need and n > sub)
+        ctx.tiles = None
+        if ctx.checkpoint:
+            ceil_div = lambda a, b: -(-a // b)
+            sub = min(sub, 64 * ceil_div(ceil_div(n, ceil_div(n, sub)), 64))        # equal sub-chunks, multiples of 64 rays
+            if hb.saved_bytes(sub, cfg["N_samples"], n_f) * ceil_div(n, sub) <= hb.SAVE_TOTAL_BYTES:
+                ctx.checkpoint = False
+                ctx.tiles = [(lo, min(lo + sub, n)) for lo in range(0, n, sub)]
         ctx.sub_rays = sub
-        r = _field_pass(cfg, rays, rnd, model_c, model_f, save=need and not ctx.checkpoint)
+        if ctx.tiles is None:
+            r = _field_pass(cfg, rays, rnd, model_c, model_f, save=need and not ctx.checkpoint)
+        else:
+            # every sub-chunk keeps its saved activations; the node's outputs are the concatenations (new tensors)
+            parts = [_field_pass(cfg, rays[lo:hi], {k_: v[lo:hi] for k_, v in rnd.items()}, model_c, model_f, save=True)
+                     for lo, hi in ctx.tiles]
+            out_keys = ("rgb_c", "disp_c", "acc_c", "raw_c") if n_f <= 0 else ("rgb_f", "disp_f", "acc_f", "raw_f", "rgb_c", "disp_c", "acc_c", "z_std")
+            r = {k_: torch.cat([p_[k_] for p_ in parts], 0) for k_ in out_keys}
         ctx.cfg, ctx.model_c, ctx.model_f = cfg, model_c, model_f
         ctx.same_net = model_f is None or model_f is model_c
         ctx.n_params_c = len(_param_slices(model_c))
@@ -177,7 +194,10 @@ class _RenderRays(torch.autograd.Function):
         # without backward would pin its ~11 GB of saved activations for good).  The one output the backward reads,
         # `raw` of the last pass, goes through save_for_backward, which autograd knows how to hold without a cycle.
         ctx.saved = None
-        if need and not ctx.checkpoint:
+        if ctx.tiles is not None:
+            keep = ("packed_c", "z_c", "act_c", "raw_c", "packed_f", "z_f", "act_f", "raw_f")
+            ctx.saved = [{k_: p_[k_] for k_ in keep if k_ in p_} for p_ in parts]     # per-sub-chunk tensors, none is an output
+        elif need and not ctx.checkpoint:
             keep = ("packed_c", "z_c", "act_c", "packed_f", "z_f", "act_f") + (("raw_c",) if n_f > 0 else ())
             ctx.saved = {k: r[k] for k in keep if k in r}
             ctx.save_for_backward(r["raw_f"] if n_f > 0 else r["raw_c"])
@@ -220,7 +240,8 @@ class _RenderRays(torch.autograd.Function):
         if not has(up_c) and not has(up_f):
             ctx.consumed = True
             if ctx.saved is not None:
-                _release(ctx.saved)
+                for r_ in (ctx.saved if isinstance(ctx.saved, list) else [ctx.saved]):
+                    _release(r_)
                 ctx.saved = None
             return none_all
         grad_c = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
@@ -263,7 +284,10 @@ class _RenderRays(torch.autograd.Function):
                         _grad_ready(ctx.model_f, grad_f)
             _release(r)
 
-        if not ctx.checkpoint:
+        if ctx.tiles is not None:
+            for i, (lo, hi) in enumerate(ctx.tiles):
+                backprop(ctx.saved[i], rays_all[lo:hi], {k: v[lo:hi] for k, v in rnd_all.items()}, lo, hi, last=i == len(ctx.tiles) - 1)
+        elif not ctx.checkpoint:
             r = dict(ctx.saved)
             r["raw_f" if fine else "raw_c"] = ctx.saved_tensors[0]
             backprop(r, rays_all, rnd_all, 0, n_all)

@@ -1194,10 +1194,11 @@ def test_adversarial_scene_psnr_delta(npa, dev):
 
 # ---------------------------------------------------------------- workspace leases / recomputing backward
 @pytest.mark.parametrize("precision", PARITY_DATAPATHS)
-def test_large_chunks_backpropagate_in_subchunks_with_recompute(npa, dev, nets, precision, monkeypatch):
-    """Ray chunks whose saved activations exceed the workspace budget run the forward without saving and the backward
-    re-runs it sub-chunk by sub-chunk: outputs identical, gradients equal to the one-shot backward up to the fp32
-    summation order of the per-sub-chunk partial sums."""
+def test_large_chunks_backpropagate_in_subchunks(npa, dev, nets, precision, monkeypatch):
+    """Ray chunks whose backward scratch exceeds the per-launch budget are rendered in equal sub-chunks.  While the saved
+    activations of all sub-chunks fit SAVE_TOTAL_BYTES every sub-chunk keeps its own lease (no recomputation); beyond
+    that the forward runs without saving and the backward re-runs it sub-chunk by sub-chunk.  Either way: outputs
+    identical, gradients equal to the one-shot backward up to the fp32 summation order of the per-sub-chunk partial sums."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
     n = 2500
@@ -1219,13 +1220,25 @@ def test_large_chunks_backpropagate_in_subchunks_with_recompute(npa, dev, nets, 
         out_a, gc_a, gf_a = run()
         monkeypatch.setattr(hb, "SAVE_BUDGET_BYTES", 4 * hb.workspace_floats(1024, 64, 128) + 1)      # -> 1024-ray sub-chunks
         assert hb.max_saved_rays(64, 128) == 1024
+        # (a) the sub-chunks' saved activations fit SAVE_TOTAL_BYTES: each keeps its lease, the forward runs ONCE per sub-chunk
+        calls = []
+        real_fwd = hb.field_fwd
+        monkeypatch.setattr(hb, "field_fwd", lambda *a, **k: (calls.append(k.get("save_act")), real_fwd(*a, **k))[1])
+        out_t, gc_t, gf_t = run()
+        assert calls == [True] * 6, calls           # 3 sub-chunks (2500 rays -> 3 x 896) x (coarse, fine), all saving, none re-run
+        # (b) they do not fit: forward without saving, backward re-runs it sub-chunk by sub-chunk
+        monkeypatch.setattr(hb, "SAVE_TOTAL_BYTES", 0)
+        del calls[:]
         out_b, gc_b, gf_b = run()
+        assert calls == [False, False] + [True] * 6, calls
     finally:
         npa.set_precision("fp32")
-    for k in out_a:
-        assert torch.equal(torch.isnan(out_a[k]), torch.isnan(out_b[k])) and torch.equal(torch.nan_to_num(out_a[k]), torch.nan_to_num(out_b[k])), k
-    for ga, gb in ((gc_a, gc_b), (gf_a, gf_b)):
-        assert float((ga - gb).abs().max()) <= 2e-5 * float(ga.abs().max()), float((ga - gb).abs().max()) / float(ga.abs().max())
+    for out_x, gc_x, gf_x in ((out_t, gc_t, gf_t), (out_b, gc_b, gf_b)):
+        for k in out_a:
+            assert torch.equal(torch.isnan(out_a[k]), torch.isnan(out_x[k])) and torch.equal(torch.nan_to_num(out_a[k]), torch.nan_to_num(out_x[k])), k
+        for ga, gb in ((gc_a, gc_x), (gf_a, gf_x)):
+            assert float((ga - gb).abs().max()) <= 2e-5 * float(ga.abs().max()), float((ga - gb).abs().max()) / float(ga.abs().max())
+    assert torch.equal(gc_t, gc_b) and torch.equal(gf_t, gf_b)      # same sub-chunks, same kernels: the two modes agree bit for bit
 
 
 def test_training_steps_reuse_the_same_workspace_buffers(npa, dev, nets):

@@ -345,6 +345,8 @@ def test_workspace_size_query_and_lease_pool():
     assert L.nerf_workspace_floats(0, 64, 128, 1) == 0
     # the default budget (48 GiB) covers every N_rand of the BASELINE configs without recomputation
     assert npa.hip_backend.max_saved_rays(64, 128) >= 8192 and npa.hip_backend.max_saved_rays(64, 128) % 1024 == 0
+    # ... and the 32,768-ray chunk of configs[3] keeps the saved activations of its four sub-chunks resident
+    assert 4 * npa.hip_backend.saved_bytes(8192, 64, 128) <= npa.hip_backend.SAVE_TOTAL_BYTES < 288e9
     w = npa.hip_backend.Workspace()
     a = w.take(1000, "cpu")
     b = w.take(1000, "cpu")
