@@ -93,18 +93,6 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[4 * nb + r] = fmaxf(acc[nb][r], 0.0f);
     };
-    auto save_mask16 = [&](int layer) __attribute__((always_inline)) {      // ReLU bitmask of the rows in h[]
-        if (!SAVE) return;
-        unsigned w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int nb = 0; nb < 16; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) w[nb >> 2] |= (h[4 * nb + r] > 0.0f ? 1u : 0u) << (8 * (nb & 3) + 4 * (q >> 1) + r);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] |= __shfl_xor(w[i], 32);
-        if (valid && q < 2)
-            nt_store(reinterpret_cast<u32x4*>(a.act + al.mask) + ((size_t)layer * P + p) * 2 + q, u32x4{w[0], w[1], w[2], w[3]});
-    };
     constexpr int NP = SAVE ? 4 : 0;        // row stores guaranteed behind the last fetch part (one per unit, positions 3..6)
     auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
         store_word(region, F, nb, r0, cvt_pk_bf16(v0, v1));
@@ -114,11 +102,35 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
     // block 2 kk + (gg >> 1), rows 2 (gg & 1), 2 (gg & 1) + 1 (the store pattern of field_fwd16_kernel<2>)
     size_t row_region = 0;
     // (the bf16 values of rows (r0, r0 + 1) of block nb ARE word g of the B operand's hi fragment of k-step kk)
+    // ... and so do the bits of their ReLU mask: two compares per unit in the shadow of its MFMAs instead of 64 at the layer's
+    // end, where neither wave of the SIMD has an MFMA in flight (mw: the four mask words of the layer in h[], without the
+    // lane-dependent shift)
+    unsigned mw[4] = {0u, 0u, 0u, 0u};
+    auto mask_bits = [&](auto nbc, auto rc) __attribute__((always_inline)) {
+        constexpr int nb = decltype(nbc)::value, r = decltype(rc)::value;
+        unsigned b = h[4 * nb + r] > 0.0f ? 1u << (8 * (nb & 3) + r) : 0u;
+        asm volatile("" : "+v"(b));
+        mw[nb >> 2] |= b;
+    };
     auto store_rows = [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
         if (!SAVE) return;
         constexpr int nb = 2 * decltype(kk)::value + (decltype(gg)::value >> 1);
         constexpr int r0 = 2 * (decltype(gg)::value & 1);
         store_word(row_region, W, nb, r0, bhi[decltype(gg)::value]);
+        mask_bits(std::integral_constant<int, nb>{}, std::integral_constant<int, r0>{});
+        mask_bits(std::integral_constant<int, nb>{}, std::integral_constant<int, r0 + 1>{});
+    };
+    auto finish_mask = [&](int layer) __attribute__((always_inline)) {     // the words save_mask16 builds, bit for bit
+        if (!SAVE) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mw[i] <<= 4 * (q >> 1);
+            mw[i] |= __shfl_xor(mw[i], 32);
+        }
+        if (valid && q < 2)
+            nt_store(reinterpret_cast<u32x4*>(a.act + al.mask) + ((size_t)layer * P + p) * 2 + q, u32x4{mw[0], mw[1], mw[2], mw[3]});
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mw[i] = 0u;
     };
 
     ring.ready();
@@ -129,7 +141,6 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
     load_bias<16>(acc, bias, q);
     ring_units<8, 4, 0, true, 0>(ring, fa, fb, fl, acc, e, no_store);
     take();
-    save_mask16(0);
     // ---- layers 1..7 (layer 5 contracts the xyz encoding first: skip connection).  Layer l writes the rows of layer l-1.
 #pragma unroll 1
     for (int l = 1; l < D; ++l) {
@@ -137,8 +148,8 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
         if (l == SKIP + 1) ring_units<8, 4, 0, false, 0>(ring, fa, fb, fl, acc, e, no_store);
         row_region = (size_t)(l - 1) * layer_floats;
         ring_units<32, 4, 0, false, NP>(ring, fa, fb, fl, acc, h, store_rows);
+        finish_mask(l - 1);
         take();
-        save_mask16(l);
     }
     // ---- density head: alpha_linear 256 -> 1 (VALU dot + quarter reduction)
     float sigma = 0.0f;
@@ -178,8 +189,10 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwd
             constexpr int nb = 2 * decltype(kk)::value + decltype(gg)::value;
             store_word(row_region, W, nb, 0, bhi[2 * decltype(gg)::value]);
             store_word(row_region, W, nb, 2, bhi[2 * decltype(gg)::value + 1]);
+            static_for<0, 4>([&](auto rc) __attribute__((always_inline)) { mask_bits(std::integral_constant<int, nb>{}, rc); });
         };
         ring_units<16, 2, 0, false, NP>(ring, fa, fb, fl, av, h, store_rows_v);
+        finish_mask(D - 1);
         ring_units<2, 2, 0, false, 0>(ring, fa, fb, fl, av, dv, no_store);
     }
     float hv[32];

@@ -1,8 +1,4 @@
 #!/bin/bash
-# scratch driver of the experiment of the moment (gpurun): tools/gpu_exp.sh <script> [args] ; more scripts separated by --
+# scratch driver for the experiment of the moment (gpurun)
 mkdir -p gpurun_out
-args=()
-for a in "$@"; do
-  if [ "$a" == "--" ]; then timeout 300 python "${args[@]}" 2>&1 | tail -60; args=(); else args+=("$a"); fi
-done
-[ ${#args[@]} -gt 0 ] && timeout 300 python "${args[@]}" 2>&1 | tail -60
+timeout 500 python tools/exp_ring_variants.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ringv6.log | tail -12

@@ -62,7 +62,18 @@ def nolds_b(d):
 
 def noepi(d):       # dgrad: no ReLU-mask arithmetic in the layer epilogue (acc copied as is); forward: no ReLU bitmask construction
     patch(B(d), "        const unsigned bit = (m[i >> 5] >> (i & 31)) & 1u;\n        d[i] = bit ? acc[i >> 4][i & 15] : 0.0f;", "        d[i] = acc[i >> 4][i & 15];")
-    patch(F(d), "        if (!SAVE) return;\n        unsigned w[4] = {0u, 0u, 0u, 0u};\n#pragma unroll\n        for (int nb = 0; nb < 16; ++nb)", "        return;\n        unsigned w[4] = {0u, 0u, 0u, 0u};\n#pragma unroll\n        for (int nb = 0; nb < 16; ++nb)")
+    nomask(d)
+
+
+def nomask(d):      # forward: no ReLU bitmask construction (bits per unit, shift / exchange / store per layer)
+    patch(F(d), "        unsigned b = h[4 * nb + r] > 0.0f ? 1u << (8 * (nb & 3) + r) : 0u;\n        asm volatile(\"\" : \"+v\"(b));\n        mw[nb >> 2] |= b;",
+          "        (void)nb; (void)r;")
+    patch(F(d), "    auto finish_mask = [&](int layer) __attribute__((always_inline)) {     // the words save_mask16 builds, bit for bit\n        if (!SAVE) return;",
+          "    auto finish_mask = [&](int layer) __attribute__((always_inline)) {\n        return;")
+
+
+def noencsave(d):   # forward: the xyz encodings are not written
+    patch(F(d), "                if (col >= 0) nt_store(reinterpret_cast<__bf16*>(a.act + al.enc)", "                if (col == -77) nt_store(reinterpret_cast<__bf16*>(a.act + al.enc)")
 
 
 W = lambda d: os.path.join(d, "field_bwd.hip")
@@ -92,12 +103,20 @@ def nosched(d):     # hipcc's own order inside a unit
     open(R(d), "w").write(s[:a] + body + s[b:])
 
 
+def head(d):        # the committed sources (git HEAD) instead of the working tree: A/B of an uncommitted change against "base"
+    for f in os.listdir(d):
+        r = subprocess.run(["git", "-C", ROOT, "show", f"HEAD:nerf-pytorch_amd/csrc/{f}"], capture_output=True)
+        if r.returncode == 0:
+            open(os.path.join(d, f), "wb").write(r.stdout)
+
+
 VARIANTS = {
-    "base": [], "nobar": [nobar], "nodma": [nodma], "nolds": [nolds_b], "halflds": [halflds], "nosplit": [nosplit], "noenc": [noenc],
+    "base": [], "head": [head], "nobar": [nobar], "nodma": [nodma], "nolds": [nolds_b], "halflds": [halflds], "nosplit": [nosplit], "noenc": [noenc],
     "prio_b": [prio_b], "prio_a": [prio_a], "nosched": [nosched],
     "mfmaonly": [nobar, nodma, nolds_b, nosplit], "nostore": [nostore], "wg_c19": [wg_coarse(19)], "wg_c26": [wg_coarse(26)], "noepi": [noepi], "noepi_nostore": [noepi, nostore], "mfmaonly_nostore": [nobar, nodma, nolds_b, nosplit, nostore],
 
-    "nobar_nodma": [nobar, nodma],
+    "nobar_nodma": [nobar, nodma], "nomask": [nomask], "noencsave": [noencsave], "nomask_nostore": [nomask, nostore],
+    "nosave_at_all": [nomask, nostore, noencsave],
 }
 
 
