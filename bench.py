@@ -216,7 +216,7 @@ def rocm_eager_baseline(cfg_name, dev, n_rays, steps=5):
 # --------------------------------------------------------------------------------------------- per-kernel table / roofline
 def _kernel_class(name):
     """(MFMAs issued per executed product, executed / algorithmic MAC ratio, arithmetic peak) of a timed kernel"""
-    fwd = name.startswith(("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd16r_kernel"))
+    fwd = name.startswith(("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd16r_kernel", "render_infer_kernel"))
     if name.startswith(("field_fwd_kernel", "field_dgrad_kernel", "wgrad256_kernel", "wgrad_kernel")):
         return 1.0, 1.0, PEAK_FP32_MFMA_TFLOPS                                  # exact-fp32 datapath
     if fwd:
@@ -682,11 +682,19 @@ def main():
         multi = {"rccl_ranks_seen": parallel.ranks_seen()}
 
     # ---- secondary numbers of the same run (never the headline)
-    other_infer = second = second_mixed = fp32_operands = None
+    other_infer = infer_chain = second = second_mixed = fp32_operands = None
     if args.mode == "train":
         k_inf = max(5, args.steps // 2)
         el_i, _ = measure(args.precision, k_inf, 2, ses.infer_step, with_kernels=False)
         other_infer = n * world * k_inf / el_i
+        infer_chain = None
+        if hb.INFER_ONE_LAUNCH and hb.render_infer_supported(N_SAMPLES, N_IMPORTANCE, args.precision):
+            hb.INFER_ONE_LAUNCH = False         # the same batches through the chain of six launches
+            try:
+                el_c, _ = measure(args.precision, k_inf, 2, ses.infer_step, with_kernels=False)
+            finally:
+                hb.INFER_ONE_LAUNCH = True
+            infer_chain = n * world * k_inf / el_c
     if not args.single_datapath and args.mode != "render_only":
         p2 = "bf16x3" if args.precision == "fp32" else "fp32"
         k2 = max(4, args.steps // 4)
@@ -804,6 +812,10 @@ def main():
             line["configs"] = legs
         if other_infer is not None:
             line["inference_rays_per_s"] = other_infer
+            if infer_chain is not None:
+                line["inference"] = {"one_launch_rays_per_s": other_infer, "chain_of_launches_rays_per_s": infer_chain,
+                                     "what": "no_grad render() of the same batches: render_infer_kernel (one launch per ray chunk, the default) "
+                                             "vs sample_coarse -> field forward -> composite -> sample_fine -> field forward -> composite"}
         if second is not None:
             line["other_datapath"] = second
         if second_mixed is not None:

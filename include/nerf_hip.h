@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 5
+#define NERF_ABI_VERSION 6
 #define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
 
@@ -255,6 +255,17 @@ int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const 
                          int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
                          float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
                          float* workspace, int training, void* stream);
+/* nerf_render_rays_fwd(training = 0) as ONE kernel launch (csrc/render_fused.hip): a workgroup owns 16 rays from the coarse
+ * depths (run_nerf.py:357-379) through both networks, raw2outputs (:262-305) and sample_pdf + sort (:392-396) to the final
+ * colours.  Same device code as the separate launches: every output is bit-identical to nerf_render_rays_fwd.  Same arguments
+ * and workspace (nerf_render_workspace_floats(cfg, n_rays, 0)).  Split-bf16 / mixed datapath only, and only sample counts
+ * for which 16 rays fill whole 128-point tiles in both passes (n_coarse and n_coarse + n_fine multiples of 8, at most 1024
+ * samples per ray): nerf_render_infer_supported(cfg) tells; otherwise NERF_E_BADARG. */
+int nerf_render_infer_supported(const NerfRenderCfg* cfg);
+int nerf_render_rays_infer(const NerfRenderCfg* cfg, const float* packed_c, const float* packed_f, const float* rays, int ray_stride,
+                           int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
+                           float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
+                           float* workspace, void* stream);
 int nerf_render_rays_bwd(const NerfRenderCfg* cfg, const float* packed_c, const float* packed_f, const float* params_c,
                          const float* params_f, const float* rays, int ray_stride, int n_rays, const float* noise_c,
                          const float* noise_f, const float* raw, const float* d_rgb, const float* d_disp, const float* d_acc,

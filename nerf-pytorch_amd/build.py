@@ -15,8 +15,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnerf_hip.so")
 STAMP_PATH = os.path.join(PKG_DIR, "libnerf_hip.stamp")
-SOURCES = ["api.hip", "render_abi.hip", "pack.hip", "ray_ops.hip", "field_fwd.hip", "field_bwd.hip", "field_fwd_bf16.hip", "field_bwd_bf16.hip", "field_fwd_ring.hip", "field_bwd_ring.hip"]
-HEADERS = ["nerf_common.h", "field_device.h", "field_device_bf16.h", "field_ring.h", "api_util.h", "launchers.h", os.path.join("..", "..", "include", "nerf_hip.h")]
+SOURCES = ["api.hip", "render_abi.hip", "pack.hip", "ray_ops.hip", "field_fwd.hip", "field_bwd.hip", "field_fwd_bf16.hip", "field_bwd_bf16.hip", "field_fwd_ring.hip", "field_bwd_ring.hip", "render_fused.hip"]
+HEADERS = ["nerf_common.h", "field_device.h", "field_device_bf16.h", "field_ring.h", "field_fwd_ring_body.h", "ray_device.h", "api_util.h", "launchers.h", os.path.join("..", "..", "include", "nerf_hip.h")]
 # -ffp-contract=off: the per-ray arithmetic is written in the reference's operation
 # order (separate multiply / add) so z_vals, dists and sample points round identically.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]

@@ -36,6 +36,25 @@ struct FineArgs {
     int n_rays, n_in, Nf, direct;   // n_in = Sc (direct == 0) or nb (direct == 1)
 };
 
+// render_rays without gradients in one launch (render_fused.hip)
+struct RenderInferArgs {
+    const float* packed_c;  // packed3 of the coarse network
+    const float* packed_f;  // packed3 of the fine network (== packed_c when there is none)
+    const float* rays;
+    int ray_stride, n_rays, n_c, n_f, lindisp, white_bkgd;
+    float noise_std;
+    const float* t_rand;    // [N][n_c] or null
+    const float* noise_c;   // [N][n_c] or null
+    const float* u;         // [N][n_f] or null (deterministic: linspace)
+    const float* noise_f;   // [N][n_c + n_f] or null
+    // coarse pass (the only pass when n_f == 0: then these ARE the outputs)
+    float *z_c, *raw_c, *w_c, *rgb_c, *disp_c, *acc_c;
+    // fine pass
+    float *z_f, *z_std, *raw_f, *rgb_f, *disp_f, *acc_f;
+};
+bool render_infer_fused_ok(int n_c, int n_f);
+hipError_t launch_render_infer(const RenderInferArgs& a, hipStream_t stream);
+
 hipError_t launch_pack(const float* canon_params, float* packed, hipStream_t stream);
 hipError_t launch_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int S,
                                 int lindisp, const float* t_rand, float* z_out, hipStream_t stream);

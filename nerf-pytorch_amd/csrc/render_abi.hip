@@ -154,6 +154,43 @@ int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const 
     return done(__func__, nerf::launch_composite(a, false, st));
 }
 
+int nerf_render_infer_supported(const NerfRenderCfg* cfg) {
+    return cfg_ok(cfg) && cfg->precision != 0 && nerf::render_infer_fused_ok(cfg->n_coarse, cfg->n_fine) ? 1 : 0;
+}
+
+int nerf_render_rays_infer(const NerfRenderCfg* cfg, const float* packed_c, const float* packed_f, const float* rays, int ray_stride,
+                           int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
+                           float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
+                           float* workspace, void* stream) {
+    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0..2, raw_noise_std >= 0)");
+    REQUIRE(nerf_render_infer_supported(cfg), "one-launch inference: split-bf16 / mixed datapath, 16 * n_coarse and 16 * (n_coarse + n_fine) "
+            "multiples of 128, n_coarse + n_fine <= 1024 (use nerf_render_rays_fwd(training = 0) otherwise)");
+    REQUIRE(packed_c && rays && rgb && disp && acc && raw && workspace, "null pointer");
+    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
+    REQUIRE(n_rays >= 0, "bad size");
+    const int Sc = cfg->n_coarse, Sf = cfg->n_fine;
+    const bool fine = Sf > 0;
+    REQUIRE(!fine || (rgb0 && disp0 && acc0 && z_std), "n_fine > 0 needs the coarse outputs rgb0 / disp0 / acc0 and z_std");
+    REQUIRE(!(cfg->raw_noise_std > 0.0f) || (noise_c && (!fine || noise_f)), "raw_noise_std > 0 needs the noise draws");
+    REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(packed_c) & 15) == 0, "workspace / raw / packed must be 16-byte aligned");
+    if (n_rays == 0) return 0;
+    const RenderWs w = render_ws(n_rays, Sc, Sf, 0);
+    float* ws = workspace;
+    const bool noisy = cfg->raw_noise_std > 0.0f;
+    nerf::RenderInferArgs a{};
+    a.packed_c = packed_c;
+    a.packed_f = (fine && packed_f) ? packed_f : packed_c;          // network_fine == None: the coarse network (run_nerf.py:400)
+    a.rays = rays; a.ray_stride = ray_stride; a.n_rays = n_rays; a.n_c = Sc; a.n_f = Sf;
+    a.lindisp = cfg->lindisp; a.white_bkgd = cfg->white_bkgd; a.noise_std = cfg->raw_noise_std;
+    a.t_rand = t_rand; a.noise_c = noisy ? noise_c : nullptr; a.u = u; a.noise_f = noisy ? noise_f : nullptr;
+    a.z_c = ws + w.z_c; a.w_c = ws + w.w_c;
+    a.raw_c = fine ? ws + w.raw_c : raw;
+    a.rgb_c = fine ? rgb0 : rgb; a.disp_c = fine ? disp0 : disp; a.acc_c = fine ? acc0 : acc;
+    a.z_f = ws + w.z_f; a.z_std = z_std; a.raw_f = raw; a.rgb_f = rgb; a.disp_f = disp; a.acc_f = acc;
+    return done(__func__, nerf::launch_render_infer(a, (hipStream_t)stream));
+}
+
 int nerf_render_rays_bwd(const NerfRenderCfg* cfg, const float* packed_c, const float* packed_f, const float* params_c,
                          const float* params_f, const float* rays, int ray_stride, int n_rays, const float* noise_c,
                          const float* noise_f, const float* raw, const float* d_rgb, const float* d_disp, const float* d_acc,

@@ -15,7 +15,7 @@ from . import build as _build
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
-ABI_VERSION = 5        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
+ABI_VERSION = 6        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
 
 
 class NerfHipError(RuntimeError):
@@ -68,6 +68,8 @@ def _declare(lib):
         "nerf_render_workspace_floats": (sz, [p, i, i]),
         "nerf_render_rays_fwd": (i, [p, p, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p, i, p]),
         "nerf_render_rays_bwd": (i, [p, p, p, p, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p, i, p]),
+        "nerf_render_infer_supported": (i, [p]),
+        "nerf_render_rays_infer": (i, [p, p, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
@@ -83,7 +85,8 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_pack_params_bf16x3_sel", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
            "nerf_field_dgrad_bf16x3", "nerf_field_dgrad3r_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_field_fwd16r_bf16x3", "nerf_debug_pack16_table",
            "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step",
-           "nerf_render_workspace_floats", "nerf_render_rays_fwd", "nerf_render_rays_bwd"]
+           "nerf_render_workspace_floats", "nerf_render_rays_fwd", "nerf_render_rays_bwd", "nerf_render_infer_supported",
+           "nerf_render_rays_infer"]
 
 
 def lib():
@@ -465,6 +468,53 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
             return flat.view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
         off += Pa * F
     raise KeyError(region)
+
+
+# render_rays without gradients as ONE launch on the split-bf16 / mixed datapaths (csrc/render_fused.hip; bit-identical to the
+# chain of launches and as fast or faster for every ray count measured).  NERF_INFER_ONE_LAUNCH=0 keeps the chain:
+# sample_coarse -> field forward -> composite -> sample_fine -> field forward -> composite
+INFER_ONE_LAUNCH = os.environ.get("NERF_INFER_ONE_LAUNCH", "1") != "0"
+
+
+def render_cfg(n_coarse, n_fine, lindisp, white_bkgd, raw_noise_std, precision):
+    return NerfRenderCfg(int(n_coarse), int(n_fine), int(bool(lindisp)), int(bool(white_bkgd)), float(raw_noise_std),
+                         {"fp32": 0, "bf16x3": 1, "mixed": 2}[precision], int(WGRAD_OPERANDS == "bf16"))
+
+
+def render_infer_supported(n_coarse, n_fine, precision):
+    """whether nerf_render_rays_infer takes these sample counts on this datapath"""
+    if precision == "fp32":
+        return False
+    cfg = render_cfg(n_coarse, n_fine, 0, 0, 0.0, precision)
+    return bool(lib().nerf_render_infer_supported(ctypes.byref(cfg)))
+
+
+def render_rays_infer(packed_c, packed_f, rays, n_coarse, n_fine, lindisp, white_bkgd, raw_noise_std, precision, rnd):
+    """nerf_render_rays_infer: the whole no-grad render_rays of `rays` in one launch.  rnd: the optional draws {t_rand, noise_c,
+    u, noise_f}.  Returns the dict of render._field_pass's outputs (rgb_c, disp_c, acc_c, raw_c[, rgb_f, disp_f, acc_f, raw_f,
+    z_std])."""
+    L = lib()
+    n, dev = rays.shape[0], rays.device
+    fine = n_fine > 0
+    S2 = n_coarse + n_fine
+    cfg = render_cfg(n_coarse, n_fine, lindisp, white_bkgd, raw_noise_std, precision)
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    rgb, disp, acc, raw = e(n, 3), e(n), e(n), e(n, S2, 4)
+    rgb0, disp0, acc0, z_std = (e(n, 3), e(n), e(n), e(n)) if fine else (None, None, None, None)
+    ws = WORKSPACE.take(L.nerf_render_workspace_floats(ctypes.byref(cfg), n, 0), dev)
+    opt = lambda k: _ptr(rnd[k], k) if rnd.get(k) is not None else None
+    try:
+        with _timed("render_infer_kernel", FLOP_FWD3_PER_POINT * n * (n_coarse + (S2 if fine else 0)), 0.0):
+            _check(L.nerf_render_rays_infer(ctypes.byref(cfg), _ptr(packed_c, "packed3"), _ptr(packed_f, "packed3") if packed_f is not None else None,
+                                            _ptr(rays, "rays"), rays.shape[1], n, opt("t_rand"), opt("noise_c"), opt("u"), opt("noise_f"),
+                                            _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(raw), _ptr(rgb0) if fine else None,
+                                            _ptr(disp0) if fine else None, _ptr(acc0) if fine else None, _ptr(z_std) if fine else None,
+                                            _ptr(ws), _stream()), "nerf_render_rays_infer")
+    finally:        # stream-ordered: the next lease is written by kernels enqueued after this one
+        WORKSPACE.give(ws)
+    if not fine:
+        return {"rgb_c": rgb, "disp_c": disp, "acc_c": acc, "raw_c": raw}
+    return {"rgb_f": rgb, "disp_f": disp, "acc_f": acc, "raw_f": raw, "rgb_c": rgb0, "disp_c": disp0, "acc_c": acc0, "z_std": z_std}
 
 
 def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):

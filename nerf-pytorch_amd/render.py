@@ -175,7 +175,13 @@ class _RenderRays(torch.autograd.Function):
                 ctx.checkpoint = False
                 ctx.tiles = [(lo, min(lo + sub, n)) for lo in range(0, n, sub)]
         ctx.sub_rays = sub
-        if ctx.tiles is None:
+        prec = cfg.get("precision", "fp32")
+        if not need and hb.INFER_ONE_LAUNCH and hb.render_infer_supported(cfg["N_samples"], n_f, prec):
+            # no gradients: coarse depths -> network -> compositing -> hierarchical depths -> network -> compositing in ONE launch
+            mf = None if (model_f is None or model_f is model_c or n_f <= 0) else model_f
+            r = hb.render_rays_infer(model_c.packed_params(prec), None if mf is None else mf.packed_params(prec), rays, cfg["N_samples"],
+                                     n_f, cfg["lindisp"], cfg["white_bkgd"], cfg["raw_noise_std"], prec, rnd)
+        elif ctx.tiles is None:
             r = _field_pass(cfg, rays, rnd, model_c, model_f, save=need and not ctx.checkpoint)
         else:
             # every sub-chunk keeps its saved activations; the node's outputs are the concatenations (new tensors)

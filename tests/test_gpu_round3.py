@@ -518,3 +518,95 @@ def test_weight_gradient_refuses_mismatched_buffers_on_the_gpu(npa, dev, nets):
     assert L.nerf_field_wgrad_phase(*args, -1, 7, nf.flat_params().data_ptr(), s) == 0
     torch.cuda.synchronize()
     assert bool(torch.isfinite(grad).all())
+
+
+# ---------------------------------------------------------------- render_rays without gradients in one launch
+@pytest.mark.parametrize("n_rays", [1, 17, 129, 1000])
+@pytest.mark.parametrize("case", ["det", "random_white_noise", "lindisp", "coarse_only", "small", "mixed_same_net"])
+def test_one_launch_inference_is_bit_identical_to_the_chain_of_launches(npa, dev, nets, n_rays, case, monkeypatch):
+    """render_infer_kernel (csrc/render_fused.hip): a workgroup takes 16 rays from the coarse depths through both networks,
+    raw2outputs and sample_pdf + sort to the colours, calling the SAME device code as the separate launches -- so every
+    output of render_rays (incl. extras: raw, z_std, rgb0 / disp0 / acc0) is bit-identical to the chain sample_coarse ->
+    field forward -> composite -> sample_fine -> field forward -> composite; ragged ray counts (last workgroup partly empty,
+    a single ray), injected random draws, density noise, white background, lindisp, no fine pass, one shared network."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    n_c, n_f = {"coarse_only": (64, 0), "small": (8, 16)}.get(case, (64, 128))
+    kw = dict(N_samples=n_c, N_importance=n_f, network_fine=nf, retraw=True)
+    rnd = None
+    if case == "random_white_noise":
+        kw.update(white_bkgd=True, perturb=1.0, raw_noise_std=0.7)
+        rnd = {k: v.to(dev) for k, v in orc.synthetic_randoms(n_rays, n_c, n_f, seed=11).items()}
+    elif case == "lindisp":
+        kw.update(lindisp=True, white_bkgd=True)
+    elif case == "mixed_same_net":
+        kw.update(network_fine=None, white_bkgd=True)
+    rays = orc.synthetic_rays(n_rays, seed=91).to(dev)
+    npa.set_precision("mixed" if case == "mixed_same_net" else "bf16x3")
+    try:
+        assert hb.render_infer_supported(n_c, n_f, npa.get_precision())
+        outs = {}
+        for one in (False, True):
+            monkeypatch.setattr(hb, "INFER_ONE_LAUNCH", one)
+            launches = []
+            real = hb.render_rays_infer
+            monkeypatch.setattr(hb, "render_rays_infer", lambda *a, **k: (launches.append(1), real(*a, **k))[1])
+            with torch.no_grad():
+                outs[one] = npa.render_rays(rays, nc, None, randoms=rnd, **kw)
+            monkeypatch.setattr(hb, "render_rays_infer", real)
+            assert len(launches) == int(one)
+    finally:
+        npa.set_precision("fp32")
+    assert set(outs[False]) == set(outs[True])
+    for k in outs[False]:
+        a, b = outs[False][k], outs[True][k]
+        assert a.shape == b.shape, k
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), (k, maxdiff(a, b))
+
+
+def test_one_launch_inference_refuses_what_it_cannot_tile(npa, dev, nets):
+    """16 rays must fill whole 128-point tiles in both passes and the datapath must be split-bf16 / mixed: anything else is
+    NERF_E_BADARG from the C entry point (and the host code keeps the chain of launches)."""
+    import ctypes
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    L = hb.lib()
+    assert not hb.render_infer_supported(63, 128, "bf16x3") and not hb.render_infer_supported(64, 127, "bf16x3")
+    assert not hb.render_infer_supported(64, 128, "fp32") and hb.render_infer_supported(64, 128, "mixed")
+    assert not hb.render_infer_supported(512, 1024, "bf16x3")      # per-ray scratch beyond one wavefront's share of the LDS
+    cfg = hb.render_cfg(63, 128, False, True, 0.0, "bf16x3")
+    n = 16
+    rays = orc.synthetic_rays(n, seed=1).to(dev)
+    e = lambda *s: torch.empty(s, device=dev)
+    ws = e(L.nerf_render_workspace_floats(ctypes.byref(cfg), n, 0))
+    p3 = nf.packed_params("bf16x3")
+    rc = L.nerf_render_rays_infer(ctypes.byref(cfg), p3.data_ptr(), p3.data_ptr(), rays.data_ptr(), 11, n, None, None, None, None,
+                                  e(n, 3).data_ptr(), e(n).data_ptr(), e(n).data_ptr(), e(n, 191, 4).data_ptr(), e(n, 3).data_ptr(),
+                                  e(n).data_ptr(), e(n).data_ptr(), e(n).data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == -1 and b"one-launch inference" in L.nerf_last_error()
+
+
+def test_one_launch_inference_is_what_render_runs_without_gradients(npa, dev, nets):
+    """render() under no_grad on the split-bf16 datapath is ONE kernel per ray chunk (timer labels of bench.py); with gradients
+    enabled, and on the exact-fp32 datapath, it stays the chain of launches."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    assert hb.INFER_ONE_LAUNCH
+    H, W, focal = 16, 16, 20.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    rays = orc.synthetic_rays(H * W, seed=4).to(dev)
+    kw = dict(network_fn=nc, network_fine=nf, network_query_fn=None, N_samples=64, N_importance=128, perturb=0., white_bkgd=True,
+              raw_noise_std=0., use_viewdirs=True, near=2., far=6.)
+    seen = {}
+    for prec, grad in (("bf16x3", False), ("bf16x3", True), ("fp32", False)):
+        npa.set_precision(prec)
+        hb.TIMER = hb.KernelTimer()
+        try:
+            with torch.set_grad_enabled(grad):
+                npa.render(H, W, K, chunk=100, rays=(rays[:, 0:3], rays[:, 3:6]), **kw)
+            seen[(prec, grad)] = set(hb.TIMER.summary())
+        finally:
+            hb.TIMER = None
+            npa.set_precision("fp32")
+    assert seen[("bf16x3", False)] == {"render_infer_kernel"}, seen
+    assert "render_infer_kernel" not in seen[("bf16x3", True)] and "render_infer_kernel" not in seen[("fp32", False)], seen
