@@ -162,6 +162,8 @@ struct WgradJob {
     int tiles_k, tile_base;         // tiles of this job: [tile_base, tile_base + tiles_n*tiles_k)
     int vecA, vecB;                 // 16-byte aligned full-row loads allowed
     int b_tile16;                   // bf16x3: B is stored in 16-point tiles with the row16 row order (field_fwd16_kernel<1>)
+    int b_ray_tiles;                // wgrad1_kernel: > 0 = B is constant along a ray (the direction encoding) and stored ONCE per
+                                    // ray as [ray][feature][8 copies] bf16 (512 B per ray); value = 32-point tiles per ray
     // bf16x3 only: a rank-1 rider on this job's B operand.  aux != nullptr: dW_aux[f] = sum_p aux[p] * B[p][f] and
     // db_aux = sum_p aux[p] are accumulated in fp32 by the B-staging threads from the values they convert anyway
     // (4 FMAs per round) -- the alpha_linear weight gradient rides on the job that stages the trunk output h7, which
@@ -645,17 +647,23 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     // B operands saved by field_fwd16_kernel<2>: the stage's 32 points are two consecutive 16-point tiles of sld rows x
     // 32 B (row16h order, nerf_common.h); 8-point group g of feature f sits at tile (g >> 1), row16h(f), bytes 16 * (g & 1)
     const bool t16 = sop == 1 && jb.b_tile16 != 0;
+    // B constant along a ray: every 8-point group of feature f of a tile is the ray's 16-byte record of f (8 copies of the
+    // value); the stage's source is the record block of the ray its tile belongs to
+    const int ray_tiles = sop == 1 ? jb.b_ray_tiles : 0;
     unsigned doff[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int q = 64 * (4 * (wave & 3) + u) + lane;
         const int f = q >> 2, jj = q & 3;
         const unsigned fc = (unsigned)min(f, swidth - 1), g = (unsigned)(jj ^ ((f >> 2) & 3));
-        doff[u] = t16 ? (g >> 1) * 32u * (unsigned)sld + 32u * (unsigned)row16h((int)fc) + 16u * (g & 1u) : 64u * fc + 16u * g;
+        doff[u] = ray_tiles > 0 ? 16u * fc
+                : t16 ? (g >> 1) * 32u * (unsigned)sld + 32u * (unsigned)row16h((int)fc) + 16u * (g & 1u) : 64u * fc + 16u * g;
     }
+    const char* rbase = reinterpret_cast<const char*>(jb.B);
+    const long tile0 = p_begin >> 5;
     const unsigned lds0 = lds_addr(sm1) + (unsigned)(sop * WG1_OP_BYTES + (wave & 3) * 4096);
     auto issue = [&](int st) {
-        const char* src = cbase + (size_t)st * tile_bytes;
+        const char* src = ray_tiles > 0 ? rbase + (size_t)((tile0 + st) / ray_tiles) * (size_t)(16 * sld) : cbase + (size_t)st * tile_bytes;
         const unsigned dst = lds0 + (unsigned)(st & 3) * WG1_STAGE_BYTES;
 #pragma unroll
         for (int u = 0; u < 4; ++u) dma_1k_s(src, doff[u], dst + 1024u * u);
@@ -917,6 +925,18 @@ __global__ void expand_dir_tiles_bf16_kernel(const float* __restrict__ dir_ray, 
     dir_pt[i] = pack8(v);
 }
 
+// ... or, when a ray's samples fill whole 32-point tiles, ONCE per ray: [ray][feature][8 copies] bf16 -- 16 bytes per (ray,
+// feature), which is the fragment wgrad1_kernel's DMA fetches for every 8-point group of that ray (2 MB instead of 50 MB for
+// 4096 x 192 points, and no per-point kernel)
+__global__ void replicate_dir_bf16_kernel(const float* __restrict__ dir_ray, u32x4* __restrict__ dir_rep, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // (ray, feature)
+    if (i >= n) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = dir_ray[i];
+    dir_rep[i] = pack8(v);
+}
+
 // phases: bit 0 = full-width jobs, bit 1 = narrow jobs, bit 2 = chunk reduction (7 = everything)
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
                               float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream,
@@ -949,7 +969,10 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         x_feat = act + al.feat; x_hv = act + al.hv; x_enc = act + al.enc; x_dir = act + al.dir_pt;
         ld_graw = 4;
         if (phases & 1) {   // act is written by the forward; the expanded copy is scratch inside the same buffer
-            if (mixed) {
+            if (mixed && S % 32 == 0) {
+                hipLaunchKernelGGL(replicate_dir_bf16_kernel, dim3((unsigned)(((long)n_rays * 32 + 255) / 256)), dim3(256), 0, stream,
+                                   act + al.dir, reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt), (long)n_rays * 32);
+            } else if (mixed) {
                 const long n_thr = ((P + 31) >> 5) * 128;
                 hipLaunchKernelGGL(expand_dir_tiles_bf16_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,
                                    act + al.dir, reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
@@ -983,6 +1006,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         j.A = A; j.B = B; j.lda = lda; j.nA = nA; j.ldb = ldb; j.nB = nB; j.b_rowdiv = rowdiv;
         // rows saved by the 16-point forward (256- / 128-wide regions) are in 16-point tiles; encodings are not
         j.b_tile16 = (x_tile16 && (ldb == W || ldb == WV)) ? 1 : 0;
+        j.b_ray_tiles = 0;
         j.c_off = c_off; j.ldc = ldc; j.bias_off = bias_off;
         const int tn = (nA + WG_TILE - 1) / WG_TILE;
         j.tiles_k = (nB + WG_TILE - 1) / WG_TILE;
@@ -1011,6 +1035,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         if (ride_sigma) { wa.job[nj - 1].aux = d_sigma; wa.job[nj - 1].aux_w_off = cn.wa; wa.job[nj - 1].aux_b_off = cn.ba; }
     } else add(d_hv, WV, WV, x_feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
     add(d_hv, WV, WV, x_dir, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
+    if (mixed && S % 32 == 0 && nj <= WG_MAX_JOBS) wa.job[nj - 1].b_ray_tiles = S / 32;       // direction encoding: one record per ray
     add(d_rgb, ld_graw, 3, x_hv, WV, WV, 1, cn.wr, WV, cn.br);
     if (nj != WG_MAX_JOBS - (fold ? 1 : 0) - (ride_sigma ? 1 : 0)) return hipErrorInvalidValue;
     // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
