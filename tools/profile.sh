@@ -4,8 +4,9 @@
 # Writes gpurun_out/prof_<prec>/ and the two summaries profiles/ expects:
 #   gpurun_out/prof_<prec>/kernel_stats.csv, gpurun_out/prof_<prec>/pmc_summary.csv
 PREC=${1:-bf16x3}; shift
+TAG=${TAG:-$PREC}           # directory tag: TAG=bf16x3_render_only tools/profile.sh bf16x3 --mode render_only --steps 2 --warmup 1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_$PREC
+OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eager-baseline --no-gate --single-datapath --no-configs --precision $PREC $@"
@@ -16,7 +17,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES G
   timeout 600 rocprofv3 --kernel-trace --pmc $pass -f csv -d $OUT/pmc_$tag -o bench -- $CMD > $OUT/pmc_$tag.log 2>&1; echo "pmc $tag rc=$?"
 done
 cd $R
-python - "$PREC" "$CMD" <<'PY'
+python - "$TAG" "$CMD" <<'PY'
 import csv, glob, collections, sys, os
 prec, cmd = sys.argv[1], sys.argv[2]
 out = f"gpurun_out/prof_{prec}"
