@@ -272,6 +272,28 @@ int nerf_render_rays_bwd(const NerfRenderCfg* cfg, const float* packed_c, const 
                          const float* d_raw_out, const float* d_rgb0, const float* d_disp0, const float* d_acc0,
                          float* workspace, float* grad_c, float* grad_f, int accumulate, void* stream);
 
+/* ---- architectures outside the fused kernels (csrc/dense.hip): the reference's layer stack (run_nerf_helpers.py:96-119) for any
+ * netdepth / netwidth / skips / multires / multires_views / i_embed = -1 / use_viewdirs = False (run_nerf.py:435-442,
+ * helpers:48-50, :93-94, :117), one layer per call.  Row-major matrices with explicit leading dimensions (a layer may read or
+ * write a column range of a wider matrix: skip connection, view branch, rgb | alpha -- no concatenations).  The GEMMs are
+ * plain library SGEMMs (rocBLAS, exact fp32, atomics off), loaded on first use; the epilogues are HIP kernels.
+ *   nerf_build_inputs : x[p] = [enc(o + d z_p) | enc(viewdir)] for every sample point (run_nerf.py:381, :41-47);
+ *                       multires / multires_views = number of frequencies, -1 = identity (i_embed = -1);
+ *                       rays [N][ray_stride] = (o3, d3, near, far[, viewdir3 in the LAST three columns])
+ *   nerf_dense_fwd    : y[P,N] (+)= x[P,K] w[N,K]^T (+ bias) (then ReLU)               = F.linear (+ F.relu), helpers:99-100
+ *   nerf_dense_dgrad  : dx[P,K] (+)= dy[P,N] w[N,K]; then dx *= (act > 0) if act       (act = post-ReLU output of the layer below)
+ *   nerf_dense_wgrad  : dw[N,K] (+)= dy^T x; dbias[N] (+)= column sums of dy (deterministic two-pass sum; scratch of
+ *                       nerf_dense_wgrad_scratch_floats(P, N) floats) */
+int nerf_build_inputs(const float* rays, int ray_stride, const float* z_vals, int n_rays, int n_samples, int multires, int multires_views,
+                      int use_viewdirs, float* x, int ldx, void* stream);
+int nerf_dense_fwd(const float* x, int ldx, int K, const float* w, int ldw, const float* bias, float* y, int ldy, int N, long P,
+                   int accumulate, int relu, void* stream);
+int nerf_dense_dgrad(const float* dy, int lddy, int N, const float* w, int ldw, float* dx, int lddx, int K, long P, int accumulate,
+                     const float* act, int ldact, void* stream);
+size_t nerf_dense_wgrad_scratch_floats(long P, int N);
+int nerf_dense_wgrad(const float* dy, int lddy, int N, const float* x, int ldx, int K, long P, float* dw, int lddw, float* dbias,
+                     float* scratch, int accumulate, void* stream);
+
 /* ---- optimizer.step() of run_nerf.py:776 for torch.optim.Adam(lr, betas=(beta1, beta2), eps) (run_nerf.py:207), fused over
  * a flat vector: params / grads / exp_avg / exp_avg_sq [n]; step = 1-based step count (bias correction). */
 int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,

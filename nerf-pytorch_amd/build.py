@@ -15,11 +15,12 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnerf_hip.so")
 STAMP_PATH = os.path.join(PKG_DIR, "libnerf_hip.stamp")
-SOURCES = ["api.hip", "render_abi.hip", "pack.hip", "ray_ops.hip", "field_fwd.hip", "field_bwd.hip", "field_fwd_bf16.hip", "field_bwd_bf16.hip", "field_fwd_ring.hip", "field_bwd_ring.hip", "render_fused.hip"]
+SOURCES = ["api.hip", "render_abi.hip", "pack.hip", "ray_ops.hip", "field_fwd.hip", "field_bwd.hip", "field_fwd_bf16.hip", "field_bwd_bf16.hip", "field_fwd_ring.hip", "field_bwd_ring.hip", "render_fused.hip", "dense.hip"]
 HEADERS = ["nerf_common.h", "field_device.h", "field_device_bf16.h", "field_ring.h", "field_fwd_ring_body.h", "ray_device.h", "api_util.h", "launchers.h", os.path.join("..", "..", "include", "nerf_hip.h")]
 # -ffp-contract=off: the per-ray arithmetic is written in the reference's operation
 # order (separate multiply / add) so z_vals, dists and sample points round identically.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+LIBS = ["-ldl"]        # dense.hip resolves rocBLAS with dlopen on first use
 
 
 def _hipcc():
@@ -50,7 +51,7 @@ def build(force=False, verbose=False):
     """Compile every HIP translation unit into nerf-pytorch_amd/libnerf_hip.so."""
     if not force and is_current():
         return LIB_PATH
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH] + LIBS
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)

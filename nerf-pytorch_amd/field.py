@@ -50,9 +50,26 @@ def get_embedder(multires, i=0):
 class NeRF(nn.Module):
     """Reference NeRF MLP (run_nerf_helpers.py:67-119), evaluated by fused HIP kernels.
 
-    Supported architecture = every BASELINE config: D=8, W=256, input_ch=63,
-    input_ch_views=27, skips=[4], use_viewdirs=True.  Anything else raises
-    (there is no eager fallback on the product path)."""
+    This class is the architecture of every BASELINE config (D=8, W=256, input_ch=63, input_ch_views=27, skips=[4],
+    use_viewdirs=True).  ``NeRF(...)`` with any other arguments the reference accepts returns a ``dense.DenseNeRF``: same
+    constructor, attributes and state_dict, evaluated layer by layer (library GEMMs behind the C ABI) instead of by the fused
+    kernels.  There is no eager / CPU fallback on either path."""
+
+    @staticmethod
+    def fused(D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
+        """whether these constructor arguments are the architecture of the fused kernels"""
+        return bool(D == 8 and W == 256 and input_ch == 63 and input_ch_views == 27 and list(skips) == [4] and use_viewdirs)
+
+    def __new__(cls, *args, **kwargs):
+        # NeRF(...) with any other arguments the reference accepts builds the layer-by-layer module (dense.py): same constructor,
+        # attributes and state_dict; the reference's arithmetic on library GEMMs instead of the fused kernels
+        if cls is NeRF and not NeRF.fused(*args, **kwargs):
+            from .dense import DenseNeRF
+            return DenseNeRF(*args, **kwargs)
+        return super().__new__(cls)
+
+    def __getnewargs_ex__(self):        # copy.deepcopy / pickle re-create the object through __new__: keep it on this class
+        return (), dict(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True)
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
         super().__init__()

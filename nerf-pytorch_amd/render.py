@@ -373,10 +373,19 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     """run_nerf.py:37-51.  inputs [N,S,3], viewdirs [N,3], fn a NeRF module.  The embedders are
     accepted for signature parity; encoding happens inside the fused kernel (and the
     netchunk loop disappears: the kernel tiles the points itself)."""
+    from .dense import DenseNeRF
+    if isinstance(fn, DenseNeRF):       # any other architecture: the reference's own composition (embed, broadcast, network)
+        flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+        embedded = embed_fn(flat)
+        if viewdirs is not None:
+            dirs = torch.reshape(viewdirs[:, None].expand(inputs.shape), [-1, inputs.shape[-1]])
+            embedded = torch.cat([embedded, embeddirs_fn(dirs)], -1)
+        out = batchify(fn, netchunk)(embedded)
+        return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
     if not isinstance(fn, NeRF):
         raise NotImplementedError("run_network: fn must be a nerf-pytorch_amd NeRF module")
     if viewdirs is None:
-        raise NotImplementedError("run_network: use_viewdirs=False is not implemented on gfx950")
+        raise ValueError("run_network: this network was built with use_viewdirs=True")
     flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
     dirs = viewdirs[:, None].expand(inputs.shape)
     dirs_flat = torch.reshape(dirs, [-1, dirs.shape[-1]])
@@ -428,10 +437,14 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     ``randoms`` (keyword-only, not in the reference) injects the random tensors
     {t_rand [N,N_samples], noise_c [N,N_samples], u [N,N_importance], noise_f [N,N_samples+N_importance]}
     instead of drawing them: the explicit form of the reference's ``pytest=`` hook."""
-    if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
-        raise NotImplementedError("render_rays: network_fn / network_fine must be nerf-pytorch_amd NeRF modules")
-    if ray_batch.shape[-1] <= 8:
-        raise NotImplementedError("render_rays: rays without view directions (use_viewdirs=False) are not implemented")
+    from .dense import DenseNeRF
+    nets = [network_fn] + ([network_fine] if network_fine is not None else [])
+    dense = all(isinstance(m, DenseNeRF) for m in nets)         # architectures outside the fused kernels: layer by layer (dense.py)
+    if not dense and not all(isinstance(m, NeRF) for m in nets):
+        raise NotImplementedError("render_rays: network_fn / network_fine must both be fused-kernel NeRF modules (D=8, W=256, 10 / 4 "
+                                  "frequencies, view directions) or both general ones (nerf_pytorch_amd.NeRF builds either)")
+    if not dense and ray_batch.shape[-1] <= 8:
+        raise ValueError("render_rays: these networks use view directions; the ray records need 11 columns (render(use_viewdirs=True))")
     rays = ray_batch.to(torch.float32).contiguous().detach()
     n = rays.shape[0]
     dev = rays.device
@@ -486,6 +499,12 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         std = 1.0       # pytest noise is pre-scaled in float64 like the reference (run_nerf.py:290)
     cfg = dict(N_samples=int(N_samples), N_importance=n_f, lindisp=bool(lindisp), white_bkgd=bool(white_bkgd),
                raw_noise_std=std, precision=_PRECISION)
+    if dense:
+        from .dense import render_rays_dense
+        ret = render_rays_dense(cfg, rays, rnd, network_fn, network_fine if n_f > 0 else None)
+        if not retraw:
+            ret.pop("raw")
+        return ret
     params = network_fn.param_list()
     same = network_fine is None or network_fine is network_fn
     if n_f > 0 and not same:
@@ -567,8 +586,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
            c2w_staticcam=None, **kwargs):
     """run_nerf.py:69-134: [rgb_map, disp_map, acc_map, extras].  With c2w the ray records are built by one HIP
     launch (get_rays + view directions + ndc_rays + near / far: SURVEY 8 f-2), no [H,W,3] intermediates."""
-    if not use_viewdirs:
-        raise NotImplementedError("render: use_viewdirs=False is not implemented on gfx950 (all BASELINE configs use it)")
+    # (use_viewdirs=False: the 11-column ray records are built all the same; networks without view directions ignore columns 8-10)
     if c2w is not None:
         net = kwargs.get("network_fn")
         dev = next(net.parameters()).device if net is not None else (c2w.device if isinstance(c2w, torch.Tensor) else None)

@@ -166,6 +166,43 @@ def main(n_rays=96):
     same(got["acc_map"], ref_list[2], "render(ndc) acc_map")
     same(got["raw"], ref_list[3]["raw"], "render(ndc) raw")
     same(got["z_std"], ref_list[3]["z_std"], "render(ndc) z_std")
+    print("other architectures (netdepth / netwidth / multires / i_embed = -1 / use_viewdirs = False -> output_linear)")
+    ARCHS = {"no_viewdirs": orc.arch_of(use_viewdirs=False), "narrow_shallow": orc.arch_of(D=6, W=128, multires=6, multires_views=2),
+             "identity_embedding": orc.arch_of(D=4, W=64, multires=-1, multires_views=-1, output_ch=4),
+             "no_viewdirs_small": orc.arch_of(D=7, W=96, multires=3, use_viewdirs=False, output_ch=4)}
+    for name, arch in ARCHS.items():
+        A = {k: arch[k] for k in ("D", "W", "input_ch", "input_ch_views", "output_ch", "skips", "use_viewdirs")}
+        nets, Ps = [], []
+        for seed in (31, 32):
+            P = orc.make_arch_params(arch, seed)
+            net = helpers.NeRF(**A)
+            assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == orc.arch_param_shapes(arch), name
+            net.load_state_dict({k: v.clone() for k, v in P.items()})
+            nets.append(net)
+            Ps.append(P)
+        i_embed = -1 if arch["multires"] < 0 else 0
+        e_fn, ch = helpers.get_embedder(arch["multires"], i_embed)
+        ed_fn, chv = helpers.get_embedder(arch["multires_views"], i_embed) if arch["use_viewdirs"] else (None, 0)
+        assert (ch, chv) == (arch["input_ch"], arch["input_ch_views"]), name
+        qfn = lambda inputs, viewdirs, network_fn, e_fn=e_fn, ed_fn=ed_fn: run_nerf.run_network(
+            inputs, viewdirs, network_fn, embed_fn=e_fn, embeddirs_fn=ed_fn, netchunk=1024 * 64)
+        rr = rays if arch["use_viewdirs"] else rays[:, :8]          # render() appends view directions only with use_viewdirs
+        torch.manual_seed(13)
+        ref = run_nerf.render_rays(rr, network_fn=nets[0], network_query_fn=qfn, N_samples=24, retraw=True, lindisp=False, perturb=1.0,
+                                   N_importance=40, network_fine=nets[1], white_bkgd=True, raw_noise_std=0.5)
+        torch.manual_seed(13)
+        rnd = dict(t_rand=torch.rand(n_rays, 24), noise_c=torch.randn(n_rays, 24), u=torch.rand(n_rays, 40), noise_f=torch.randn(n_rays, 64))
+        Pg = [{k: v.clone().requires_grad_(True) for k, v in P.items()} for P in Ps]
+        got = orc.trace_rays(rr, Pg[0], Pg[1], 24, 40, perturb=1.0, white_bkgd=True, raw_noise_std=0.5, retraw=True, arch=arch, **rnd)
+        for k in ref:
+            same(got[k], ref[k], f"{name} {k}")
+        loss = helpers.img2mse(ref["rgb_map"], target) + helpers.img2mse(ref["rgb0"], target)
+        loss.backward()
+        (orc.mse(got["rgb_map"], target) + orc.mse(got["rgb0"], target)).backward()
+        for net, P in zip(nets, Pg):
+            for k, p in net.state_dict(keep_vars=True).items():
+                if p.grad is not None or P[k].grad is not None:         # views_linears is unused without view directions
+                    same(P[k].grad, p.grad, f"{name} grad {k}")
     print("ORACLE PINNED: every function bit-identical to the reference on CPU")
 
 

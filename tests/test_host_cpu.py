@@ -83,11 +83,27 @@ def test_nerf_module_state_dict_and_flat_binding():
     assert torch.equal(npa.NeRF(**kw).pts_linears[0].weight, ref_first)
 
 
-def test_unsupported_architectures_raise():
-    with pytest.raises(NotImplementedError):
-        npa.NeRF(D=8, W=128, input_ch=63, input_ch_views=27, use_viewdirs=True)
-    with pytest.raises(NotImplementedError):
-        npa.NeRF(D=8, W=256, input_ch=63, input_ch_views=0, use_viewdirs=False)
+def test_other_architectures_build_the_layer_by_layer_module():
+    """NeRF(...) with any arguments the reference's constructor accepts: the BASELINE architecture is the fused-kernel class,
+    everything else a DenseNeRF with the reference's state_dict (names, order, shapes) and default initialisation."""
+    import copy
+    import workloads as wl
+    fused = npa.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    assert type(fused) is npa.NeRF and type(copy.deepcopy(fused)) is npa.NeRF
+    for arch in (wl.arch_of(use_viewdirs=False), wl.arch_of(D=6, W=128, multires=6, multires_views=2),
+                 wl.arch_of(D=4, W=64, multires=-1, multires_views=-1, output_ch=4), wl.arch_of(W=128)):
+        A = {k: arch[k] for k in ("D", "W", "input_ch", "input_ch_views", "output_ch", "skips", "use_viewdirs")}
+        torch.manual_seed(3)
+        net = npa.NeRF(**A)
+        assert type(net).__name__ == "DenseNeRF" and not isinstance(net, npa.NeRF)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == wl.arch_param_shapes(arch)
+        assert (net.multires, net.multires_views) == (arch["multires"], arch["multires_views"] if arch["use_viewdirs"] else -1)
+        torch.manual_seed(3)
+        assert torch.equal(net.pts_linears[0].weight, torch.nn.Linear(arch["input_ch"], arch["W"]).weight)
+        assert type(copy.deepcopy(net)).__name__ == "DenseNeRF"
+    assert type(npa.NeRF()).__name__ == "DenseNeRF"            # the reference's defaults: D=8, W=256, 3 + 3 inputs, no view directions
+    with pytest.raises(ValueError):
+        npa.NeRF(D=5, W=64, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True)       # the reference fails at its first forward
 
 
 def test_config_parser_reads_reference_style_files(tmp_path):

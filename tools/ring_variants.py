@@ -127,7 +127,7 @@ def build(name):
     for fn in VARIANTS[name]:
         fn(d)
     out = os.path.join(ROOT, "nerf-pytorch_amd", f"libexp_{name}.so")
-    cmd = [nbuild._hipcc()] + nbuild.FLAGS + [os.path.join(d, s) for s in nbuild.SOURCES] + ["-o", out]
+    cmd = [nbuild._hipcc()] + nbuild.FLAGS + [os.path.join(d, s) for s in nbuild.SOURCES] + ["-o", out] + nbuild.LIBS
     os.makedirs("/tmp/rv/include", exist_ok=True)
     shutil.copy(os.path.join(ROOT, "include", "nerf_hip.h"), "/tmp/rv/include/nerf_hip.h")
     r = subprocess.run(cmd, capture_output=True, text=True)

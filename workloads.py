@@ -59,6 +59,51 @@ def make_params(seed, dtype=torch.float32, device="cpu", gain=1.0, sigma_gain=1.
     return out
 
 
+def arch_of(D=8, W=256, multires=10, multires_views=4, use_viewdirs=True, output_ch=5, skips=(4,)):
+    """architecture dict of the reference's NeRF constructor (helpers:67-94) as create_nerf builds it (run_nerf.py:180-199):
+    multires / multires_views = -1 is i_embed = -1 (identity embedding)"""
+    ch = lambda L: 3 if L < 0 else 3 + 6 * L
+    return dict(D=D, W=W, input_ch=ch(multires), input_ch_views=ch(multires_views) if use_viewdirs else 0, output_ch=output_ch,
+                skips=list(skips), use_viewdirs=use_viewdirs, multires=multires, multires_views=multires_views)
+
+
+def arch_param_shapes(arch):
+    """state_dict of the reference NeRF for `arch`, in registration order (helpers:78-94; views_linears exists in both variants)"""
+    D, W, cx, cd = arch["D"], arch["W"], arch["input_ch"], arch["input_ch_views"]
+    shapes = []
+    for i in range(D):
+        fan_in = cx if i == 0 else (W + cx if (i - 1) in arch["skips"] else W)
+        shapes += [(f"pts_linears.{i}.weight", (W, fan_in)), (f"pts_linears.{i}.bias", (W,))]
+    shapes += [("views_linears.0.weight", (W // 2, cd + W)), ("views_linears.0.bias", (W // 2,))]
+    if arch["use_viewdirs"]:
+        shapes += [("feature_linear.weight", (W, W)), ("feature_linear.bias", (W,)), ("alpha_linear.weight", (1, W)),
+                   ("alpha_linear.bias", (1,)), ("rgb_linear.weight", (3, W // 2)), ("rgb_linear.bias", (3,))]
+    else:
+        shapes += [("output_linear.weight", (arch["output_ch"], W)), ("output_linear.bias", (arch["output_ch"],))]
+    return shapes
+
+
+def make_arch_params(arch, seed, dtype=torch.float32, sigma_gain=8.0, sigma_bias=1.0):
+    """deterministic parameters for any architecture (He-uniform; the density row scaled so that rays see structure)"""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name, shp in arch_param_shapes(arch):
+        if name.endswith("weight"):
+            a = rs.uniform(-1.0, 1.0, size=shp) * math.sqrt(6.0 / shp[1])
+            if name == "alpha_linear.weight":
+                a = a * sigma_gain
+            if name == "output_linear.weight":
+                a[3] = a[3] * sigma_gain
+        else:
+            a = rs.uniform(-0.1, 0.1, size=shp)
+            if name == "alpha_linear.bias":
+                a = a + sigma_bias
+            if name == "output_linear.bias":
+                a[3] = a[3] + sigma_bias
+        out[name] = torch.tensor(a, dtype=dtype)
+    return out
+
+
 def _damp_bands(P, n_xyz_freqs=10):
     """Scale the columns of encoding band k (sin/cos of 2^k x) by 2^-k in the two layers that read the xyz encoding:
     every band then contributes the same spatial gradient, the spectral decay a trained NeRF shows, instead of a field
