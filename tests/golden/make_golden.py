@@ -198,8 +198,65 @@ def main_round2():
     gate_case("gate_fern", run_nerf, helpers, orc.fern_batch(1024, seed=32), orc.FERN)
 
 
+def main_round3():
+    """Round-3 fixtures: architectures outside the fused kernels, produced by the REAL reference through render() -- the command
+    line's default (no --use_viewdirs: output_linear with 5 channels) and --netdepth 6 --netwidth 128 --multires 6
+    --multires_views 2 with view directions.  Stored per case: the reference's outputs for 128 lego-like rays (24 + 40 samples,
+    jitter, density noise, white background), its loss, a digest of every gradient, and per quantity the reference's own
+    fp32-vs-fp64 distance (the oracle in fp64; the oracle is pinned bit-identical to the reference for these architectures)."""
+    run_nerf, helpers = load_reference()
+    lcfg = orc.LEGO
+    for name in orc.DENSE_CASES:
+        arch, Pc, Pf, batch, target, n_c, n_f = orc.dense_case(name)
+        n = batch.shape[1]
+        A = {k: arch[k] for k in ("D", "W", "input_ch", "input_ch_views", "output_ch", "skips", "use_viewdirs")}
+        Ps = [Pc, Pf]
+        nets = []
+        for P in Ps:
+            net = helpers.NeRF(**A)
+            net.load_state_dict({k: v.clone() for k, v in P.items()})
+            nets.append(net)
+        i_embed = -1 if arch["multires"] < 0 else 0
+        e_fn, _ = helpers.get_embedder(arch["multires"], i_embed)
+        ed_fn = helpers.get_embedder(arch["multires_views"], i_embed)[0] if arch["use_viewdirs"] else None
+        qfn = lambda inputs, viewdirs, network_fn: run_nerf.run_network(inputs, viewdirs, network_fn, embed_fn=e_fn, embeddirs_fn=ed_fn,
+                                                                         netchunk=1024 * 64)
+        torch.manual_seed(55)
+        rgb, disp, acc, extras = run_nerf.render(lcfg["H"], lcfg["W"], orc.intrinsics(lcfg), chunk=1024, rays=batch, ndc=False, near=2.0,
+                                                 far=6.0, use_viewdirs=arch["use_viewdirs"], network_fn=nets[0], network_query_fn=qfn,
+                                                 N_samples=n_c, N_importance=n_f, network_fine=nets[1], perturb=1.0, white_bkgd=True,
+                                                 raw_noise_std=0.5, retraw=True)
+        loss = helpers.img2mse(rgb, target) + helpers.img2mse(extras["rgb0"], target)
+        loss.backward()
+        torch.manual_seed(55)       # the stream the reference consumed (run_nerf.py:371, :285, helpers:208, :285)
+        rnd = dict(t_rand=torch.rand(n, n_c), noise_c=torch.randn(n, n_c), u=torch.rand(n, n_f), noise_f=torch.randn(n, n_c + n_f))
+        flat = orc.assemble_render_rays(lcfg["H"], lcfg["W"], orc.intrinsics(lcfg), batch[0], batch[1], False, 2.0, 6.0)
+        rr = flat if arch["use_viewdirs"] else flat[:, :8]
+        P64 = [{k: v.double().requires_grad_(True) for k, v in P.items()} for P in Ps]
+        o64 = orc.trace_rays(rr.double(), P64[0], P64[1], n_c, n_f, perturb=1.0, white_bkgd=True, raw_noise_std=0.5, retraw=True, arch=arch,
+                             **{k: v.double() for k, v in rnd.items()})
+        (orc.mse(o64["rgb_map"], target.double()) + orc.mse(o64["rgb0"], target.double())).backward()
+        ref = dict(rgb_map=rgb, disp_map=disp, acc_map=acc, rgb0=extras["rgb0"], acc0=extras["acc0"], z_std=extras["z_std"], raw=extras["raw"])
+        save = {"rays_checksum": np.float64(checksum(batch)), "params_checksum": np.float64(sum(checksum(v) for P in Ps for v in P.values())),
+                "loss": np.float64(loss.item())}
+        for k, v in ref.items():
+            save[k] = v.detach().numpy()
+            save[k + "/noise"] = (v.detach().double() - o64[k].detach()).abs().numpy()
+        for tag, net, P in (("c", nets[0], P64[0]), ("f", nets[1], P64[1])):
+            g32 = {k: p.grad for k, p in net.state_dict(keep_vars=True).items() if p.grad is not None}
+            g64 = {k: P[k].grad for k in g32}
+            for k, v in grad_digest(g32, g64).items():
+                save[f"grad_{tag}/{k}"] = v
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **save)
+        print(f"{name}: loss {loss.item():.6f}, mean acc {float(acc.detach().mean()):.3f}, rgb noise {save['rgb_map/noise'].max():.2e} -> "
+              f"{os.path.basename(path)} ({os.path.getsize(path)} B)")
+
+
 if __name__ == "__main__":
-    if "--round2" in sys.argv:
+    if "--round3" in sys.argv:
+        main_round3()
+    elif "--round2" in sys.argv:
         main_round2()
     else:
         main()

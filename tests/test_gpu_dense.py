@@ -149,3 +149,48 @@ def test_networks_of_the_two_kinds_do_not_mix(npa, dev):
         npa.render_rays(rays, fused, None, N_samples=8, N_importance=8, network_fine=dense)
     with pytest.raises(ValueError):
         npa.NeRF(D=5, W=64, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True)       # the reference fails at its first forward
+
+
+@pytest.mark.parametrize("name", sorted(orc.DENSE_CASES))
+def test_dense_architectures_against_reference_produced_fixtures(npa, dev, name):
+    """tests/golden/dense_*.npz hold what the REAL reference computed through render() for these architectures (128 rays, 24 + 40
+    samples, jitter, density noise, white background) together with its own fp32-vs-fp64 distance per ray.  render() here, same
+    rays / weights / draws: coarse quantities per ray within 10 x that distance (floor 1e-5), fine quantities on 90 % of the rays
+    (sample_pdf amplifies rounding in empty bins, in the reference itself), loss, and every gradient tensor."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    arch, Pc, Pf, batch, target, n_c, n_f = orc.dense_case(name)
+    n = batch.shape[1]
+    nets = []
+    for P in (Pc, Pf):
+        net = npa.NeRF(**{k: arch[k] for k in CTOR}).to(dev)
+        net.load_state_dict(P)
+        nets.append(net)
+    torch.manual_seed(55)       # the stream the reference consumed
+    rnd = dict(t_rand=torch.rand(n, n_c), noise_c=torch.randn(n, n_c), u=torch.rand(n, n_f), noise_f=torch.randn(n, n_c + n_f))
+    cfg = orc.LEGO
+    rgb, disp, acc, extras = npa.render(cfg["H"], cfg["W"], orc.intrinsics(cfg), chunk=1024, rays=batch.to(dev), ndc=False, near=2.0, far=6.0,
+                                        use_viewdirs=arch["use_viewdirs"], network_fn=nets[0], network_query_fn=None, N_samples=n_c,
+                                        N_importance=n_f, network_fine=nets[1], perturb=1.0, white_bkgd=True, raw_noise_std=0.5, retraw=True,
+                                        randoms={k: v.to(dev) for k, v in rnd.items()})
+    out = dict(extras, rgb_map=rgb, disp_map=disp, acc_map=acc)
+    assert out["raw"].shape == gold["raw"].shape
+    for k in ("rgb0", "acc0"):
+        err = np.abs(out[k].detach().cpu().numpy().astype(np.float64) - gold[k])
+        assert float((err - 10 * gold[k + "/noise"]).max()) <= 1e-5, (name, k, float(err.max()))
+    for k in ("rgb_map", "acc_map", "z_std"):
+        err = np.abs(out[k].detach().cpu().numpy().astype(np.float64) - gold[k])
+        frac = float((err <= np.maximum(10 * gold[k + "/noise"], 1e-5)).mean())
+        assert frac >= 0.9, (name, k, frac, float(err.max()))
+    loss = npa.img2mse(rgb, target.to(dev)) + npa.img2mse(extras["rgb0"], target.to(dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(gold["loss"])) <= 1e-4, (name, float(loss.detach()), float(gold["loss"]))
+    for tag, net in (("c", nets[0]), ("f", nets[1])):
+        for nm, p in net.named_parameters():
+            key = f"grad_{tag}/{nm}/val"
+            if key not in gold.files:
+                assert p.grad is None, (tag, nm)
+                continue
+            got = p.grad.reshape(-1)[torch.tensor(gold[f"grad_{tag}/{nm}/idx"], device=dev)].cpu().numpy().astype(np.float64)
+            tol = max(2e-4 * float(gold[f"grad_{tag}/{nm}/max"]), 10 * float(gold[f"grad_{tag}/{nm}/noise"]))
+            assert float(np.abs(got - gold[key]).max()) <= tol, (name, tag, nm, float(np.abs(got - gold[key]).max()), tol)

@@ -131,3 +131,33 @@ def test_known_answers():
     raw = torch.full((1, 64, 4), -3.0)
     rgb, disp, acc, _, _ = orc.composite(raw, z, torch.tensor([[0., 0., -1.]]), None, True)
     assert torch.equal(rgb, torch.ones(1, 3)) and acc.item() == 0 and torch.isnan(disp).all()
+
+
+@pytest.mark.parametrize("name", sorted(orc.DENSE_CASES))
+def test_oracle_reproduces_reference_golden_of_other_architectures(name):
+    """tests/golden/dense_*.npz: the REAL reference through render() for architectures outside the fused kernels (no view
+    directions + output_linear; 6 x 128 with 6 / 2 frequencies).  The oracle's general layer stack (field_mlp_arch) must
+    reproduce them bit for bit on the CPU: outputs, loss, gradient digests."""
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    arch, Pc, Pf, batch, target, n_c, n_f = orc.dense_case(name)
+    n = batch.shape[1]
+    assert abs(float(batch.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-9
+    cfg = orc.LEGO
+    flat = orc.assemble_render_rays(cfg["H"], cfg["W"], orc.intrinsics(cfg), batch[0], batch[1], False, 2.0, 6.0)
+    rr = flat if arch["use_viewdirs"] else flat[:, :8]
+    torch.manual_seed(55)
+    rnd = dict(t_rand=torch.rand(n, n_c), noise_c=torch.randn(n, n_c), u=torch.rand(n, n_f), noise_f=torch.randn(n, n_c + n_f))
+    Pg = [{k: v.clone().requires_grad_(True) for k, v in P.items()} for P in (Pc, Pf)]
+    out = orc.trace_rays(rr, Pg[0], Pg[1], n_c, n_f, perturb=1.0, white_bkgd=True, raw_noise_std=0.5, retraw=True, arch=arch, **rnd)
+    loss = orc.mse(out["rgb_map"], target) + orc.mse(out["rgb0"], target)
+    loss.backward()
+    assert loss.item() == float(gold["loss"])
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "acc0", "z_std", "raw"):
+        assert np.array_equal(out[k].detach().numpy(), gold[k], equal_nan=True), k
+    for tag, P in (("c", Pg[0]), ("f", Pg[1])):
+        for nm, p in P.items():
+            key = f"grad_{tag}/{nm}/val"
+            if key in gold.files:
+                assert np.array_equal(p.grad.reshape(-1)[gold[f"grad_{tag}/{nm}/idx"]].numpy(), gold[key]), (tag, nm)
+            else:
+                assert p.grad is None, (tag, nm)

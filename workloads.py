@@ -104,6 +104,25 @@ def make_arch_params(arch, seed, dtype=torch.float32, sigma_gain=8.0, sigma_bias
     return out
 
 
+DENSE_CASES = {       # fixtures tests/golden/dense_*.npz: (architecture, (gain, bias) of the density row)
+    "dense_no_viewdirs": (dict(use_viewdirs=False), (8.0, -2.0)),                                 # the command line's default
+    "dense_narrow_shallow": (dict(D=6, W=128, multires=6, multires_views=2), (8.0, 1.0)),         # --netdepth 6 --netwidth 128 ...
+}
+
+
+def dense_case(name):
+    """(arch, P_coarse, P_fine, rays (2, n, 3), target, n_coarse, n_fine) of a dense-architecture fixture.  The fine network is
+    the coarse one perturbed by 0.3 % (one scene, like scene_params)."""
+    kw, (gain, bias) = DENSE_CASES[name]
+    arch = arch_of(**kw)
+    Pc = make_arch_params(arch, 41, sigma_gain=gain, sigma_bias=bias)
+    rs = np.random.RandomState(541)
+    Pf = {k: v * torch.tensor(1.0 + 3e-3 * rs.standard_normal(tuple(v.shape)), dtype=torch.float32) for k, v in Pc.items()}
+    n = 128
+    target = torch.tensor(np.random.RandomState(98).rand(n, 3), dtype=torch.float32)
+    return arch, Pc, Pf, lego_batch(n, seed=11), target, 24, 40
+
+
 def _damp_bands(P, n_xyz_freqs=10):
     """Scale the columns of encoding band k (sin/cos of 2^k x) by 2^-k in the two layers that read the xyz encoding:
     every band then contributes the same spatial gradient, the spectral decay a trained NeRF shows, instead of a field
