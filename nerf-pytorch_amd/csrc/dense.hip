@@ -123,6 +123,16 @@ __global__ void build_inputs_kernel(const float* __restrict__ rays, int ray_stri
     }
 }
 
+// the handle is shared: stream binding and the GEMM it applies to must not interleave between host threads
+std::mutex g_gemm_mutex;
+int gemm(const RocBlas& rb, hipStream_t st, int ta, int tb, int m, int n, int k, const float* A, int lda, const float* B, int ldb,
+         float beta, float* C, int ldc) {
+    std::lock_guard<std::mutex> lock(g_gemm_mutex);
+    const float one = 1.0f;
+    if (rb.set_stream(rb.h, st) != 0) return 1;
+    return rb.sgemm(rb.h, ta, tb, m, n, k, &one, A, lda, B, ldb, &beta, C, ldc);
+}
+
 int check_dims(const char* fn, long P, int a, int b) {
     if (P < 0 || a <= 0 || b <= 0 || P > 0x7fffffffL) return fail_arg(fn, "bad size (rows must fit an int, widths > 0)");
     return 0;
@@ -141,10 +151,8 @@ int nerf_dense_fwd(const float* x, int ldx, int K, const float* w, int ldw, cons
     const RocBlas& rb = rocblas();
     if (!rb.h) return fail_arg(__func__, rb.error);
     hipStream_t st = (hipStream_t)stream;
-    rb.set_stream(rb.h, st);
-    const float one = 1.0f, beta = accumulate ? 1.0f : 0.0f;
     // row-major y[P,N] = x[P,K] w[N,K]^T  ==  column-major y^T (N x P) = w (K x N, ld ldw)^T * x^T (K x P, ld ldx)
-    if (rb.sgemm(rb.h, RB_OP_T, RB_OP_N, N, (int)P, K, &one, w, ldw, x, ldx, &beta, y, ldy) != 0) return fail_arg(__func__, "rocblas_sgemm failed");
+    if (gemm(rb, st, RB_OP_T, RB_OP_N, N, (int)P, K, w, ldw, x, ldx, accumulate ? 1.0f : 0.0f, y, ldy) != 0) return fail_arg(__func__, "rocblas_sgemm failed");
     if (bias || relu) hipLaunchKernelGGL(bias_act_kernel, dim3(blocks_for(P * N)), dim3(256), 0, st, y, ldy, N, P, bias, relu);
     return done(__func__, hipGetLastError());
 }
@@ -157,10 +165,8 @@ int nerf_dense_dgrad(const float* dy, int lddy, int N, const float* w, int ldw, 
     const RocBlas& rb = rocblas();
     if (!rb.h) return fail_arg(__func__, rb.error);
     hipStream_t st = (hipStream_t)stream;
-    rb.set_stream(rb.h, st);
-    const float one = 1.0f, beta = accumulate ? 1.0f : 0.0f;
     // row-major dx[P,K] = dy[P,N] w[N,K]  ==  column-major dx^T (K x P) = w (K x N, ld ldw) * dy^T (N x P, ld lddy)
-    if (rb.sgemm(rb.h, RB_OP_N, RB_OP_N, K, (int)P, N, &one, w, ldw, dy, lddy, &beta, dx, lddx) != 0) return fail_arg(__func__, "rocblas_sgemm failed");
+    if (gemm(rb, st, RB_OP_N, RB_OP_N, K, (int)P, N, w, ldw, dy, lddy, accumulate ? 1.0f : 0.0f, dx, lddx) != 0) return fail_arg(__func__, "rocblas_sgemm failed");
     if (act) hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks_for(P * K)), dim3(256), 0, st, dx, lddx, K, P, act, ldact);
     return done(__func__, hipGetLastError());
 }
@@ -179,10 +185,8 @@ int nerf_dense_wgrad(const float* dy, int lddy, int N, const float* x, int ldx, 
     const RocBlas& rb = rocblas();
     if (!rb.h) return fail_arg(__func__, rb.error);
     hipStream_t st = (hipStream_t)stream;
-    rb.set_stream(rb.h, st);
-    const float one = 1.0f, beta = accumulate ? 1.0f : 0.0f;
     // row-major dw[N,K] = dy[P,N]^T x[P,K]  ==  column-major dw^T (K x N, ld lddw) = x^T (K x P, ld ldx) * (dy^T (N x P, ld lddy))^T
-    if (rb.sgemm(rb.h, RB_OP_N, RB_OP_T, K, N, (int)P, &one, x, ldx, dy, lddy, &beta, dw, lddw) != 0) return fail_arg(__func__, "rocblas_sgemm failed");
+    if (gemm(rb, st, RB_OP_N, RB_OP_T, K, N, (int)P, x, ldx, dy, lddy, accumulate ? 1.0f : 0.0f, dw, lddw) != 0) return fail_arg(__func__, "rocblas_sgemm failed");
     if (dbias) {
         const int nb = (int)((P + COLSUM_ROWS - 1) / COLSUM_ROWS);
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nb, (unsigned)((N + 63) / 64)), dim3(64), 0, st, dy, lddy, N, P, scratch);
