@@ -686,15 +686,22 @@ def main():
     if args.mode == "train":
         k_inf = max(5, args.steps // 2)
         el_i, _ = measure(args.precision, k_inf, 2, ses.infer_step, with_kernels=False)
-        other_infer = n * world * k_inf / el_i
         infer_chain = None
         if hb.INFER_ONE_LAUNCH and hb.render_infer_supported(N_SAMPLES, N_IMPORTANCE, args.precision):
-            hb.INFER_ONE_LAUNCH = False         # the same batches through the chain of six launches
-            try:
-                el_c, _ = measure(args.precision, k_inf, 2, ses.infer_step, with_kernels=False)
-            finally:
-                hb.INFER_ONE_LAUNCH = True
+            # the same batches through the chain of six launches, measured alternately with the one-launch kernel (the clock the
+            # chip grants drifts over a run: whichever is measured first after the training steps looks ~1 % slower)
+            el_c = None
+            for _ in range(2):
+                hb.INFER_ONE_LAUNCH = False
+                try:
+                    e, _ = measure(args.precision, k_inf, 2, ses.infer_step, with_kernels=False)
+                finally:
+                    hb.INFER_ONE_LAUNCH = True
+                el_c = e if el_c is None else min(el_c, e)
+                e, _ = measure(args.precision, k_inf, 2, ses.infer_step, with_kernels=False)
+                el_i = min(el_i, e)
             infer_chain = n * world * k_inf / el_c
+        other_infer = n * world * k_inf / el_i
     if not args.single_datapath and args.mode != "render_only":
         p2 = "bf16x3" if args.precision == "fp32" else "fp32"
         k2 = max(4, args.steps // 4)

@@ -1,5 +1,8 @@
 #!/bin/bash
 # scratch driver for the experiment of the moment (gpurun)
 mkdir -p gpurun_out
-bash tools/profile.sh bf16x3 > gpurun_out/prof_train.log 2>&1; tail -3 gpurun_out/prof_train.log
-TAG=bf16x3_render_only bash tools/profile.sh bf16x3 --mode render_only --steps 2 --warmup 1 > gpurun_out/prof_render.log 2>&1; tail -3 gpurun_out/prof_render.log
+for i in 1 2; do
+timeout 300 python bench.py --no-cpu-baseline --no-eager-baseline --single-datapath --no-configs --no-gate --steps 20 > gpurun_out/q.json 2> gpurun_out/q.err; tail -c 300 gpurun_out/q.err
+python -c "
+import json; d=json.loads([l for l in open('gpurun_out/q.json') if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['inference']['one_launch_rays_per_s'], d['inference']['chain_of_launches_rays_per_s'])"
+done
