@@ -596,6 +596,23 @@ class Session:
             self.sync.close()
 
 
+def _guarded(errors, name, fn):
+    """Run a SECONDARY measurement (a `configs` leg, a baseline): the headline has been measured by then and must be printed
+    whatever happens here; a failure is recorded in the line under `errors` instead of ending the run."""
+    try:
+        return fn()
+    except Exception as e:      # noqa: BLE001 (deliberately broad: out of memory, a missing fixture, a host without rocm tools ...)
+        errors[name] = f"{type(e).__name__}: {e}"[:400]
+        try:
+            import torch
+            import nerf_pytorch_amd as npa
+            npa.hip_backend.WORKSPACE.clear()
+            torch.cuda.empty_cache()
+        except Exception:       # noqa: BLE001
+            pass
+        return None
+
+
 def main():
     args = parse_args()
     relaunch_if_needed(args)
@@ -739,31 +756,42 @@ def main():
     legs = None
     default_run = (world == 1 and args.mode == "train" and args.config == "lego" and not args.strong and not args.no_configs
                    and args.rays == N_RAND)
+    errors = {}
     if default_run:
         legs = {}
         lego_gate = None if gate is None else {k: gate[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed") if k in gate}
-        fern = Session("fern", args, rank, world, dev, N_RAND, False)
-        el, _ = measure(args.precision, 5, 2, fern.train_step, with_kernels=False)
-        g = None if args.no_gate else fern.gate(args.precision, with_operands=False)
-        legs["fern_train"] = {"workload": "BASELINE configs[2]: fern-like 504x378, NDC rays near=0 far=1, raw_noise_std=1, N_rand=4096 x (64+128), training step",
-                              "value": N_RAND * 5 / el, "unit": "rays/s", "steps": 5, "ms_per_step": 1e3 * el / 5,
-                              "precision_gate": None if g is None else {k: g[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed")}}
-        fern.close()
-        del fern
-        el, _ = measure(args.precision, 2, 1, ses.frame_step, with_kernels=False)
-        legs["render_only"] = {"workload": f"BASELINE configs[4] on one GPU: {args.frame}x{args.frame} frames of the lego spiral, no_grad render(c2w=...), chunks of {args.chunk}",
-                               "value": args.frame * args.frame * 2 / el, "unit": "rays/s", "steps": 2, "s_per_frame": el / 2,
-                               "precision_gate": lego_gate}
-        big = Session("lego", args, rank, world, dev, N_RAND, True)
-        el, _ = measure(args.precision, 2, 1, big.train_step, with_kernels=False)
-        legs["batch_32768"] = {"workload": "the 32,768-ray global batch of BASELINE configs[3] on ONE GPU (lego 64+128, training step; rendered in 4 "
-                                           "sub-chunks of 8192 rays that all keep their saved activations: ~90 of the 288 GB)",
-                               "value": 32768 * 2 / el, "unit": "rays/s", "steps": 2, "ms_per_step": 1e3 * el / 2,
-                               "precision_gate": lego_gate}
-        big.close()
-        del big
-        hb.WORKSPACE.clear()
-        torch.cuda.empty_cache()
+
+        def leg_fern():
+            fern = Session("fern", args, rank, world, dev, N_RAND, False)
+            try:
+                el, _ = measure(args.precision, 5, 2, fern.train_step, with_kernels=False)
+                g = None if args.no_gate else fern.gate(args.precision, with_operands=False)
+            finally:
+                fern.close()
+            return {"workload": "BASELINE configs[2]: fern-like 504x378, NDC rays near=0 far=1, raw_noise_std=1, N_rand=4096 x (64+128), training step",
+                    "value": N_RAND * 5 / el, "unit": "rays/s", "steps": 5, "ms_per_step": 1e3 * el / 5,
+                    "precision_gate": None if g is None else {k: g[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed")}}
+
+        def leg_render():
+            el, _ = measure(args.precision, 2, 1, ses.frame_step, with_kernels=False)
+            return {"workload": f"BASELINE configs[4] on one GPU: {args.frame}x{args.frame} frames of the lego spiral, no_grad render(c2w=...), chunks of {args.chunk}",
+                    "value": args.frame * args.frame * 2 / el, "unit": "rays/s", "steps": 2, "s_per_frame": el / 2, "precision_gate": lego_gate}
+
+        def leg_big():
+            big = Session("lego", args, rank, world, dev, N_RAND, True)
+            try:
+                el, _ = measure(args.precision, 2, 1, big.train_step, with_kernels=False)
+            finally:
+                big.close()
+                hb.WORKSPACE.clear()
+                torch.cuda.empty_cache()
+            return {"workload": "the 32,768-ray global batch of BASELINE configs[3] on ONE GPU (lego 64+128, training step; rendered in 4 "
+                                "sub-chunks of 8192 rays that all keep their saved activations: ~90 of the 288 GB)",
+                    "value": 32768 * 2 / el, "unit": "rays/s", "steps": 2, "ms_per_step": 1e3 * el / 2, "precision_gate": lego_gate}
+        for name, fn in (("fern_train", leg_fern), ("render_only", leg_render), ("batch_32768", leg_big)):
+            res = _guarded(errors, "configs." + name, fn)
+            if res is not None:
+                legs[name] = res
 
     if rank == 0:
         cfg, H, W = ses.cfg, ses.H, ses.W
@@ -829,8 +857,10 @@ def main():
             line["mixed_precision_training"] = second_mixed
         if fp32_operands is not None:
             line["fp32_operand_storage"] = fp32_operands
+        eb = None
         if world == 1 and not args.no_eager_baseline and args.mode != "render_only":
-            eb = rocm_eager_baseline(args.config, dev, n)
+            eb = _guarded(errors, "rocm_eager_baseline", lambda: rocm_eager_baseline(args.config, dev, n))
+        if eb is not None:
             line["rocm_eager_baseline"] = eb
             ref = eb["train_rays_per_s"] if args.mode == "train" else eb["infer_rays_per_s"]
             line["speedup_vs_rocm_eager"] = {"headline": value / ref}
@@ -841,7 +871,11 @@ def main():
             if other_infer is not None:
                 line["speedup_vs_rocm_eager"]["inference"] = other_infer / eb["infer_rays_per_s"]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.config)
+            cb = _guarded(errors, "cpu_baseline", lambda: cpu_baseline(args.config))
+            if cb is not None:
+                line["cpu_baseline"] = cb
+        if errors:
+            line["errors"] = errors
         print(json.dumps(line))
     ses.close()
     if world > 1:
