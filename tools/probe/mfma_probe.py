@@ -23,3 +23,23 @@ for label, data in (("random bf16 pairs", (torch.randn(4096 * 4, device=dev).bfl
             mf = waves * units * 12
             print(f"{label:18s} {name:40s} fill {fill}: {t * 1e3:7.3f} ms  {mf * flop / t / 1e15:5.2f} PFLOP/s = {mf * flop / t / 2.5e15:5.1%} of 2.5 PF; "
                   f"{t * 2.4e9 / (mf / 1024):5.1f} clk(2.4 GHz) per MFMA per SIMD", flush=True)
+
+# ---- what a tf32-class datapath would issue: main term on bf16, both correction terms on block-scaled fp8 (K = 128 per MFMA)
+L.probe_mfma8.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+data = (torch.randn(4096 * 4, device=dev).bfloat16().view(torch.int16).to(torch.int32) & 0xffff) * 65537
+data = (data & 0x7e7e7e7e).to(torch.int32).contiguous()         # as fp8 e4m3 bytes: finite values only
+units = 260                                                     # the forward's unit count; one group = 4 k-steps x 4 units
+groups = units // 16
+for fill in (0, 1, 2):
+    def run8():
+        assert L.probe_mfma8(fill, data.data_ptr(), out.data_ptr(), blocks, groups, s) == 0
+    def run1():
+        assert L.probe_mfma(1, fill, data.data_ptr(), out.data_ptr(), blocks, groups * 16, s) == 0
+    res = {}
+    for name, fn in (("bf16 x3 (MODE 1)", run1), ("bf16 + 2 x fp8 K128", run8)):
+        for _ in range(2): fn()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(5): fn()
+        torch.cuda.synchronize(); res[name] = (time.perf_counter() - t) / 5
+    a, b = res["bf16 x3 (MODE 1)"], res["bf16 + 2 x fp8 K128"]
+    print(f"same products, fill {fill}: bf16x3 {a * 1e3:7.3f} ms   bf16 main + fp8 corrections {b * 1e3:7.3f} ms   ratio {b / a:.3f}", flush=True)
