@@ -692,7 +692,8 @@ def main():
                  "allreduce_what": "2 x 2.38 MB fp32 all-reduce (both networks' buckets), back to back, nothing else on the GPU",
                  "overlap_started": ses.sync.started,
                  "overlap_started_what": f"exchanges started under the backward over {args.warmup + args.steps + max(2, min(args.steps, 6))} "
-                                         "steps (one per step = the coarse bucket; the fine bucket is exchanged in finish())",
+                                         "steps (two per step: the coarse network's bucket while the fine network's backward still runs, the fine network's "
+                                         "the moment its backward ends; finish() waits and scales)",
                  "ranks_identical": parallel.ranks_identical([ses.net_c.flat_params(), ses.net_f.flat_params()]),
                  "rccl_ranks_seen": parallel.ranks_seen()}
     elif world > 1:
