@@ -765,12 +765,12 @@ def main():
         def leg_fern():
             fern = Session("fern", args, rank, world, dev, N_RAND, False)
             try:
-                el, _ = measure(args.precision, 5, 2, fern.train_step, with_kernels=False)
+                el, _ = measure(args.precision, 10, 3, fern.train_step, with_kernels=False)
                 g = None if args.no_gate else fern.gate(args.precision, with_operands=False)
             finally:
                 fern.close()
             return {"workload": "BASELINE configs[2]: fern-like 504x378, NDC rays near=0 far=1, raw_noise_std=1, N_rand=4096 x (64+128), training step",
-                    "value": N_RAND * 5 / el, "unit": "rays/s", "steps": 5, "ms_per_step": 1e3 * el / 5,
+                    "value": N_RAND * 10 / el, "unit": "rays/s", "steps": 10, "ms_per_step": 1e3 * el / 10,
                     "precision_gate": None if g is None else {k: g[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed")}}
 
         def leg_render():
