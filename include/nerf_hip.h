@@ -294,6 +294,14 @@ size_t nerf_dense_wgrad_scratch_floats(long P, int N);
 int nerf_dense_wgrad(const float* dy, int lddy, int N, const float* x, int ldx, int K, long P, float* dw, int lddw, float* dbias,
                      float* scratch, int accumulate, void* stream);
 
+/* ---- img2mse (run_nerf_helpers.py:11: torch.mean((x - y) ** 2), the loss of run_nerf.py:765-772) in one launch, and its
+ * gradient w.r.t. x in one more: out[0] = mean((x - y)^2) over n elements (deterministic block-ordered sum); dx = (2 g / n)(x - y)
+ * with g = grad_out[0] read on the device.  scratch: nerf_mse_scratch_floats() floats, ZERO before its first use (the kernel
+ * leaves it zeroed). */
+int nerf_mse_scratch_floats(void);
+int nerf_mse_fwd(const float* x, const float* y, long n, float* scratch, float* out, void* stream);
+int nerf_mse_bwd(const float* x, const float* y, long n, const float* grad_out, float* dx, void* stream);
+
 /* ---- optimizer.step() of run_nerf.py:776 for torch.optim.Adam(lr, betas=(beta1, beta2), eps) (run_nerf.py:207), fused over
  * a flat vector: params / grads / exp_avg / exp_avg_sq [n]; step = 1-based step count (bias correction). */
 int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,

@@ -421,6 +421,18 @@ int nerf_field_fwd_mixed(const float* packed3, const float* rays, int ray_stride
                                                   (hipStream_t)stream));
 }
 
+int nerf_mse_scratch_floats(void) { return nerf::MSE_SCRATCH_FLOATS; }
+int nerf_mse_fwd(const float* x, const float* y, long n, float* scratch, float* out, void* stream) {
+    REQUIRE(x && y && scratch && out, "null pointer");
+    REQUIRE(n > 0, "bad size");
+    return done(__func__, nerf::launch_mse_fwd(x, y, n, scratch, out, (hipStream_t)stream));
+}
+int nerf_mse_bwd(const float* x, const float* y, long n, const float* grad_out, float* dx, void* stream) {
+    REQUIRE(x && y && grad_out && dx, "null pointer");
+    REQUIRE(n > 0, "bad size");
+    return done(__func__, nerf::launch_mse_bwd(x, y, n, grad_out, dx, (hipStream_t)stream));
+}
+
 int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,
                    float beta2, float eps, int step, void* stream) {
     REQUIRE(params && grads && exp_avg && exp_avg_sq, "null pointer");

@@ -58,6 +58,9 @@ hipError_t launch_render_infer(const RenderInferArgs& a, hipStream_t stream);
 hipError_t launch_pack(const float* canon_params, float* packed, hipStream_t stream);
 hipError_t launch_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int S,
                                 int lindisp, const float* t_rand, float* z_out, hipStream_t stream);
+constexpr int MSE_SCRATCH_FLOATS = 256 + 1;      // per-block partial sums + the ticket word of mse_fwd_kernel
+hipError_t launch_mse_fwd(const float* x, const float* y, long n, float* scratch, float* out, hipStream_t stream);
+hipError_t launch_mse_bwd(const float* x, const float* y, long n, const float* g, float* dx, hipStream_t stream);
 hipError_t launch_embed(const float* x, long n_pts, int n_freqs, float* out, hipStream_t stream);
 hipError_t launch_make_rays(int H, int W, const float* K9, const float* pose12, const float* pose_static12, int ndc,
                             float near, float far, float* rays, int ray_stride, hipStream_t stream);

@@ -128,6 +128,64 @@ __global__ void make_rays_kernel(RayGenArgs a) {
 }
 
 // ------------------------------------------------------------------ launchers
+// ------------------------------------------------------------------ img2mse (run_nerf_helpers.py:11) and its gradient
+// mean((x - y)^2) over n elements in ONE launch, deterministic: every block sums its contiguous slice in a fixed tree, writes its
+// partial sum, and the block that takes the last ticket adds the partials in block order.  scratch: [MSE_BLOCKS] partial sums +
+// one ticket word (zero before the launch; the last block resets it).
+constexpr int MSE_BLOCKS = 256, MSE_THREADS = 256;
+__global__ __launch_bounds__(MSE_THREADS) void mse_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, long n,
+                                                               float* __restrict__ scratch, float* __restrict__ out) {
+    __shared__ float red[MSE_THREADS];
+    __shared__ bool last;
+    const int nb = gridDim.x;
+    const long per = (n + nb - 1) / nb, lo = blockIdx.x * per, hi = min(lo + per, n);
+    float s = 0.0f;
+    for (long i = lo + threadIdx.x; i < hi; i += MSE_THREADS) { const float d = x[i] - y[i]; s += d * d; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = MSE_THREADS / 2; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    unsigned* ticket = reinterpret_cast<unsigned*>(scratch + MSE_BLOCKS);
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = red[0];
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == (unsigned)nb - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // (agent-scope load: the partial sums were written by other CUs; read them from L2, not from this CU's vector cache)
+    red[threadIdx.x] = threadIdx.x < nb ? __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(scratch) + threadIdx.x, __ATOMIC_RELAXED,
+                                                                            __HIP_MEMORY_SCOPE_AGENT)) : 0.0f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int b = 0; b < nb; ++b) t += red[b];
+        out[0] = t / (float)n;
+        *ticket = 0u;
+    }
+}
+// d/dx mean((x - y)^2) * g = (2 g / n) (x - y); g is a device scalar (the upstream gradient of the loss)
+__global__ void mse_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, long n, const float* __restrict__ g,
+                               float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = 2.0f * g[0] / (float)n;
+    dx[i] = c * (x[i] - y[i]);
+}
+
+hipError_t launch_mse_fwd(const float* x, const float* y, long n, float* scratch, float* out, hipStream_t stream) {
+    const int nb = (int)min((long)MSE_BLOCKS, (n + 4 * MSE_THREADS - 1) / (4 * MSE_THREADS));
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(nb < 1 ? 1 : nb), dim3(MSE_THREADS), 0, stream, x, y, n, scratch, out);
+    return hipGetLastError();
+}
+hipError_t launch_mse_bwd(const float* x, const float* y, long n, const float* g, float* dx, hipStream_t stream) {
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, n, g, dx);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int S,
                                 int lindisp, const float* t_rand, float* z_out, hipStream_t stream) {
     const long n = (long)n_rays * S;

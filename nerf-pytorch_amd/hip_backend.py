@@ -69,6 +69,9 @@ def _declare(lib):
         "nerf_render_rays_fwd": (i, [p, p, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p, i, p]),
         "nerf_render_rays_bwd": (i, [p, p, p, p, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p, i, p]),
         "nerf_render_infer_supported": (i, [p]),
+        "nerf_mse_scratch_floats": (i, []),
+        "nerf_mse_fwd": (i, [p, p, l, p, p, p]),
+        "nerf_mse_bwd": (i, [p, p, l, p, p, p]),
         "nerf_build_inputs": (i, [p, i, p, i, i, i, i, i, p, i, p]),
         "nerf_dense_fwd": (i, [p, i, i, p, i, p, p, i, i, l, i, i, p]),
         "nerf_dense_dgrad": (i, [p, i, i, p, i, p, i, i, l, i, p, i, p]),
@@ -91,7 +94,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_field_dgrad_bf16x3", "nerf_field_dgrad3r_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_field_fwd16r_bf16x3", "nerf_debug_pack16_table",
            "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step",
            "nerf_render_workspace_floats", "nerf_render_rays_fwd", "nerf_render_rays_bwd", "nerf_render_infer_supported",
-           "nerf_render_rays_infer", "nerf_build_inputs", "nerf_dense_fwd", "nerf_dense_dgrad", "nerf_dense_wgrad_scratch_floats",
+           "nerf_render_rays_infer", "nerf_mse_scratch_floats", "nerf_mse_fwd", "nerf_mse_bwd", "nerf_build_inputs", "nerf_dense_fwd", "nerf_dense_dgrad", "nerf_dense_wgrad_scratch_floats",
            "nerf_dense_wgrad"]
 
 

@@ -610,3 +610,26 @@ def test_one_launch_inference_is_what_render_runs_without_gradients(npa, dev, ne
             npa.set_precision("fp32")
     assert seen[("bf16x3", False)] == {"render_infer_kernel"}, seen
     assert "render_infer_kernel" not in seen[("bf16x3", True)] and "render_infer_kernel" not in seen[("fp32", False)], seen
+
+
+# ---------------------------------------------------------------- img2mse in one launch
+@pytest.mark.parametrize("shape", [(1, 3), (4096, 3), (333, 7), (800 * 100, 3)])
+def test_img2mse_kernel_matches_the_reference_expression(npa, dev, shape):
+    """npa.img2mse on GPU tensors is one launch (+ one for the gradient): value and gradient against torch.mean((x - y) ** 2) in
+    fp64; deterministic from run to run; CPU tensors and broadcasting keep the reference's expression."""
+    g = torch.Generator().manual_seed(shape[0])
+    x = torch.rand(shape, generator=g).to(dev).requires_grad_(True)
+    y = torch.rand(shape, generator=g).to(dev)
+    up = 0.7
+    loss = npa.img2mse(x, y)
+    (loss * up).backward()
+    x64 = x.detach().double().requires_grad_(True)
+    ref = torch.mean((x64 - y.double()) ** 2)
+    (ref * up).backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-6 * float(ref.detach())
+    assert maxdiff(x.grad, x64.grad) <= 1e-6 * float(x64.grad.abs().max())
+    again = npa.img2mse(x.detach(), y)
+    assert torch.equal(again, loss.detach())
+    yb = y[:1]                                     # broadcasting: the reference's expression
+    assert torch.allclose(npa.img2mse(x.detach(), yb), torch.mean((x.detach() - yb) ** 2))
+    assert torch.allclose(npa.img2mse(x.detach().cpu(), y.cpu()), torch.mean((x.detach().cpu() - y.cpu()) ** 2))
