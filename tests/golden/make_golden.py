@@ -41,19 +41,28 @@ def grad_digest(named_grads, named_grads64):
     return out
 
 
-def oracle_fp64(rays, Pc, Pf, target, kw, rnd):
+def oracle_fp64(rays, Pc, Pf, target, kw, rnd, chunk=512):
     """The same computation in float64 (oracle == reference bit for bit in fp32, see pin_against_reference):
-    its distance from the fp32 reference is the reference's own rounding noise on these inputs."""
+    its distance from the fp32 reference is the reference's own rounding noise on these inputs.  Rays are independent and the
+    loss is a mean, so large batches run in chunks of `chunk` rays whose gradients accumulate (memory: a 4096-ray batch
+    in fp64 with autograd would hold ~50 GB)."""
     P64c = {k: v.double().requires_grad_(True) for k, v in Pc.items()}
     P64f = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
     n_f = kw["N_importance"]
-    out = orc.trace_rays(rays.double(), P64c, P64f if n_f > 0 else None, 64, n_f, perturb=kw["perturb"],
-                         lindisp=kw["lindisp"], white_bkgd=kw["white_bkgd"], raw_noise_std=kw["raw_noise_std"],
-                         retraw=True, **{k: v.double() for k, v in rnd.items()})
-    loss = orc.mse(out["rgb_map"], target.double())
-    if "rgb0" in out:
-        loss = loss + orc.mse(out["rgb0"], target.double())
-    loss.backward()
+    n = rays.shape[0]
+    pieces = {}
+    for i in range(0, n, chunk):
+        out = orc.trace_rays(rays[i:i + chunk].double(), P64c, P64f if n_f > 0 else None, 64, n_f, perturb=kw["perturb"],
+                             lindisp=kw["lindisp"], white_bkgd=kw["white_bkgd"], raw_noise_std=kw["raw_noise_std"],
+                             retraw=True, **{k: v[i:i + chunk].double() for k, v in rnd.items()})
+        t = target[i:i + chunk].double()
+        loss = ((out["rgb_map"] - t) ** 2).sum() / (n * 3)
+        if "rgb0" in out:
+            loss = loss + ((out["rgb0"] - t) ** 2).sum() / (n * 3)
+        loss.backward()
+        for k, v in out.items():
+            pieces.setdefault(k, []).append(v.detach())
+    out = {k: torch.cat(v, 0) for k, v in pieces.items()}
     return out, {k: v.grad for k, v in P64c.items() if v.grad is not None}, {k: v.grad for k, v in P64f.items() if v.grad is not None}
 
 
@@ -119,7 +128,7 @@ def run_case(name, run_nerf, helpers, rays, nets, Pc, Pf, target, **cfg):
         d = (v.double() - out64[k].detach())
         both_nan = torch.isnan(v) & torch.isnan(out64[k].detach())
         rec["noise/" + k] = np.float64(d.abs().masked_fill(both_nan, 0.0).max())
-        rec[k] = (v[:, ::8] if k == "raw" else v).numpy()
+        rec[k] = (v[::cfg.get("raw_ray_stride", 1), ::8] if k == "raw" else v).numpy()
     rec.update({"c/" + k: v for k, v in grad_digest({k: p.grad for k, p in net_c.named_parameters() if p.grad is not None}, g64c).items()})
     rec.update({"f/" + k: v for k, v in grad_digest({k: p.grad for k, p in net_f.named_parameters() if p.grad is not None}, g64f).items()})
     path = os.path.join(HERE, name + ".npz")
@@ -253,8 +262,53 @@ def main_round3():
               f"{os.path.basename(path)} ({os.path.getsize(path)} B)")
 
 
+def main_round4():
+    """Round-4 fixtures at BASELINE.json's OWN batch sizes, through the reference's render() (run_nerf.py:69-134 -> :54-66 ->
+    :308-418): configs[1] = one 4096-ray lego training step, configs[2] = one 4096-ray fern / NDC training step (outputs per
+    ray, loss, a digest of every gradient, the reference's fp32-vs-fp64 noise per quantity), and configs[3]'s 32,768-ray batch
+    as ONE chunk, forward only (maps + loss) -- the shape npa.render(chunk=32768) renders in resident sub-chunks."""
+    import time
+    run_nerf, helpers = load_reference()
+    Pc, Pf = orc.scene_params()
+    nets = (reference_networks(helpers, Pc), reference_networks(helpers, Pf))
+    n = 4096
+    target = torch.tensor(np.random.RandomState(98).rand(n, 3), dtype=torch.float32)
+    lcfg, fcfg = orc.LEGO, orc.FERN
+    t0 = time.time()
+    run_case("lego_cfg2_train", run_nerf, helpers, orc.lego_batch(n, seed=17), nets, Pc, Pf, target, seed=1234, raw_ray_stride=16,
+             render=dict(H=lcfg["H"], W=lcfg["W"], K=orc.intrinsics(lcfg), ndc=False, near=2.0, far=6.0), kw=dict(perturb=1.0))
+    print(f"  ({time.time() - t0:.0f} s)", flush=True)
+    run_case("fern_cfg3_train", run_nerf, helpers, orc.fern_batch(n, seed=13), nets, Pc, Pf, target, seed=4321, raw_ray_stride=16,
+             render=dict(H=fcfg["H"], W=fcfg["W"], K=orc.intrinsics(fcfg), ndc=True, near=0.0, far=1.0),
+             kw=dict(perturb=1.0, raw_noise_std=1.0, white_bkgd=False, N_importance=128))
+    print(f"  ({time.time() - t0:.0f} s)", flush=True)
+    # configs[3]: 32,768 rays as one chunk, forward only
+    n = 32768
+    batch = orc.lego_batch(n, seed=19)
+    target = torch.tensor(np.random.RandomState(97).rand(n, 3), dtype=torch.float32)
+    embed_fn, _ = helpers.get_embedder(10, 0)
+    embeddirs_fn, _ = helpers.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, network_fn: run_nerf.run_network(
+        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
+    torch.manual_seed(2024)
+    with torch.no_grad():
+        rgb, disp, acc, extras = run_nerf.render(800, 800, orc.intrinsics(dict(lcfg, H=800, W=800, focal=1111.0)), chunk=1024 * 32, rays=batch,
+                                                 ndc=False, near=2.0, far=6.0, use_viewdirs=True, network_fn=nets[0], network_query_fn=qfn,
+                                                 N_samples=64, N_importance=128, network_fine=nets[1], perturb=1.0, white_bkgd=True,
+                                                 raw_noise_std=0.0, lindisp=False)
+        loss = helpers.img2mse(rgb, target) + helpers.img2mse(extras["rgb0"], target)
+    rec = dict(loss=np.float64(loss.item()), rays_checksum=checksum(batch), rgb_map=rgb.numpy(), disp_map=disp.numpy(), acc_map=acc.numpy(),
+               rgb0=extras["rgb0"].numpy(), acc0=extras["acc0"].numpy(), z_std=extras["z_std"].numpy())
+    path = os.path.join(HERE, "lego_cfg4_forward.npz")
+    np.savez_compressed(path, **rec)
+    print(f"lego_cfg4_forward: {n} rays in one chunk, loss {loss.item():.6f}, mean acc {float(acc.mean()):.3f} -> {os.path.basename(path)} "
+          f"({os.path.getsize(path)} B)  ({time.time() - t0:.0f} s)")
+
+
 if __name__ == "__main__":
-    if "--round3" in sys.argv:
+    if "--round4" in sys.argv:
+        main_round4()
+    elif "--round3" in sys.argv:
         main_round3()
     elif "--round2" in sys.argv:
         main_round2()
