@@ -57,7 +57,10 @@ PEAK_HBM_GBS = 8000.0               # HBM3E spec (~6.3 TB/s achievable, MI355X_M
 DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products W_hi x_hi + W_hi x_lo + W_lo x_hi in the forward and the delta chain, f32 "
                                         "accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are stored as "
                                         "bf16 and multiplied exactly, f32 accumulate — NERF_WGRAD_OPERANDS=fp32 stores and splits fp32)",
-              "mixed": "bf16x3 forward + bf16 backward (mixed-precision training option)"}
+              "mixed": "bf16x3 forward + bf16 backward (mixed-precision training option)",
+              "fp16x3": "fp16x3 (split-fp16 MFMA products W_hi x_hi + W_hi x_lo + W_lo x_hi, hi = fp16(v), lo = fp16(v - hi): ~2^-22 per product, in the "
+                        "forward and the delta chain, f32 accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are the "
+                        "fp16 hi words (11 significant bits), multiplied exactly, f32 accumulate; deltas scaled by a power of two per launch)"}
 
 
 def parse_args(argv=None):
@@ -71,16 +74,23 @@ def parse_args(argv=None):
     ap.add_argument("--rays", type=int, default=N_RAND, help="rays per GPU per step (weak scaling)")
     ap.add_argument("--frame", type=int, default=800, help="render_only: frame side in pixels")
     ap.add_argument("--chunk", type=int, default=1024 * 32)
-    ap.add_argument("--precision", choices=["fp32", "bf16x3", "mixed"], default=os.environ.get("NERF_BENCH_PRECISION", "bf16x3"),
-                    help="headline field datapath.  bf16x3 = split-bf16 (3 bf16 MFMAs per product, fp32 accumulate, fp32 "
-                         "activations / gradients), admitted by the north-star PSNR criterion, which this run re-measures and "
-                         "prints (`precision_gate`); fp32 = exact fp32 MFMA (the parity anchor).  The other datapath is measured "
-                         "in the same run (`other_datapath`).")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "mixed", "fp16x3"], default=os.environ.get("NERF_BENCH_PRECISION", "fp16x3"),
+                    help="headline field datapath.  fp16x3 (default) = three-term split with fp16 parts (3 MFMAs per product, ~2^-22 per product, "
+                         "fp32 accumulate / activations / gradients, 11-bit operands for the weight-gradient GEMM); bf16x3 = the same with bf16 parts "
+                         "(2^-17, 8-bit operands: rounds 1-3); both admitted by the north-star PSNR criterion, which this run re-measures and "
+                         "prints (`precision_gate`); fp32 = exact fp32 MFMA (the parity anchor).  The other datapaths are measured "
+                         "in the same run (`other_datapath`, `bf16x3_datapath`).")
     ap.add_argument("--single-datapath", action="store_true", help="skip the secondary datapath measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--no-gate", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other single-GPU configurations")
+    ap.add_argument("--sustained-s", type=float, default=10.0,
+                    help="default run only: seconds of back-to-back training steps for `sustained` (rate over the whole interval and per "
+                         "second, board power and shader clock sampled meanwhile); 0 = skip")
+    ap.add_argument("--no-training-gate", action="store_true",
+                    help="skip `precision_gate.training` (default run: the converging teacher / student pair of --long, 500 Adam steps of 1024 "
+                         "rays on fp32, fp32 one ulp away and the headline datapath; ~25 s)")
     ap.add_argument("--long", action="store_true",
                     help="also fit a student to a teacher scene in every datapath (3 seeds x --long-steps Adam steps of 1024 rays, same "
                          "initialisation, batches and draws) and report the held-out PSNR per datapath as mean +- spread "
@@ -211,6 +221,93 @@ def rocm_eager_baseline(cfg_name, dev, n_rays, steps=5):
             "rate_of": "median step", "spread": spread,
             "what": f"reference algorithm as eager PyTorch-ROCm ops on this GPU (oracle ops on cuda tensors), {n_rays} rays x (64+128), "
                     f"{cfg_name} workload, torch {torch.__version__}, timed after the product legs (warm GPU)"}
+
+
+# --------------------------------------------------------------------------------------------- board power and clocks
+class PowerSampler:
+    """Board power and shader clock of GPU 0 sampled from a second thread while a leg runs ("put the roof in the
+    record").  Source: the amdgpu hwmon files when they exist (power1_average / power1_input in microwatts, freq1_input in Hz:
+    ~0.1 ms per sample), else `rocm-smi --showpower --showclocks --csv` (~40 ms per sample).  Never raises: a box without
+    either reports `source: none`."""
+
+    def __init__(self, period_s=0.05):
+        import glob
+        import threading
+        self.period, self.samples, self._stop = period_s, [], threading.Event()
+        self.cap_w, self.source = None, "none"
+        self._power = self._freq = None
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pw = [f for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))]
+            if pw:
+                self._power = os.path.join(hw, pw[0])
+                fq = os.path.join(hw, "freq1_input")
+                self._freq = fq if os.path.exists(fq) else None
+                cap = os.path.join(hw, "power1_cap")
+                try:
+                    self.cap_w = float(open(cap).read()) / 1e6
+                except Exception:       # noqa: BLE001
+                    pass
+                self.source = "hwmon"
+                break
+        if self._power is None:
+            import shutil
+            if shutil.which("rocm-smi"):
+                self.source = "rocm-smi"
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        if self.source == "hwmon":
+            try:
+                w = float(open(self._power).read()) / 1e6
+                mhz = float(open(self._freq).read()) / 1e6 if self._freq else None
+                return w, mhz
+            except Exception:           # noqa: BLE001
+                return None
+        if self.source == "rocm-smi":
+            import subprocess
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower", "--csv"], capture_output=True, text=True, timeout=5).stdout
+                rows = [r for r in out.strip().splitlines() if r.startswith("card")]
+                head = [r for r in out.strip().splitlines() if r.startswith("device")]
+                if not rows or not head:
+                    return None
+                cols, vals = head[0].split(","), rows[0].split(",")
+                rec = dict(zip(cols, vals))
+                w = next((float(v) for k, v in rec.items() if "Current Socket Graphics Package Power" in k or "Average Graphics Package Power" in k), None)
+                cap = next((float(v) for k, v in rec.items() if "Max Graphics Package Power" in k), None)
+                if cap:
+                    self.cap_w = cap
+                sclk = next((v for k, v in rec.items() if k.startswith("sclk clock speed")), None)
+                mhz = float(sclk.strip("()Mhz")) if sclk else None
+                return (w, mhz) if w is not None else None
+            except Exception:           # noqa: BLE001
+                return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            r = self._read()
+            if r is not None:
+                self.samples.append((time.perf_counter(),) + r)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=10)
+
+    def summary(self, t0=None, t1=None):
+        rows = [r for r in self.samples if (t0 is None or r[0] >= t0) and (t1 is None or r[0] <= t1)]
+        if not rows:
+            return {"source": self.source, "samples": 0}
+        w = sorted(r[1] for r in rows)
+        f = [r[2] for r in rows if r[2] is not None]
+        return {"source": self.source, "samples": len(rows), "cap_w": self.cap_w, "mean_w": sum(w) / len(w), "p95_w": w[min(len(w) - 1, int(0.95 * len(w)))],
+                "max_w": w[-1], "sclk_mhz_mean": (sum(f) / len(f)) if f else None, "sclk_mhz_min": min(f) if f else None,
+                "frac_of_cap": (sum(w) / len(w) / self.cap_w) if self.cap_w else None}
 
 
 # --------------------------------------------------------------------------------------------- per-kernel table / roofline
@@ -361,7 +458,7 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
-def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024):
+def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024, which=None):
     """Training equivalence of the datapaths, measured instead of argued: the same student (a different scene's weights)
     is fitted to a teacher scene's images with the fused Adam for `steps` steps of `n_batch` rays, once per datapath and
     seed, with identical initialisation, batch order and random draws; held-out PSNR (2048 rays, evaluated on the exact
@@ -408,8 +505,10 @@ def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024):
                                        f"nan {int(torch.isnan(out).sum())}, target [{float(tgt_held.min())}, {float(tgt_held.max())}], "
                                        f"same storage {out.data_ptr() == tgt_held.data_ptr()}")
                 return -10 * math.log10(mse)
-            for name, prec, operands in (("fp32", "fp32", None), ("fp32_twin", "fp32", None), ("bf16x3", "bf16x3", "bf16"),
+            for name, prec, operands in (("fp32", "fp32", None), ("fp32_twin", "fp32", None), ("fp16x3", "fp16x3", None), ("bf16x3", "bf16x3", "bf16"),
                                          ("bf16x3_fp32_operands", "bf16x3", "fp32"), ("mixed", "mixed", None)):
+                if which is not None and name not in which:
+                    continue
                 if operands is not None:
                     hb.WGRAD_OPERANDS = operands
                 torch.manual_seed(seed)
@@ -561,15 +660,16 @@ class Session:
             with torch.no_grad():
                 rgb_g = npa.render(self.H, self.W, self.K, chunk=self.args.chunk, rays=gbatch, **kwargs)[0]
             gate = wl.precision_gate(rgb_g, torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"]))
-            if with_operands and precision == "bf16x3" and hb.WGRAD_OPERANDS == "bf16":
+            if with_operands and ((precision == "bf16x3" and hb.WGRAD_OPERANDS == "bf16") or precision == "fp16x3"):
                 # the one place this datapath stores less than fp32: the operands of the weight-gradient GEMM (bf16, RNE).
                 # Gradient of the training loss against the fixture's target, this storage vs fp32 storage (same kernels
                 # otherwise; tests/test_gpu_parity.py test_bf16_operand_storage_* hold the 4096-ray batch to <= 3e-4)
                 tgt = torch.tensor(gold["target"]).to(dev)
 
-                def grads_with(operands):
+                def grads_with(operands, prec=precision):
                     before = hb.WGRAD_OPERANDS
                     hb.WGRAD_OPERANDS = operands
+                    npa.set_precision(prec)
                     try:
                         for m in gate_nets:
                             m.zero_grad()
@@ -578,9 +678,13 @@ class Session:
                         return torch.cat([gate_nets[0].last_flat_grad, gate_nets[1].last_flat_grad]).double()
                     finally:
                         hb.WGRAD_OPERANDS = before
-                g16, g32 = grads_with("bf16"), grads_with("fp32")
+                        npa.set_precision(precision)
+                # reference point: the split-bf16 chain with fp32 operand storage (round 3's fp32-class gradient)
+                g16, g32 = grads_with("bf16"), grads_with("fp32", "bf16x3")
                 gate["wgrad_operands"] = {
-                    "stored_as": "bf16 (forward and delta chain: 3-term split-bf16 arithmetic, unchanged)",
+                    "stored_as": ("fp16 hi words of the fp16 split (11 significant bits); compared with the split-bf16 chain storing fp32 operands, so the "
+                                  "difference also contains the two chains' own product errors (2^-22 vs 2^-17)") if precision == "fp16x3" else
+                                 "bf16 (forward and delta chain: 3-term split-bf16 arithmetic, unchanged)",
                     "gradient_rel_l2_vs_fp32_operand_storage": float((g16 - g32).norm() / g32.norm()),
                     "gradient_cosine_deficit": 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm())), "rays": 1024}
         finally:
@@ -746,18 +850,83 @@ def main():
                              "value": n * world * k4 / el4, "unit": "rays/s", "steps": k4, "ms_per_step": 1e3 * el4 / k4,
                              "kernels": _brief(kernel_table(kern4))}
     npa.set_precision(args.precision)
+    default_run = (world == 1 and args.mode == "train" and args.config == "lego" and not args.strong and not args.no_configs
+                   and args.rays == N_RAND)
+    errors = {}
+
+    # ---- the headline leg again, for seconds instead of 0.15 s, with board power and clock sampled meanwhile: the loop `value`
+    # stands for runs 200 k iterations (run_nerf.py:711), and the roof of the MFMA-bound kernels is the power cap
+    def sustained_leg(fn, seconds, rays_per_call, chunk=50):
+        hb.TIMER = None
+        for i in range(5):
+            fn(i)
+        torch.cuda.synchronize()
+        marks = []
+        with PowerSampler() as ps:
+            time.sleep(0.3)                                      # a few idle samples first
+            idle = ps.summary()
+            t0 = time.perf_counter()
+            i = 0
+            while time.perf_counter() - t0 < seconds:
+                for _ in range(chunk):
+                    fn(i)
+                    i += 1
+                torch.cuda.synchronize()
+                marks.append((time.perf_counter(), i))
+            t1 = time.perf_counter()
+            busy = ps.summary(t0 + min(1.0, 0.25 * seconds), t1)
+        per_s, last_t, last_i = [], t0, 0
+        for t, k in marks:                                       # rate per ~1 s window: the DVFS settling, if any, shows here
+            if t - last_t >= 1.0 or (t, k) == marks[-1]:
+                per_s.append(round(rays_per_call * (k - last_i) / (t - last_t)))
+                last_t, last_i = t, k
+        return {"seconds": t1 - t0, "steps": i, "rays_per_s": rays_per_call * i / (t1 - t0), "ms_per_step": 1e3 * (t1 - t0) / i,
+                "rays_per_s_by_second": per_s, "power": busy, "idle_power": idle}
+    sustained = None
+    if default_run and args.sustained_s > 0 and rank == 0:
+        def _sus():
+            out = {"train": sustained_leg(step, args.sustained_s, n), "infer": sustained_leg(ses.infer_step, max(2.0, 0.3 * args.sustained_s), n)}
+            out["what"] = ("training steps (the headline's step function) / no_grad render() calls issued back to back for the stated seconds, "
+                           "synchronised every 50 calls; power = board power and shader clock of GPU 0 sampled every 50 ms after the first second; "
+                           "cap_w = the board's power limit")
+            return out
+        sustained = _guarded(errors, "sustained", _sus)
+
+    bf16x3_leg = None
+    if not args.single_datapath and args.mode == "train" and args.precision == "fp16x3":
+        # rounds 1-3's headline datapath in the same run (bf16 parts: 2^-17 products, 8-bit weight-gradient operands)
+        def _b3():
+            kb = max(5, args.steps // 2)
+            elb, kernb = measure("bf16x3", kb, 2, step, with_kernels=True)
+            out = {"dtype": DTYPE_NAME["bf16x3"], "value": n * world * kb / elb, "unit": "rays/s", "steps": kb, "ms_per_step": 1e3 * elb / kb,
+                   "kernels": _brief(kernel_table(kernb))}
+            if not args.no_gate and rank == 0:
+                g = ses.gate("bf16x3", with_operands=False)
+                out["precision_gate"] = None if g is None else {k: g[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed")}
+            # ... and with fp32 operand storage (round 3's fp32-class-gradient leg)
+            hb.WGRAD_OPERANDS = "fp32"
+            try:
+                el4, _ = measure("bf16x3", kb, 2, step, with_kernels=False)
+            finally:
+                hb.WGRAD_OPERANDS = "bf16"
+            out["fp32_operand_storage"] = {"value": n * world * kb / el4, "ms_per_step": 1e3 * el4 / kb}
+            return out
+        bf16x3_leg = _guarded(errors, "bf16x3_datapath", _b3)
+        npa.set_precision(args.precision)
 
     gate = None
     if not args.no_gate and rank == 0:
         gate = ses.gate(args.precision)
         if args.long and gate is not None:
             gate["training"] = convergence_table(dev, args.long_steps)
+        elif default_run and gate is not None and not args.no_training_gate:
+            # the converging pair of --long (teacher 5 / student 6), 500 steps, fp32 / fp32 one ulp away / headline
+            tr = _guarded(errors, "precision_gate.training", lambda: convergence_table(dev, 500, seeds=(0,), which=("fp32", "fp32_twin", args.precision)))
+            if tr is not None:
+                gate["training"] = tr
 
     # ---- short legs of the other single-GPU configurations (BASELINE configs[2], [4] and the 32,768-ray batch of [3])
     legs = None
-    default_run = (world == 1 and args.mode == "train" and args.config == "lego" and not args.strong and not args.no_configs
-                   and args.rays == N_RAND)
-    errors = {}
     if default_run:
         legs = {}
         lego_gate = None if gate is None else {k: gate[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed") if k in gate}
@@ -858,6 +1027,12 @@ def main():
             line["mixed_precision_training"] = second_mixed
         if fp32_operands is not None:
             line["fp32_operand_storage"] = fp32_operands
+        if bf16x3_leg is not None:
+            line["bf16x3_datapath"] = bf16x3_leg
+        if sustained is not None:
+            line["sustained"] = sustained
+            line["sustained_rays_per_s"] = sustained["train"]["rays_per_s"]
+            line["power"] = sustained["train"]["power"]
         eb = None
         if world == 1 and not args.no_eager_baseline and args.mode != "render_only":
             eb = _guarded(errors, "rocm_eager_baseline", lambda: rocm_eager_baseline(args.config, dev, n))
@@ -869,6 +1044,11 @@ def main():
                 line["speedup_vs_rocm_eager"][second["dtype"]] = second["value"] / ref
             if fp32_operands is not None:
                 line["speedup_vs_rocm_eager"]["fp32_operands"] = fp32_operands["value"] / ref
+            if bf16x3_leg is not None:
+                line["speedup_vs_rocm_eager"]["bf16x3"] = bf16x3_leg["value"] / ref
+                line["speedup_vs_rocm_eager"]["bf16x3_fp32_operands"] = bf16x3_leg["fp32_operand_storage"]["value"] / ref
+            if sustained is not None:
+                line["speedup_vs_rocm_eager"]["sustained"] = sustained["train"]["rays_per_s"] / ref
             if other_infer is not None:
                 line["speedup_vs_rocm_eager"]["inference"] = other_infer / eb["infer_rays_per_s"]
         if world == 1 and not args.no_cpu_baseline:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 6
+#define NERF_ABI_VERSION 7
 #define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
 
@@ -166,6 +166,24 @@ int nerf_field_fwd16_bf16x3(const float* packed3, const float* rays, int ray_str
 int nerf_field_fwd16r_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                              int n_samples, float* raw, float* act, void* stream);
 int nerf_debug_pack16_table(int* out_host);
+/* ---- the three-term split with a selectable 16-bit type (ABI v7; csrc/split_types.h).  split = 0: bfloat16 -- exactly the
+ * entry points above (nerf_pack_params_bf16x3_sel, nerf_field_fwd16r_bf16x3, nerf_field_dgrad3r_bf16x3(delta_bf16 = 1)), bit for
+ * bit.  split = 1: IEEE half ("fp16x3"): W x = W_hi x_hi + W_hi x_lo + W_lo x_hi with hi = fp16(v), lo = fp16(v - hi) on
+ * v_mfma_f32_16x16x32_f16 / 32x32x16_f16 -- the same MFMA count, ~2^-22 per product instead of 2^-17 (fp32-class), and the rows /
+ * deltas saved for the weight-gradient GEMM carry 11 significant bits instead of 8.  The three calls of one network evaluation
+ * must use the same split (the packed buffer, the save buffer and the delta buffer hold 16-bit elements of that type;
+ * nerf_field_wgrad_phase(datapath = -1) picks the matching GEMM from the buffer records, datapath 5 = fp16 operands).
+ *   Range (split = 1): weights, encodings and activations must stay below 65520 in magnitude (a NeRF's are O(1..100)); an
+ *   overflow turns into inf / NaN in `raw`.  Deltas are tiny (upstream gradients ~1e-6): nerf_field_dgrad_split(split = 1) first
+ *   reduces max|d_raw| on the device and runs the chain on s * d_raw with s the power of two that puts that maximum in [16, 32)
+ *   (the chain is linear; s and 1/s live in the delta buffer), every stored delta and partial weight gradient carries s, and
+ *   the reduction phase of nerf_field_wgrad_phase multiplies by 1/s -- exact.  A non-finite d_raw propagates to the gradient.
+ * Replace run_nerf.py:37-51 + run_nerf_helpers.py:15-45, :96-119 and their autograd like the entry points they generalise. */
+int nerf_pack_params_split(const float* params, float* packed3, int streams, int split, void* stream);
+int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                         int n_samples, float* raw, float* act /* nullable: inference */, int split, void* stream);
+int nerf_field_dgrad_split(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
+                           float* delta, int split, void* stream);
 /* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  dgrad also leaves a tiled
  * copy of d_raw inside delta, which is what wgrad contracts with: nerf_field_wgrad_bf16x3 must be given the delta
  * buffer of nerf_field_dgrad_bf16x3 for the same d_raw (its own d_raw argument is not read).  All weight-gradient
@@ -213,7 +231,8 @@ int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_
  * Buffers the library has not written (copies, foreign producers) are not checked.
  * nerf_buffer_layout: the recorded kind, or -1 for an unknown buffer.  act: 0 fp32 point-major rows (nerf_field_fwd),
  * 1 / 2 = 32-point tiles fp32 / bf16 (nerf_field_fwd_bf16x3 / _mixed), 3 / 4 = rows in 16-point tiles fp32 / bf16
- * (nerf_field_fwd16_bf16x3, nerf_field_fwd16r_bf16x3); delta (*is_delta = 1): 0 fp32 rows, 1 / 2 = 32-point tiles fp32 / bf16. */
+ * (nerf_field_fwd16_bf16x3, nerf_field_fwd16r_bf16x3), 5 = rows in 16-point tiles of fp16 (nerf_field_fwd_split(split = 1));
+ * delta (*is_delta = 1): 0 fp32 rows, 1 / 2 / 3 = 32-point tiles fp32 / bf16 / fp16. */
 int nerf_buffer_layout(const float* buf, int* is_delta, int* n_rays, int* n_samples);
 /* nerf_field_wgrad / nerf_field_wgrad_bf16x3 split into their three launches so that a profiler can bracket each:
  * phases bit 0 = the eight full-width (256x256) jobs (datapaths 1-4: all jobs), bit 1 = the six narrow jobs (fp32 datapath
@@ -225,7 +244,8 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
                                            (32-point tiles); 3 the same, act saved by nerf_field_fwd16_bf16x3 (rows in
                                            16-point tiles); 2 bf16 operands (act from nerf_field_fwd_mixed, delta from
                                            nerf_field_dgrad_mixed or nerf_field_dgrad_bf16x3(delta_bf16 = 1)); 4 the
-                                           same, act saved by nerf_field_fwd16_bf16x3(bf16_save = 1) (16-point tiles) */,
+                                           same, act saved by nerf_field_fwd16_bf16x3(bf16_save = 1) (16-point tiles); 5 fp16
+                                           operands (nerf_field_fwd_split / nerf_field_dgrad_split with split = 1) */,
                            int phases, const float* params /* canonical parameters; may be NULL for datapath 0 */,
                            void* stream);
 /* ---- render_rays in one call (run_nerf.py:308-418 and its autograd): the whole of a ray batch's forward, and the whole of
@@ -237,7 +257,9 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
  * (depths, coarse raw, compositing weights; when training also the saved activations, deltas and partial gradients: ~23 KB
  * per sample point on the default datapath -- split larger ray batches, the reference's `chunk` argument does exactly that).
  *   precision 0: exact fp32 datapath; 1: split-bf16 (wgrad_operands_bf16 selects the storage of the weight-gradient GEMM's
- *   operands, 1 = the default of the binding); 2: mixed-precision training option.
+ *   operands, 1 = the default of the binding); 2: mixed-precision training option; 3: split-fp16 (fp16 operand storage).
+ *   Backward with accumulate = 0: every gradient vector handed in is written -- a network whose pass received no upstream
+ *   gradient gets zeros; d_disp / d_acc may be given without d_rgb.
  *   packed_f / params_f / grad_f NULL (or packed_f == packed_c): the fine pass uses the coarse network (network_fine None).
  *   Outputs as the reference's dict: rgb/disp/acc/raw = the last pass (rgb_map, disp_map, acc_map, raw [n, n_coarse + n_fine, 4]);
  *   rgb0/disp0/acc0/z_std = the coarse pass and the std of the fine samples (n_fine > 0 only).
@@ -247,7 +269,7 @@ typedef struct NerfRenderCfg {
     int n_coarse, n_fine;          /* N_samples, N_importance */
     int lindisp, white_bkgd;
     float raw_noise_std;
-    int precision;                 /* 0 fp32, 1 split-bf16, 2 mixed */
+    int precision;                 /* 0 fp32, 1 split-bf16, 2 mixed, 3 split-fp16 (packed buffers from nerf_pack_params_split(split = 1)) */
     int wgrad_operands_bf16;       /* precision 1: operands of the weight-gradient GEMM stored as bf16 (1) or fp32 (0) */
 } NerfRenderCfg;
 size_t nerf_render_workspace_floats(const NerfRenderCfg* cfg, int n_rays, int training);

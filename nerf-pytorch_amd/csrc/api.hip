@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <iterator>
 #include <mutex>
 #include <unordered_map>
 #include "nerf_common.h"
@@ -17,11 +18,18 @@ namespace nerf_api {
 static std::mutex g_tag_mutex;
 static std::unordered_map<const void*, BufTag> g_tags;
 
+static unsigned long g_tag_seq = 0;
+
 void tag_record(const void* buf, int is_delta, int kind, int n_rays, int n_samples) {
     if (!buf) return;
     std::lock_guard<std::mutex> lock(g_tag_mutex);
-    if (g_tags.size() > 4096) g_tags.clear();       // a training loop re-uses a handful of buffers; this only bounds leaks
-    g_tags[buf] = BufTag{is_delta, kind, n_rays, n_samples};
+    // a training loop re-uses a handful of buffers; the bound only limits leaks.  Eviction is by AGE (the 2048 most recently
+    // written records always survive): the record of an `act` whose backward is still pending is never dropped by a burst
+    // of unrelated writes, as a wholesale clear() would.
+    if (g_tags.size() > 4096)
+        for (auto it = g_tags.begin(); it != g_tags.end();)
+            it = (g_tag_seq - it->second.seq > 2048) ? g_tags.erase(it) : std::next(it);
+    g_tags[buf] = BufTag{is_delta, kind, n_rays, n_samples, ++g_tag_seq};
 }
 bool tag_lookup(const void* buf, BufTag* out) {
     std::lock_guard<std::mutex> lock(g_tag_mutex);
@@ -36,6 +44,7 @@ int datapath_of(int act_kind, int delta_kind) {
     if (act_kind == ACT_TILE32_BF16 && delta_kind == DELTA_TILE32_BF16) return 2;
     if (act_kind == ACT_TILE16_F32 && delta_kind == DELTA_TILE32_F32) return 3;
     if (act_kind == ACT_TILE16_BF16 && delta_kind == DELTA_TILE32_BF16) return 4;
+    if (act_kind == ACT_TILE16_F16 && delta_kind == DELTA_TILE32_F16) return 5;
     return -1;
 }
 
@@ -266,8 +275,8 @@ static int datapath_from_tags(const char* fn, const void* act, const void* delta
     if (!(ka && kd)) return -1;
     const int dp = datapath_of(ta.kind, td.kind);
     if (dp < 0) {
-        snprintf(g_err, sizeof(g_err), "%s: act layout %d (0 fp32 rows, 1/2 32-point tiles fp32/bf16, 3/4 16-point tiles fp32/bf16) cannot be "
-                 "contracted with delta kind %d (0 fp32 rows, 1/2 tiles fp32/bf16): the forward and the dgrad that wrote them belong to different datapaths",
+        snprintf(g_err, sizeof(g_err), "%s: act layout %d (0 fp32 rows, 1/2 32-point tiles fp32/bf16, 3/4/5 16-point tiles fp32/bf16/fp16) cannot be "
+                 "contracted with delta kind %d (0 fp32 rows, 1/2/3 tiles fp32/bf16/fp16): the forward and the dgrad that wrote them belong to different datapaths",
                  fn, ta.kind, td.kind);
         *rc = NERF_E_BADARG;
     }
@@ -278,7 +287,7 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
                            float* partial, float* grad, int accumulate, int datapath, int phases, const float* params,
                            void* stream) {
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && datapath >= -1 && datapath <= 4, "bad size");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && datapath >= -1 && datapath <= 5, "bad size");
     int rc;
     const int recorded = datapath_from_tags(__func__, act, delta, n_rays, n_samples, &rc);
     if (rc) return rc;
@@ -316,7 +325,19 @@ int nerf_field_dgrad3r_bf16x3(const float* packed3, const float* act, const floa
             "packed/act/d_raw/delta must be 16-byte aligned");
     if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
     tag_record(delta, 1, delta_bf16 ? DELTA_TILE32_BF16 : DELTA_TILE32_F32, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_dgrad3r(packed3, act, d_raw, n_rays, n_samples, delta, delta_bf16, (hipStream_t)stream));
+    return done(__func__, nerf::launch_field_dgrad3r(packed3, act, d_raw, n_rays, n_samples, delta, delta_bf16, 0, (hipStream_t)stream));
+}
+
+int nerf_field_dgrad_split(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
+                           float* delta, int split, void* stream) {
+    REQUIRE(packed3 && act && d_raw && delta, "null pointer");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && (split == 0 || split == 1), "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
+            "packed/act/d_raw/delta must be 16-byte aligned");
+    if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
+    tag_record(delta, 1, split ? DELTA_TILE32_F16 : DELTA_TILE32_BF16, n_rays, n_samples);
+    return done(__func__, nerf::launch_field_dgrad3r(packed3, act, d_raw, n_rays, n_samples, delta, 1, split, (hipStream_t)stream));
 }
 
 int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
@@ -382,8 +403,26 @@ int nerf_field_fwd16r_bf16x3(const float* packed3, const float* rays, int ray_st
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
     if (act) tag_record(act, 0, ACT_TILE16_BF16, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_fwd16r(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act,
+    return done(__func__, nerf::launch_field_fwd16r(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, 0,
                                                     (hipStream_t)stream));
+}
+
+int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                         int n_samples, float* raw, float* act, int split, void* stream) {
+    REQUIRE(packed3 && rays && z_vals && raw, "null pointer");
+    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && (split == 0 || split == 1), "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
+    if (act) tag_record(act, 0, split ? ACT_TILE16_F16 : ACT_TILE16_BF16, n_rays, n_samples);
+    return done(__func__, nerf::launch_field_fwd16r(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, split,
+                                                    (hipStream_t)stream));
+}
+
+int nerf_pack_params_split(const float* params, float* packed3, int streams, int split, void* stream) {
+    REQUIRE(params && packed3, "null pointer");
+    REQUIRE(streams >= 0 && streams <= 15 && (split == 0 || split == 1), "streams is a mask of bits 0..3, split 0 (bf16) or 1 (fp16)");
+    return done(__func__, nerf::launch_pack3_sel(params, packed3, streams, (hipStream_t)stream, split));
 }
 
 int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream) {

@@ -14,7 +14,7 @@
 //                        written in canonical layout and summed by
 //   wgrad_reduce_kernel (deterministic, no atomics).
 #include <type_traits>
-#include "field_device_bf16.h"
+#include "split_types.h"
 
 #include "launchers.h"
 
@@ -617,13 +617,9 @@ __device__ inline void dma_1k_s(const void* sbase, unsigned voff, unsigned lds_d
         : "v"(voff), "s"(sbase), "s"(lds_dst_uniform)
         : "memory");
 }
-__device__ inline float sum_bf16x8(u32x4 w) {
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s += __uint_as_float(w[i] << 16) + __uint_as_float(w[i] & 0xffff0000u);
-    return s;
-}
-
+// SP: element type of the stored operands (split_types.h: bf16, or fp16 = the hi words of the fp16 split -- then every delta
+// carries the launch's power-of-two scale, which wgrad_reduce_kernel removes)
+template <typename SP>
 __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm1[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -710,9 +706,9 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
             for (int i = 0; i < 4; ++i) {
                 if (i >= ni) break;
                 const u32x4 af = fragment(sa + i * 32 * 64, t, left);
-                if (want_bias) rowsum[i] += sum_bf16x8(af);
+                if (want_bias) rowsum[i] += SP::sum8(af);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af, bf[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(af, bf[j], acc[i][j]);
             }
         }
     };
@@ -734,9 +730,9 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(sa + i * 32 * 64 + frag[t]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (decltype(with_bias)::value) rowsum[i] += sum_bf16x8(af[i]);
+                if (decltype(with_bias)::value) rowsum[i] += SP::sum8(af[i]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(af[i], bf[j], acc[i][j]);
             }
         }
     };
@@ -791,14 +787,17 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
 // fold == 1 (split-bf16 / mixed, feature layer folded into the view branch, nerf_common.h): the job (delta_hv, h7) left
 //   G = delta_hv^T h7 in the slot of views_linears.0.weight[:, :256]; G and this call's dbv = sum delta_hv go to
 //   `scratch` ([128][256] | [128]) for wgrad_fold_kernel, and feature_linear.{weight,bias} / Wv[:, :256] are left to it.
+// inv_scale (nullable): device word holding 1 / s of the launch's delta scale (fp16 split, DeltaLayout3::scale): every partial
+// sum carries the factor s = 2^k, removed here exactly.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate,
-                                    int fold, float* __restrict__ scratch) {
+                                    int fold, float* __restrict__ scratch, const float* __restrict__ inv_scale) {
     constexpr Canon cn = canon();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N_PARAMS) return;
     if (fold && i >= cn.wf && i < cn.bf + W) return;                    // produced by wgrad_fold_kernel (no partials exist)
     float s = 0.0f;
     for (int cix = 0; cix < n_chunks; ++cix) s += partial[(size_t)cix * N_PARAMS + i];
+    if (inv_scale) s *= inv_scale[0];
     if (fold) {
         if (i >= cn.wv && i < cn.bv) {
             const int k = (i - cn.wv) / (W + IN_DIR), col = (i - cn.wv) % (W + IN_DIR);
@@ -910,6 +909,11 @@ __global__ void expand_dir_tiles_kernel(const float* __restrict__ dir_ray, f32x4
     dir_pt[i] = v;
 }
 // ... and with bf16 elements (mixed-precision backward): thread = (tile, feature, 8-point group)
+template <typename SP>
+__device__ inline u32x4 pack8_sp(const float* v) {
+    return u32x4{SP::cvt_pk(v[0], v[1]), SP::cvt_pk(v[2], v[3]), SP::cvt_pk(v[4], v[5]), SP::cvt_pk(v[6], v[7])};
+}
+template <typename SP>
 __global__ void expand_dir_tiles_bf16_kernel(const float* __restrict__ dir_ray, u32x4* __restrict__ dir_pt, long P, int S) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n_tiles = (P + 31) >> 5;
@@ -922,19 +926,20 @@ __global__ void expand_dir_tiles_bf16_kernel(const float* __restrict__ dir_ray, 
         const long p = min(tile * 32 + 8 * g + e, P - 1);
         v[e] = dir_ray[(p / S) * 32 + f];
     }
-    dir_pt[i] = pack8(v);
+    dir_pt[i] = pack8_sp<SP>(v);
 }
 
 // ... or, when a ray's samples fill whole 32-point tiles, ONCE per ray: [ray][feature][8 copies] bf16 -- 16 bytes per (ray,
 // feature), which is the fragment wgrad1_kernel's DMA fetches for every 8-point group of that ray (2 MB instead of 50 MB for
 // 4096 x 192 points, and no per-point kernel)
+template <typename SP>
 __global__ void replicate_dir_bf16_kernel(const float* __restrict__ dir_ray, u32x4* __restrict__ dir_rep, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // (ray, feature)
     if (i >= n) return;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = dir_ray[i];
-    dir_rep[i] = pack8(v);
+    dir_rep[i] = pack8_sp<SP>(v);
 }
 
 // phases: bit 0 = full-width jobs, bit 1 = narrow jobs, bit 2 = chunk reduction (7 = everything)
@@ -945,6 +950,9 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     // backward (bf16 operands, one MFMA per product), 3 = split-bf16 with act saved by the 16-point forward (rows in
     // 16-point tiles, nerf_common.h row16)
     // 4 = bf16 operands whose B rows were saved by the 16-point forward (16-point bf16 tiles, row16h order)
+    // 5 = the same with fp16 elements (fp16 split: deltas scaled by the launch's power of two, removed in the reduction)
+    const bool f16 = bf16x3 == 5;
+    if (f16) bf16x3 = 4;
     const bool mixed = bf16x3 == 2 || bf16x3 == 4;
     const bool x_tile16 = bf16x3 == 3 || bf16x3 == 4;
     bf16x3 = bf16x3 == 0 ? 0 : (mixed ? 2 : 1);
@@ -957,10 +965,12 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     // operand bases.  fp32 datapath: point-major rows (lda = row pitch); bf16x3: 32-point feature-major tiles
     // (lda = features per tile, a feature offset f0 is folded into the base as f0 * 32)
     const float *d_h[D], *d_feat, *d_hv, *d_rgb, *d_sigma, *x_h[D], *x_feat, *x_hv, *x_enc, *x_dir;
+    const float* inv_scale = nullptr;
     int ld_graw;
     if (bf16x3) {
         const ActLayout3 al = act_layout3((size_t)P, (size_t)n_rays);
         const DeltaLayout3 dl = delta_layout3((size_t)P);
+        if (f16) inv_scale = delta + dl.scale + 1;
         for (int l = 0; l < D; ++l) { d_h[l] = delta + dl.h[l]; x_h[l] = act + al.h[l]; }
         d_feat = delta + dl.feat; d_hv = delta + dl.hv; d_rgb = delta + dl.graw;
         // feature 3 of the 4-wide tile: 3 rows of 32 fp32 (bf16x3) or 32 bf16 (mixed, same region, 2-byte elements)
@@ -970,12 +980,16 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         ld_graw = 4;
         if (phases & 1) {   // act is written by the forward; the expanded copy is scratch inside the same buffer
             if (mixed && S % 32 == 0) {
-                hipLaunchKernelGGL(replicate_dir_bf16_kernel, dim3((unsigned)(((long)n_rays * 32 + 255) / 256)), dim3(256), 0, stream,
-                                   act + al.dir, reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt), (long)n_rays * 32);
+                const dim3 grid((unsigned)(((long)n_rays * 32 + 255) / 256));
+                u32x4* dst = reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt);
+                if (f16) hipLaunchKernelGGL(replicate_dir_bf16_kernel<SplitF16>, grid, dim3(256), 0, stream, act + al.dir, dst, (long)n_rays * 32);
+                else hipLaunchKernelGGL(replicate_dir_bf16_kernel<SplitBF16>, grid, dim3(256), 0, stream, act + al.dir, dst, (long)n_rays * 32);
             } else if (mixed) {
                 const long n_thr = ((P + 31) >> 5) * 128;
-                hipLaunchKernelGGL(expand_dir_tiles_bf16_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,
-                                   act + al.dir, reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
+                const dim3 grid((unsigned)((n_thr + 255) / 256));
+                u32x4* dst = reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt);
+                if (f16) hipLaunchKernelGGL(expand_dir_tiles_bf16_kernel<SplitF16>, grid, dim3(256), 0, stream, act + al.dir, dst, P, S);
+                else hipLaunchKernelGGL(expand_dir_tiles_bf16_kernel<SplitBF16>, grid, dim3(256), 0, stream, act + al.dir, dst, P, S);
             } else {
                 const long n_thr = ((P + 31) >> 5) * 256;
                 hipLaunchKernelGGL(expand_dir_tiles_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,
@@ -1067,7 +1081,9 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     }
     static bool attr1_set = false, attr3_set = false;
     if (mixed && !attr1_set) {
-        e = hipFuncSetAttribute((const void*)wgrad1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG1_LDS_BYTES);
+        e = hipFuncSetAttribute((const void*)wgrad1_kernel<SplitBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, WG1_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)wgrad1_kernel<SplitF16>, hipFuncAttributeMaxDynamicSharedMemorySize, WG1_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr1_set = true;
     }
@@ -1077,7 +1093,8 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         attr3_set = true;
     }
     if (big.n_jobs > 0 && mixed && (phases & 1)) {
-        hipLaunchKernelGGL(wgrad1_kernel, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
+        if (f16) hipLaunchKernelGGL(wgrad1_kernel<SplitF16>, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
+        else hipLaunchKernelGGL(wgrad1_kernel<SplitBF16>, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     } else if (big.n_jobs > 0 && bf16x3 && (phases & 1)) {
@@ -1097,7 +1114,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     if (phases & 4) {
         float* scratch = partial + wgrad_partial_floats(P) - N_DERIVED;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, stream,
-                           (const float*)partial, n_chunks, grad, accumulate, fold ? 1 : 0, scratch);
+                           (const float*)partial, n_chunks, grad, accumulate, fold ? 1 : 0, scratch, inv_scale);
         if (fold)
             hipLaunchKernelGGL(wgrad_fold_kernel, dim3((WV * W + W * W + W + 255) / 256), dim3(256), 0, stream,
                                params, (const float*)scratch, grad, accumulate);

@@ -8,7 +8,8 @@
 // store, and behind each of four units per chunk a 4 KiB DMA part (field_ring.h: unit_pipelined, WeightRingT<4>).
 // Same transposed fragment stream (P3B), same MFMA order per accumulator, same masks: every delta written is
 // BIT-IDENTICAL to field_dgrad3_kernel<MODE> (tests/test_gpu_round3.py::test_ring_dgrad_bit_identical).
-// MODE 0: fp32 deltas (operands of wgrad3_256_kernel); MODE 2: the same chain, deltas written as bf16 (wgrad1_kernel).
+// MODE 0: fp32 deltas (operands of wgrad3_256_kernel); MODE 2: the same chain, deltas written as 16-bit elements of the split's
+// type SP (split_types.h; wgrad1_kernel).  SP = SplitF16: the chain runs on s * d_raw, s a power of two per launch (delta_scale_kernel).
 // The mixed-precision chain (MODE 1) stays on field_dgrad3_kernel<1>.
 #include <type_traits>
 #include "field_ring.h"
@@ -43,9 +44,45 @@ __device__ inline void apply_mask3r(float (&d)[NV], const f32x16* acc, u32x4 m) 
     }
 }
 
-template <int MODE>
+// max|d_raw| over the launch -> the power-of-two scale of the fp16 split's chain (nerf_common.h, DeltaLayout3::scale).  Blocks
+// reduce their slice and atomicMax the bit pattern (non-negative floats order like unsigned integers: the result does not depend
+// on the order of the atomics); the last block to arrive (ticket) derives s.  Non-finite or zero maxima give s = 1.
+__global__ __launch_bounds__(256) void delta_scale_kernel(const f32x4* __restrict__ d_raw, long n4, unsigned* __restrict__ slot) {
+    float m = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = d_raw[i];
+        m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);     // (NaN: fmaxf keeps the other operand)
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float wm[4];
+    __shared__ bool last;
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        atomicMax(slot + 2, __float_as_uint(m));
+        __threadfence();
+        last = atomicAdd(slot + 3, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const unsigned bits = atomicMax(slot + 2, 0u);      // (read through the atomic path)
+        const int e = (int)((bits >> 23) & 0xffu);          // biased exponent of the maximum
+        // s = 2^(TARGET - (e - 127)); e == 0 (zero / subnormal maximum) or e == 255 (inf): no scaling
+        int k = DELTA_SCALE_TARGET_LOG2 - (e - 127);
+        if (e == 0 || e == 255) k = 0;
+        k = max(-100, min(100, k));
+        reinterpret_cast<float*>(slot)[0] = __uint_as_float((unsigned)(127 + k) << 23);
+        reinterpret_cast<float*>(slot)[1] = __uint_as_float((unsigned)(127 - k) << 23);
+    }
+}
+
+template <int MODE, typename SP>
 __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldBwdRingArgs a) {
-    static_assert(MODE == 0 || MODE == 2, "3-term chain; fp32 or bf16 deltas");
+    static_assert(MODE == 0 || MODE == 2, "3-term chain; fp32 or 16-bit deltas");
+    static_assert(!SP::F16 || MODE == 2, "the fp16 split stores fp16 deltas");
     constexpr bool OUT16 = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -64,13 +101,17 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     const DeltaLayout3 dl = delta_layout3(P);
     const size_t tile = (size_t)blockIdx.x * FIELD3_WAVES + wave;          // this wave's tile of every delta region
     const int lslot = half * 128 + (lane & 31);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);       // (d_rgb3, d_sigma)
+    f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);             // (d_rgb3, d_sigma)
+    if (SP::F16) {      // the whole chain is linear in d_raw: run it on s * d_raw (s = 2^k, exact), see DeltaLayout3::scale
+        const float sc = a.delta[dl.scale];
+        g = f32x4{g[0] * sc, g[1] * sc, g[2] * sc, g[3] * sc};
+    }
     if (valid) {        // tile-major copy of d_raw: the A operand of the rgb_linear / alpha_linear weight gradients
         const size_t goff = tile * (4 * 32) + half * 64 + (lane & 31);
         if (OUT16) {
-            __bf16* gt = reinterpret_cast<__bf16*>(a.delta + dl.graw) + goff;
-            nt_store(gt, (__bf16)(half ? g[2] : g[0]));
-            nt_store(gt + 32, (__bf16)(half ? g[3] : g[1]));
+            unsigned short* gt = reinterpret_cast<unsigned short*>(a.delta + dl.graw) + goff;
+            nt_store(gt, SP::cvt1(half ? g[2] : g[0]));
+            nt_store(gt + 32, SP::cvt1(half ? g[3] : g[1]));
         } else {
             float* gt = a.delta + dl.graw + goff;
             nt_store(gt, half ? g[2] : g[0]);
@@ -148,7 +189,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     store_region = dl.hv;
     // unit (k-step kk, group gg) writes values 8 kk + 4 gg .. + 3: as bf16 pairs they ARE words 2 gg, 2 gg + 1 of the k-step's
     // hi fragment (value 2 q, 2 q + 1 = rows r = 2 (q % 8), r + 1 of block q / 8)
-    ring_units<16, 2, 0, true, 0>(ring, fa, fb, fl, acc, dhv, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
+    ring_units<SP, 16, 2, 0, true, 0>(ring, fa, fb, fl, acc, dhv, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
         constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;            // unit 0..15: 64 values -> 4 per unit
 #pragma unroll
         for (int t = 0; t < (OUT16 ? 2 : 4); ++t) {
@@ -167,7 +208,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
         store_region = (size_t)l * pad32(P) * W;                            // dl.h[l]: delta of layer l = input of this step
-        ring_units<32, 2, 0, false, NP>(ring, fa, fb, fl, acc, d, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
+        ring_units<SP, 32, 2, 0, false, NP>(ring, fa, fb, fl, acc, d, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
             constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;        // unit 0..31: 128 values -> 4 per unit
 #pragma unroll
             for (int t = 0; t < (OUT16 ? 2 : 4); ++t) {
@@ -182,27 +223,39 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
         apply_mask3r<128>(d, acc, m);
     }
     // dl.h[0]
-    if (OUT16) store_tile3h_pair<0, 8>(reinterpret_cast<__bf16*>(a.delta + (tile_ok ? (size_t)0 : dl.feat)) + (tile_ok ? tile * (size_t)(W * 32) : (size_t)0), lane, d);
+    if (OUT16) store_tile16_pair<SP, 0, 8>(reinterpret_cast<unsigned short*>(a.delta + (tile_ok ? (size_t)0 : dl.feat)) + (tile_ok ? tile * (size_t)(W * 32) : (size_t)0), lane, d);
     else if (valid) store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);
 }
 
-hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
-                                float* delta, int bf16_out, hipStream_t stream) {
-    const long P = (long)n_rays * S;
-    if (P <= 0) return hipSuccess;
+template <int MODE, typename SP>
+static hipError_t launch_dgrad_one(const FieldBwdRingArgs& ba, unsigned blocks, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)field_dgrad3r_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3r_kernel<MODE, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    hipLaunchKernelGGL((field_dgrad3r_kernel<MODE, SP>), dim3(blocks), dim3(FIELD3_WAVES * 64), RING_LDS_FLOATS * 4, stream, ba);
+    return hipGetLastError();
+}
+
+// out16: deltas stored as 16-bit elements of the split's type (operands of wgrad1_kernel); split: 0 bf16, 1 fp16 (out16 only)
+hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
+                                float* delta, int out16, int split, hipStream_t stream) {
+    const long P = (long)n_rays * S;
+    if (P <= 0) return hipSuccess;
+    if (split && !out16) return hipErrorInvalidValue;
     FieldBwdRingArgs ba{packed3, act, d_raw, delta, n_rays, S};
     const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
-    if (bf16_out) hipLaunchKernelGGL(field_dgrad3r_kernel<2>, dim3(blocks), dim3(FIELD3_WAVES * 64), RING_LDS_FLOATS * 4, stream, ba);
-    else hipLaunchKernelGGL(field_dgrad3r_kernel<0>, dim3(blocks), dim3(FIELD3_WAVES * 64), RING_LDS_FLOATS * 4, stream, ba);
-    return hipGetLastError();
+    if (split) {
+        unsigned* slot = reinterpret_cast<unsigned*>(delta + delta_layout3((size_t)P).scale);
+        hipError_t e = hipMemsetAsync(slot, 0, 16, stream);
+        if (e != hipSuccess) return e;
+        const unsigned sb = (unsigned)min((long)512, (P + 255) / 256);
+        hipLaunchKernelGGL(delta_scale_kernel, dim3(sb), dim3(256), 0, stream, reinterpret_cast<const f32x4*>(d_raw), P, slot);
+        return launch_dgrad_one<2, SplitF16>(ba, blocks, stream);
+    }
+    return out16 ? launch_dgrad_one<2, SplitBF16>(ba, blocks, stream) : launch_dgrad_one<0, SplitBF16>(ba, blocks, stream);
 }
 
 }  // namespace nerf

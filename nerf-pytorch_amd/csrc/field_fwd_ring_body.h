@@ -1,4 +1,4 @@
-// Body of the 16-point-per-wave split-bf16 forward on the weight ring (see field_fwd_ring.hip): one workgroup tile of 128
+// Body of the 16-point-per-wave three-term-split forward (bf16 or fp16 split: split_types.h) on the weight ring (see field_fwd_ring.hip): one workgroup tile of 128
 // sample points through encode + 8x256 trunk + density head + folded view branch -> raw[.,4].  Shared by
 // field_fwd16r_kernel (one tile per workgroup) and render_infer_kernel (render_fused.hip: the tiles of 16 rays, coarse and
 // fine pass, inside one launch): same code, bit-identical results.
@@ -28,9 +28,10 @@ static_assert((FWD16_UNITS_TRUNK + FWD16_UNITS_SKIP) * UNIT_WORDS == P16F_VIEWS,
 
 // One workgroup tile (8 waves x 16 points = 128 consecutive sample points, tile index `wg`) through the whole network.
 // The workgroup must have passed a barrier since its last use of `lds` (kernel start, or the caller's own __syncthreads()).
-template <int SAVE>
+// SP: the 16-bit type of the three-term split (split_types.h) -- of the products AND of the rows saved for the backward.
+template <int SAVE, typename SP>
 __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, float* lds, long wg) {
-    static_assert(SAVE == 0 || SAVE == 2, "inference or bf16 rows");
+    static_assert(SAVE == 0 || SAVE == 2, "inference or 16-bit rows");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4;
@@ -78,7 +79,7 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int col = encslot(s, q);
-                if (col >= 0) nt_store(reinterpret_cast<__bf16*>(a.act + al.enc) + tile * (size_t)(64 * 32) + (size_t)col * 32 + pp, (__bf16)e[s]);
+                if (col >= 0) nt_store(reinterpret_cast<unsigned short*>(a.act + al.enc) + tile * (size_t)(64 * 32) + (size_t)col * 32 + pp, SP::cvt1(e[s]));
             }
         }
     }
@@ -94,7 +95,7 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     };
     constexpr int NP = SAVE ? 4 : 0;        // row stores guaranteed behind the last fetch part (one per unit, positions 3..6)
     auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
-        store_word(region, F, nb, r0, cvt_pk_bf16(v0, v1));
+        store_word(region, F, nb, r0, SP::cvt_pk(v0, v1));
     };
     auto no_store = [](auto, auto, const u32x4&) __attribute__((always_inline)) {};
     // rows of the layer in h[] leave while the next contraction consumes them: unit (k-step kk, group gg) covers
@@ -138,15 +139,15 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
 
     // ---- layer 0: 63 -> 256 (2 k-steps of the xyz encoding)
     load_bias<16>(acc, bias, q);
-    ring_units<8, 4, 0, true, 0>(ring, fa, fb, fl, acc, e, no_store);
+    ring_units<SP, 8, 4, 0, true, 0>(ring, fa, fb, fl, acc, e, no_store);
     take();
     // ---- layers 1..7 (layer 5 contracts the xyz encoding first: skip connection).  Layer l writes the rows of layer l-1.
 #pragma unroll 1
     for (int l = 1; l < D; ++l) {
         load_bias<16>(acc, bias + l * W, q);
-        if (l == SKIP + 1) ring_units<8, 4, 0, false, 0>(ring, fa, fb, fl, acc, e, no_store);
+        if (l == SKIP + 1) ring_units<SP, 8, 4, 0, false, 0>(ring, fa, fb, fl, acc, e, no_store);
         row_region = (size_t)(l - 1) * layer_floats;
-        ring_units<32, 4, 0, false, NP>(ring, fa, fb, fl, acc, h, store_rows);
+        ring_units<SP, 32, 4, 0, false, NP>(ring, fa, fb, fl, acc, h, store_rows);
         finish_mask(l - 1);
         take();
     }
@@ -190,9 +191,9 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
             store_word(row_region, W, nb, 2, bhi[2 * decltype(gg)::value + 1]);
             static_for<0, 4>([&](auto rc) __attribute__((always_inline)) { mask_bits(std::integral_constant<int, nb>{}, rc); });
         };
-        ring_units<16, 2, 0, false, NP>(ring, fa, fb, fl, av, h, store_rows_v);
+        ring_units<SP, 16, 2, 0, false, NP>(ring, fa, fb, fl, av, h, store_rows_v);
         finish_mask(D - 1);
-        ring_units<2, 2, 0, false, 0>(ring, fa, fb, fl, av, dv, no_store);
+        ring_units<SP, 2, 2, 0, false, 0>(ring, fa, fb, fl, av, dv, no_store);
     }
     float hv[32];
 #pragma unroll

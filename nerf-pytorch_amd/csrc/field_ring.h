@@ -19,7 +19,7 @@
 //     the other wave of the SIMD covers with its own MFMAs as long as the parts are short.
 #pragma once
 #include <type_traits>
-#include "field_device_bf16.h"
+#include "split_types.h"
 
 namespace nerf {
 
@@ -142,43 +142,29 @@ struct WeightRingT {
 };
 using WeightRing = WeightRingT<8>;
 
-// one (hi, lo) word pair of a B operand: values (v0, v1) -> bf16x2 hi word, bf16x2 word of the remainders (split8, one pair)
-// (the packed conversion is written as one v_cvt_pk_bf16_f32: from the C++ form hipcc derives the low half's float with a
-// second conversion of v0 alone -- one VALU operation more per pair; the values are those of split8 bit for bit)
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
-    const unsigned h = cvt_pk_bf16(v0, v1);
-    hi = h;
-    lo = cvt_pk_bf16(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
-}
+// 8 fp32 values -> (hi, lo) B fragments of the split SP (split_types.h), pair by pair
+template <typename SP>
 __device__ __forceinline__ void split8_pk(const float* v, u32x4& hi, u32x4& lo) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         unsigned h, l;
-        split_pair(v[2 * i], v[2 * i + 1], h, l);
+        SP::split_pair(v[2 * i], v[2 * i + 1], h, l);
         hi[i] = h;
         lo[i] = l;
     }
 }
 constexpr int lgkmcnt_only(int n) { return 0xC07F | (n << 8); }     // s_waitcnt immediate: lgkmcnt(n), vmcnt / expcnt not waited for
 
-__device__ __forceinline__ f32x4 mfma_acc(u32x4 a, u32x4 b, f32x4 c) { return mfma16_bf16(a, b, c); }      // 16 points / wave
-__device__ __forceinline__ f32x16 mfma_acc(u32x4 a, u32x4 b, f32x16 c) { return mfma_bf16(a, b, c); }     // 32 points / wave
-
 // ONE UNIT, instruction by instruction (sched_barrier(0) pins the order; hipcc's own schedule of the same work is
 // [8 requests][operand split][12 MFMAs], and because the two waves of a SIMD run the same stream in lockstep, a phase
 // without MFMAs is a phase in which that SIMD's matrix pipe idles -- measured on the phased kernel: removing the
 // requests / the split / the DMA gained their full issue time, the second wave covered none of it).  Every MFMA is
 // followed by at most one LDS request or a few VALU operations, which issue in its 16-cycle shadow:
-//     hi[i] * bhi   + request lo[i] of THIS unit        (used 8 MFMAs later)   [16x16x32 or 32x32x16 MFMAs: mfma_acc]
+//     hi[i] * bhi   + request lo[i] of THIS unit        (used 8 MFMAs later)   [16x16x32 or 32x32x16 MFMAs of the split SP]
 //     hi[i] * blo   + request hi[i] of the NEXT unit    (used 8 MFMAs later, in the next unit)
 //     lo[i] * bhi   + `tail(i)`: a quarter of the next k-step's operand split, the unit's row store
 // The order per accumulator (hi*hi, hi*lo, lo*hi) is the order of mma16_group: results stay bit-identical.
-template <int NB, typename Acc, typename Tail>
+template <typename SP, int NB, typename Acc, typename Tail>
 __device__ __forceinline__ void unit_pipelined(Acc (&acc)[NB], int g4, const Frag& cur, Frag& lo, Frag& nxt, const u32x4* p, const u32x4* pn,
                                                const u32x4 bhi, const u32x4 blo, Tail tail) {
     // ONE wait for the four hi fragments (requested 8 MFMAs ago; hipcc otherwise waits in front of each MFMA: 8 s_waitcnt per
@@ -186,20 +172,20 @@ __device__ __forceinline__ void unit_pipelined(Acc (&acc)[NB], int g4, const Fra
     __builtin_amdgcn_s_waitcnt(lgkmcnt_only(0));
     static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        acc[g4 + i] = mfma_acc(cur.w[i], bhi, acc[g4 + i]);
+        acc[g4 + i] = SP::mfma(cur.w[i], bhi, acc[g4 + i]);
         lo.w[i] = p[(2 * i + 1) * 64];
         __builtin_amdgcn_sched_barrier(0);
     });
     static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        acc[g4 + i] = mfma_acc(cur.w[i], blo, acc[g4 + i]);
+        acc[g4 + i] = SP::mfma(cur.w[i], blo, acc[g4 + i]);
         nxt.w[i] = pn[(2 * i) * 64];
         __builtin_amdgcn_sched_barrier(0);
     });
     __builtin_amdgcn_s_waitcnt(lgkmcnt_only(4));        // ... and one for the four lo fragments (the next unit's hi requests stay in flight)
     static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        acc[g4 + i] = mfma_acc(lo.w[i], bhi, acc[g4 + i]);
+        acc[g4 + i] = SP::mfma(lo.w[i], bhi, acc[g4 + i]);
         tail(ic);
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -208,10 +194,10 @@ __device__ __forceinline__ void unit_pipelined(Acc (&acc)[NB], int g4, const Fra
 // NU units of one contraction: G groups (units) per k-step, B operand of k-step s = v[VOFF + 8 s ..+7].  The first
 // unit is at position 0 of its chunk (every contraction starts on a chunk boundary); FIRST = the very first units of
 // the kernel (no fetch in progress at positions 0..2).  `after(k-step, group, bhi)` runs behind the 10th MFMA of each
-// unit (row stores; bhi = the hi words of the k-step in progress, which ARE the bf16 values of its rows).  NPEND: see WeightRing::barrier (the row stores of positions 3..6 follow the last part of a fetch: 4 when
+// unit (row stores; bhi = the hi words of the k-step in progress, which ARE the 16-bit values of its rows).  NPEND: see WeightRing::barrier (the row stores of positions 3..6 follow the last part of a fetch: 4 when
 // one per unit).  fa holds the hi fragments of the first unit on entry and of the unit after the last one on exit (NU is
 // even); fb is the second hi set, fl the lo set of the unit in progress.
-template <int NU, int G, int VOFF, bool FIRST, int NPEND, int NW, typename Acc, int NB, int NV, typename After>
+template <typename SP, int NU, int G, int VOFF, bool FIRST, int NPEND, int NW, typename Acc, int NB, int NV, typename After>
 __device__ __forceinline__ void ring_units(WeightRingT<NW>& ring, Frag& fa, Frag& fb, Frag& fl, Acc (&acc)[NB], const float (&v)[NV], After after) {
     static_assert(NU % 2 == 0, "fragment sets alternate");
     static_assert(G == 4 || G == 2, "units per k-step");
@@ -219,7 +205,7 @@ __device__ __forceinline__ void ring_units(WeightRingT<NW>& ring, Frag& fa, Frag
     // of k-step s (4 / G word pairs each), in the shadow of their last MFMAs
     // (two operand sets, alternating by k-step parity: no register copies when a k-step begins)
     u32x4 Bh[2], Bl[2];
-    split8_pk(&v[VOFF], Bh[0], Bl[0]);
+    split8_pk<SP>(&v[VOFF], Bh[0], Bl[0]);
     static_for<0, NU>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         constexpr int s = i / G, g = i % G, pos = i % CHUNK_UNITS;
@@ -234,12 +220,12 @@ __device__ __forceinline__ void ring_units(WeightRingT<NW>& ring, Frag& fa, Frag
         const u32x4 *p, *pn;
         ring.unit_ptrs(p, pn);
         __builtin_amdgcn_sched_barrier(0);
-        unit_pipelined(acc, 4 * g, cur, fl, nxt, p, pn, bhi, blo, [&](auto tc) __attribute__((always_inline)) {
+        unit_pipelined<SP>(acc, 4 * g, cur, fl, nxt, p, pn, bhi, blo, [&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
             if constexpr (more && ((G == 4 && t == 0) || (G == 2 && t < 2))) {
                 constexpr int j = G == 4 ? g : 2 * g + t;
                 unsigned wh, wl;
-                split_pair(v[VOFF + 8 * (s + 1) + 2 * j], v[VOFF + 8 * (s + 1) + 2 * j + 1], wh, wl);
+                SP::split_pair(v[VOFF + 8 * (s + 1) + 2 * j], v[VOFF + 8 * (s + 1) + 2 * j + 1], wh, wl);
                 asm volatile("" : "+v"(wh), "+v"(wl));      // pins the six VALU operations HERE (pure code would sink to its use)
                 nhi[j] = wh;
                 nlo[j] = wl;

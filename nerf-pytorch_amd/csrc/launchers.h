@@ -51,6 +51,7 @@ struct RenderInferArgs {
     float *z_c, *raw_c, *w_c, *rgb_c, *disp_c, *acc_c;
     // fine pass
     float *z_f, *z_std, *raw_f, *rgb_f, *disp_f, *acc_f;
+    int split;              // 16-bit type of the three-term split the packed buffers were made for: 0 bf16, 1 fp16
 };
 bool render_infer_fused_ok(int n_c, int n_f);
 hipError_t launch_render_infer(const RenderInferArgs& a, hipStream_t stream);
@@ -86,14 +87,15 @@ void pack_table_host(int* out);
 void pack3_table_host(int* out);
 void pack16_table_host(int* out);
 hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream);
-hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream);
+hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream, int split = 0);
 hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                              int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
 hipError_t launch_field_fwd16(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                               int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
+// split (ring kernels, repack, streaming weight-gradient GEMM): 0 = bf16 three-term split, 1 = fp16 (csrc/split_types.h)
 hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
-                               int n_rays, int S, float* raw, float* act, hipStream_t stream);
+                               int n_rays, int S, float* raw, float* act, int split, hipStream_t stream);
 hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
-                                float* delta, int bf16_out, hipStream_t stream);
+                                float* delta, int out16, int split, hipStream_t stream);
 
 }  // namespace nerf

@@ -301,7 +301,10 @@ __host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N) {
     a.total = o;
     return a;
 }
-struct DeltaLayout3 { size_t h[D], feat, hv, graw, total; };     // graw: tiles of 4 = copy of d_raw (rgb3, sigma)
+// graw: tiles of 4 = copy of d_raw (rgb3, sigma).  scale: 4 floats {s, 1/s, max|d_raw| bits, 0} -- the fp16 split's delta chain
+// runs on s * d_raw, s an exact power of two chosen per launch (delta_scale_kernel, field_bwd_ring.hip) so that the deltas sit in
+// fp16's range; every stored delta and every partial weight gradient carries the factor s, wgrad_reduce_kernel removes it.
+struct DeltaLayout3 { size_t h[D], feat, hv, graw, scale, total; };
 __host__ __device__ inline DeltaLayout3 delta_layout3(size_t P) {
     DeltaLayout3 a{};
     const size_t Pp = pad32(P);
@@ -311,8 +314,13 @@ __host__ __device__ inline DeltaLayout3 delta_layout3(size_t P) {
     a.hv = o;   o += Pp * WV;
     a.graw = o; o += Pp * 4;
     o += 2048;          // the weight-gradient staging reads 64 rows of 128 B from a tile of this 4-row region
+    a.scale = o; o += 4;
     a.total = o;
     return a;
 }
+// the scaled d_raw's largest magnitude: 2^DELTA_SCALE_TARGET_LOG2 <= s * max|d_raw| < 2 * that.  fp16 overflows at 2^16: a delta may
+// grow 2^11-fold along the chain before it does (measured growth on the test scenes: <= 8); hi + lo is exact to 2^-25 absolute,
+// i.e. 2^-29 of the largest upstream gradient.
+constexpr int DELTA_SCALE_TARGET_LOG2 = 4;
 
 }  // namespace nerf

@@ -5,6 +5,7 @@
 // read lane-linear fragments.  ~1.2 M elements, one launch per optimizer step.
 #include <hip/hip_runtime.h>
 #include "nerf_common.h"
+#include "split_types.h"
 
 #include "launchers.h"
 
@@ -198,6 +199,8 @@ void pack3_table_host(int* out) {
 // streams of the delta chain (P3B), bit 3 = their hi-only copy (P1B, mixed-precision chain).  The small fp32 parameters
 // are always written.  The default configuration (16-point forward + split-bf16 chain) needs bits 0 | 2: 2.3 M of the
 // 4.1 M 16-bit elements, in one launch instead of four.
+// SP (split_types.h): the 16-bit type the weights are split into -- the same buffer layout either way.
+template <typename SP>
 __global__ void pack3_all_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived, float* __restrict__ packed,
                                  int n16f, int n3f, int n3b, int n1b) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,8 +209,7 @@ __global__ void pack3_all_kernel(const float* __restrict__ canon_params, const f
         unsigned short v = 0;
         if (src >= 0) {
             const float x = param_or_derived(canon_params, derived, src);
-            const unsigned short hi = bf16_rne(x);
-            v = is_lo ? bf16_rne(x - __uint_as_float((unsigned)hi << 16)) : hi;
+            v = is_lo ? split_lo<SP>(x) : split_hi<SP>(x);
         }
         *dst = v;
     };
@@ -250,15 +252,16 @@ __global__ void pack3_all_kernel(const float* __restrict__ canon_params, const f
     }
 }
 
-hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream) {
+hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream, int split) {
     const int threads = 256;
     float* derived = packed + P3_DERIVED;
     hipLaunchKernelGGL(derive_folded_kernel, dim3((8 * N_DERIVED + threads - 1) / threads), dim3(threads), 0, stream, canon_params, derived);
     const int n16f = (streams & 1) ? 2 * P16F_WORDS : 0, n3f = (streams & 2) ? 2 * P3F_END : 0;
     const int n3b = (streams & 4) ? 2 * (P3B_END - P3F_END) : 0, n1b = (streams & 8) ? 2 * P1B_KSTEPS * KSTEP1_W8 : 0;
     const long total = (long)n16f + n3f + n3b + n1b + (PACKED_FLOATS - SM_BIAS);
-    hipLaunchKernelGGL(pack3_all_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, stream,
-                       canon_params, (const float*)derived, packed, n16f, n3f, n3b, n1b);
+    const dim3 grid((unsigned)((total + threads - 1) / threads));
+    if (split) hipLaunchKernelGGL(pack3_all_kernel<SplitF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3f, n3b, n1b);
+    else hipLaunchKernelGGL(pack3_all_kernel<SplitBF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3f, n3b, n1b);
     return hipGetLastError();
 }
 

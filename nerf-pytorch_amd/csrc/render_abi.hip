@@ -60,7 +60,7 @@ __global__ void add_inplace_kernel(float* dst, const float* src, size_t n) {
 }
 
 bool cfg_ok(const NerfRenderCfg* c) {
-    return c && c->n_coarse >= 3 && c->n_fine >= 0 && c->n_coarse + c->n_fine <= 4096 && c->precision >= 0 && c->precision <= 2 &&
+    return c && c->n_coarse >= 3 && c->n_fine >= 0 && c->n_coarse + c->n_fine <= 4096 && c->precision >= 0 && c->precision <= 3 &&
            c->raw_noise_std >= 0.0f;
 }
 
@@ -71,10 +71,14 @@ hipError_t field_forward(const NerfRenderCfg* c, const float* packed, const floa
         if (act) tag_record(act, 0, ACT_ROWS_F32, n, S);
         return nerf::launch_field_fwd(packed, rays, stride, z, n, S, raw, act, st);
     }
+    if (c->precision == 3) {        // fp16 split: 16-bit (fp16) rows always
+        if (act) tag_record(act, 0, ACT_TILE16_F16, n, S);
+        return nerf::launch_field_fwd16r(packed, rays, stride, z, n, S, raw, act, 1, st);
+    }
     const bool bf16_rows = c->precision == 2 || c->wgrad_operands_bf16;
     if (!act || bf16_rows) {
         if (act) tag_record(act, 0, ACT_TILE16_BF16, n, S);
-        return nerf::launch_field_fwd16r(packed, rays, stride, z, n, S, raw, act, st);
+        return nerf::launch_field_fwd16r(packed, rays, stride, z, n, S, raw, act, 0, st);
     }
     tag_record(act, 0, ACT_TILE16_F32, n, S);
     return nerf::launch_field_fwd16(packed, rays, stride, z, n, S, raw, act, 0, st);
@@ -84,10 +88,16 @@ hipError_t field_forward(const NerfRenderCfg* c, const float* packed, const floa
 hipError_t field_backward(const NerfRenderCfg* c, const float* packed, const float* params, const float* act, const float* d_raw, int n, int S,
                           float* delta, float* partial, float* grad, int accumulate, hipStream_t st) {
     if (c->precision == 0) return nerf::launch_field_bwd(packed, act, d_raw, n, S, delta, partial, grad, accumulate, st);
-    const bool bf16_rows = c->precision == 2 || c->wgrad_operands_bf16;
     hipError_t e;
+    if (c->precision == 3) {
+        e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, 1, 1, st);
+        if (e != hipSuccess) return e;
+        tag_record(delta, 1, DELTA_TILE32_F16, n, S);
+        return nerf::launch_field_wgrad(act, delta, d_raw, n, S, partial, grad, accumulate, 5, 7, st, params);
+    }
+    const bool bf16_rows = c->precision == 2 || c->wgrad_operands_bf16;
     if (c->precision == 2) e = nerf::launch_field_dgrad3(packed, act, d_raw, n, S, delta, 1, st);
-    else e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, bf16_rows ? 1 : 0, st);
+    else e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, bf16_rows ? 1 : 0, 0, st);
     if (e != hipSuccess) return e;
     tag_record(delta, 1, bf16_rows ? DELTA_TILE32_BF16 : DELTA_TILE32_F32, n, S);
     return nerf::launch_field_wgrad(act, delta, d_raw, n, S, partial, grad, accumulate, bf16_rows ? 4 : 3, 7, st, params);
@@ -106,7 +116,7 @@ int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const 
                          int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
                          float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
                          float* workspace, int training, void* stream) {
-    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0..2, raw_noise_std >= 0)");
+    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0..3, raw_noise_std >= 0)");
     REQUIRE(packed_c && rays && rgb && disp && acc && raw && workspace, "null pointer");
     REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
     REQUIRE(n_rays >= 0, "bad size");
@@ -162,7 +172,7 @@ int nerf_render_rays_infer(const NerfRenderCfg* cfg, const float* packed_c, cons
                            int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
                            float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
                            float* workspace, void* stream) {
-    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0..2, raw_noise_std >= 0)");
+    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0..3, raw_noise_std >= 0)");
     REQUIRE(nerf_render_infer_supported(cfg), "one-launch inference: split-bf16 / mixed datapath, 16 * n_coarse and 16 * (n_coarse + n_fine) "
             "multiples of 128, n_coarse + n_fine <= 1024 (use nerf_render_rays_fwd(training = 0) otherwise)");
     REQUIRE(packed_c && rays && rgb && disp && acc && raw && workspace, "null pointer");
@@ -188,6 +198,7 @@ int nerf_render_rays_infer(const NerfRenderCfg* cfg, const float* packed_c, cons
     a.raw_c = fine ? ws + w.raw_c : raw;
     a.rgb_c = fine ? rgb0 : rgb; a.disp_c = fine ? disp0 : disp; a.acc_c = fine ? acc0 : acc;
     a.z_f = ws + w.z_f; a.z_std = z_std; a.raw_f = raw; a.rgb_f = rgb; a.disp_f = disp; a.acc_f = acc;
+    a.split = cfg->precision == 3 ? 1 : 0;
     return done(__func__, nerf::launch_render_infer(a, (hipStream_t)stream));
 }
 
@@ -216,7 +227,11 @@ int nerf_render_rays_bwd(const NerfRenderCfg* cfg, const float* packed_c, const 
         float* d_raw = ws + w.d_raw;
         const size_t n4 = (size_t)n_rays * S * 4;
         if (g_rgb || g_disp || g_acc) {
-            if (!g_rgb) return hipErrorInvalidValue;      // (d_disp / d_acc without d_rgb: pass zeros for d_rgb)
+            if (!g_rgb) {       // d_disp / d_acc without d_rgb: a zero d_rgb (the partial-sum region is free until field_backward)
+                hipError_t err = hipMemsetAsync(ws + w.partial, 0, (size_t)n_rays * 3 * sizeof(float), st);
+                if (err != hipSuccess) return err;
+                g_rgb = ws + w.partial;
+            }
             nerf::CompositeArgs a{raw_p, z, rays + 3, cfg->raw_noise_std > 0.0f ? noise : nullptr, cfg->raw_noise_std, ray_stride, n_rays, S,
                                   cfg->white_bkgd, nullptr, nullptr, nullptr, nullptr, nullptr, g_rgb, g_acc, g_disp, d_raw, nullptr, nullptr};
             hipError_t err = nerf::launch_composite(a, true, st);
@@ -234,15 +249,23 @@ int nerf_render_rays_bwd(const NerfRenderCfg* cfg, const float* packed_c, const 
     };
     bool wrote_c = false;
     if (fine) {
-        if (d_rgb0 || d_disp0 || d_acc0) {
+        const bool up_c = d_rgb0 || d_disp0 || d_acc0, up_f = d_rgb || d_disp || d_acc || d_raw_out;
+        REQUIRE(up_c || up_f, "no upstream gradient");
+        if (up_c) {
             e = pass(packed_c, params_c, ws + w.act_c, ws + w.raw_c, ws + w.z_c, noise_c, Sc, d_rgb0, d_disp0, d_acc0, nullptr, grad_c, accumulate);
             if (e != hipSuccess) return done(__func__, e);
             wrote_c = true;
         }
-        if (d_rgb || d_disp || d_acc || d_raw_out) {
+        if (up_f) {
             e = pass(same_net ? packed_c : packed_f, same_net ? params_c : params_f, ws + w.act_f, raw, ws + w.z_f, noise_f, S2, d_rgb, d_disp,
                      d_acc, d_raw_out, same_net ? grad_c : grad_f, same_net ? (accumulate || wrote_c) : accumulate);
             if (e != hipSuccess) return done(__func__, e);
+        }
+        // accumulate == 0 promises that every gradient vector is WRITTEN: a network whose pass has no upstream gradient gets zeros
+        if (!accumulate) {
+            const size_t gbytes = (size_t)nerf::N_PARAMS * sizeof(float);
+            if (!up_c && !same_net) { e = hipMemsetAsync(grad_c, 0, gbytes, st); if (e != hipSuccess) return done(__func__, e); }
+            if (!up_f && !same_net) { e = hipMemsetAsync(grad_f, 0, gbytes, st); if (e != hipSuccess) return done(__func__, e); }
         }
         return 0;
     }

@@ -26,7 +26,7 @@ namespace nerf {
 // workgroup is wavefront k mod 8's in the per-ray phases
 constexpr int FUSED_SCRATCH_FLOATS = 2048;  // LDS floats per wavefront in the per-ray phases (the weight ring is idle then)
 
-template <int FUSED_RAYS>
+template <int FUSED_RAYS, typename SP>
 __global__ __launch_bounds__(FIELD_WAVES * 64) void render_infer_kernel(RenderInferArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void render_infer_kernel(RenderIn
         const FieldFwdRingArgs fa{second ? a.packed_f : a.packed_c, a.rays, second ? a.z_f : a.z_c, second ? a.raw_f : a.raw_c,
                                   nullptr, a.ray_stride, a.n_rays, second ? S2 : Sc};
         const long wg = second ? (long)blockIdx.x * tiles_f + (t - tiles_c) : (long)blockIdx.x * tiles_c + t;
-        field_fwd16r_tile<0>(fa, lds, wg);
+        field_fwd16r_tile<0, SP>(fa, lds, wg);
     }
     // ---- 5. colours of the last pass
     __syncthreads();
@@ -103,34 +103,40 @@ bool render_infer_fused_ok(int n_c, int n_f) {
            2 * S2 <= FUSED_SCRATCH_FLOATS && 3 * n_c + np2 <= FUSED_SCRATCH_FLOATS;
 }
 
-hipError_t launch_render_infer(const RenderInferArgs& a, hipStream_t stream) {
-    if (a.n_rays <= 0) return hipSuccess;
+template <int R, typename SP>
+static hipError_t launch_infer_one(const RenderInferArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)render_infer_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)render_infer_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)render_infer_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)render_infer_kernel<R, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    const dim3 grid((unsigned)((a.n_rays + R - 1) / R)), block(FIELD_WAVES * 64);
+    hipLaunchKernelGGL((render_infer_kernel<R, SP>), grid, block, RING_LDS_FLOATS * 4, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_infer(const RenderInferArgs& a, hipStream_t stream) {
+    if (a.n_rays <= 0) return hipSuccess;
     // rays per workgroup: the fewest (4, 8, 16) that fill whole 128-point tiles in both passes -- more, shorter workgroups
     // fill the last round of 256 better and drift apart, so that one workgroup's per-ray phase meets another's network tiles
     const int S2 = a.n_c + a.n_f;
-    auto tiles = [&](int R) { return (R * a.n_c) % PTS_PER_WG == 0 && (R * S2) % PTS_PER_WG == 0; };
+    auto tiles = [&](int R) { return (R == 4 || R == 8 || R == 16) && (R * a.n_c) % PTS_PER_WG == 0 && (R * S2) % PTS_PER_WG == 0; };
     static const char* force = getenv("NERF_FUSED_RAYS");
     int R = tiles(4) ? 4 : tiles(8) ? 8 : 16;
     if (R == 4 && tiles(8)) {       // 8 per workgroup when that fills its last round of 256 workgroups to 95 % (measured: 4096 and
         const long wg8 = (a.n_rays + 7) / 8;        // 32768 rays 0.3-0.7 % faster with 8; 1024 and 5000 rays 13-60 % faster with 4)
         if ((double)wg8 >= 0.95 * (double)(((wg8 + 255) / 256) * 256)) R = 8;
     }
-    if (force && tiles(atoi(force))) R = atoi(force);
-    const dim3 grid((unsigned)((a.n_rays + R - 1) / R)), block(FIELD_WAVES * 64);
-    if (R == 4) hipLaunchKernelGGL(render_infer_kernel<4>, grid, block, RING_LDS_FLOATS * 4, stream, a);
-    else if (R == 8) hipLaunchKernelGGL(render_infer_kernel<8>, grid, block, RING_LDS_FLOATS * 4, stream, a);
-    else hipLaunchKernelGGL(render_infer_kernel<16>, grid, block, RING_LDS_FLOATS * 4, stream, a);
-    return hipGetLastError();
+    if (force && tiles(atoi(force))) R = atoi(force);       // (only 4, 8, 16; anything else is ignored)
+    if (a.split) {
+        if (R == 4) return launch_infer_one<4, SplitF16>(a, stream);
+        if (R == 8) return launch_infer_one<8, SplitF16>(a, stream);
+        return launch_infer_one<16, SplitF16>(a, stream);
+    }
+    if (R == 4) return launch_infer_one<4, SplitBF16>(a, stream);
+    if (R == 8) return launch_infer_one<8, SplitBF16>(a, stream);
+    return launch_infer_one<16, SplitBF16>(a, stream);
 }
 
 }  // namespace nerf

@@ -15,7 +15,7 @@ from . import build as _build
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
-ABI_VERSION = 6        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
+ABI_VERSION = 7        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
 
 
 class NerfHipError(RuntimeError):
@@ -61,6 +61,9 @@ def _declare(lib):
         "nerf_field_fwd_mixed": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_field_fwd16_bf16x3": (i, [p, p, i, p, i, i, p, p, i, p]),
         "nerf_field_fwd16r_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
+        "nerf_pack_params_split": (i, [p, p, i, i, p]),
+        "nerf_field_fwd_split": (i, [p, p, i, p, i, i, p, p, i, p]),
+        "nerf_field_dgrad_split": (i, [p, p, p, i, i, p, i, p]),
         "nerf_debug_pack16_table": (i, [p]),
         "nerf_field_dgrad_mixed": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p, p]),
@@ -92,6 +95,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_pack_params_bf16x3_sel", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
            "nerf_field_dgrad_bf16x3", "nerf_field_dgrad3r_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_field_fwd16r_bf16x3", "nerf_debug_pack16_table",
+           "nerf_pack_params_split", "nerf_field_fwd_split", "nerf_field_dgrad_split",
            "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step",
            "nerf_render_workspace_floats", "nerf_render_rays_fwd", "nerf_render_rays_bwd", "nerf_render_infer_supported",
            "nerf_render_rays_infer", "nerf_mse_scratch_floats", "nerf_mse_fwd", "nerf_mse_bwd", "nerf_build_inputs", "nerf_dense_fwd", "nerf_dense_dgrad", "nerf_dense_wgrad_scratch_floats",
@@ -227,7 +231,10 @@ def pack_table():
 
 # "mixed" = the bf16x3 forward (identical outputs) with a bf16 backward: saved activations / deltas rounded to bf16,
 # one bf16 MFMA per product in dgrad and wgrad (fp32 accumulation).  A training-speed option, not a parity datapath.
-PRECISIONS = ("fp32", "bf16x3", "mixed")
+# "fp16x3" (round 4) = the same three-term split with IEEE-half parts (csrc/split_types.h): ~2^-22 per product instead of 2^-17
+# and 11-bit instead of 8-bit operands for the weight-gradient GEMM, at the bf16 MFMA count; needs |activations| < 65520.
+PRECISIONS = ("fp32", "bf16x3", "mixed", "fp16x3")
+SPLIT = ("bf16x3", "mixed", "fp16x3")       # datapaths on the three-term-split kernels (folded feature layer, tiled saves)
 
 
 def pack_table3():
@@ -269,7 +276,8 @@ if WGRAD_OPERANDS not in ("bf16", "fp32"):
 
 
 def _bf16_operands(precision):
-    return precision == "mixed" or (precision == "bf16x3" and WGRAD_OPERANDS == "bf16")
+    """the weight-gradient GEMM's operands are stored as 16-bit elements (bf16; fp16 on the fp16 split, always)"""
+    return precision in ("mixed", "fp16x3") or (precision == "bf16x3" and WGRAD_OPERANDS == "bf16")
 
 
 # the bf16x3 / mixed forward runs the 16-point-per-wave kernel (2 waves / SIMD); "0" selects the 32-point kernel
@@ -292,6 +300,11 @@ def _small_offset():
 
 def pack_params(flat, out=None, precision="fp32"):
     L = lib()
+    if precision == "fp16x3":       # fp16 (hi, lo) fragments: the 16-point forward stream and the transposed streams of the delta chain
+        if out is None:
+            out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
+        _check(L.nerf_pack_params_split(_ptr(flat, "params"), _ptr(out, "packed"), 1 | 4, 1, _stream()), "nerf_pack_params_split")
+        return out
     if precision in ("bf16x3", "mixed"):
         if out is None:
             out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
@@ -423,7 +436,7 @@ class NerfRenderCfg(ctypes.Structure):
                 ("raw_noise_std", ctypes.c_float), ("precision", ctypes.c_int), ("wgrad_operands_bf16", ctypes.c_int)]
 
 
-ACT_LAYOUTS = {0: "fp32 rows", 1: "tile32 fp32", 2: "tile32 bf16", 3: "tile16 fp32", 4: "tile16 bf16"}
+ACT_LAYOUTS = {0: "fp32 rows", 1: "tile32 fp32", 2: "tile32 bf16", 3: "tile16 fp32", 4: "tile16 bf16", 5: "tile16 fp16"}
 
 
 def buffer_layout(buf):
@@ -453,12 +466,13 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
     16-point tiles with the row16 row order (tile16=True; default: what field_fwd recorded on the buffer).  bf16=True:
     2-byte elements (mixed; bf16x3 with WGRAD_OPERANDS == "bf16"; default: what field_fwd recorded) in 32-point tiles,
     or — rows saved by the 16-point forward, tile16=True — in 16-point tiles with the row16h row order."""
-    tiled = precision in ("bf16x3", "mixed")
-    kind = buffer_layout(buf)[0] if buf.is_cuda else -1
+    tiled = precision in SPLIT
+    kind, is_delta = buffer_layout(buf)[:2] if buf.is_cuda else (-1, False)
+    f16 = precision == "fp16x3"         # 16-bit elements are IEEE halves
     if tile16 is None:
-        tile16 = kind in (3, 4)
+        tile16 = kind in (3, 4, 5) and not is_delta
     if bf16 is None:
-        bf16 = precision == "mixed" or kind in (2, 4)
+        bf16 = precision in ("mixed", "fp16x3") or kind in (2, 4)
     Pa = (P + 31) // 32 * 32 if tiled else P
     widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
     off = 0
@@ -468,7 +482,7 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
             if not tiled:
                 return flat.view(P, F)
             if bf16:                        # 2-byte elements in the first half of the region
-                flat = flat.view(torch.bfloat16)[:Pa * F].float()
+                flat = flat.view(torch.float16 if f16 else torch.bfloat16)[:Pa * F].float()
             if tile16 and F in (256, 128):
                 rows = flat.view(Pa // 16, F, 16).permute(0, 2, 1).reshape(Pa, F)[:P]      # [P, row]
                 if bf16:
@@ -487,7 +501,7 @@ INFER_ONE_LAUNCH = os.environ.get("NERF_INFER_ONE_LAUNCH", "1") != "0"
 
 def render_cfg(n_coarse, n_fine, lindisp, white_bkgd, raw_noise_std, precision):
     return NerfRenderCfg(int(n_coarse), int(n_fine), int(bool(lindisp)), int(bool(white_bkgd)), float(raw_noise_std),
-                         {"fp32": 0, "bf16x3": 1, "mixed": 2}[precision], int(WGRAD_OPERANDS == "bf16"))
+                         {"fp32": 0, "bf16x3": 1, "mixed": 2, "fp16x3": 3}[precision], int(WGRAD_OPERANDS == "bf16"))
 
 
 def render_infer_supported(n_coarse, n_fine, precision):
@@ -533,8 +547,14 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     act = WORKSPACE.take(act_floats(n, S), rays.device) if save_act else None
     b16 = _bf16_operands(precision)
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
-    if precision in ("bf16x3", "mixed"):
+    if precision in SPLIT:
         nbytes = BYTES_ACT3_PER_POINT * n * S if save_act else 16.0 * n * S
+    if precision == "fp16x3":
+        with _timed("field_fwd16r_kernel<fp16" + (", save>" if save_act else ">"), FLOP_FWD3_PER_POINT * n * S,
+                    BYTES_ACT3_BF16_PER_POINT * n * S if save_act else nbytes):
+            _check(lib().nerf_field_fwd_split(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                              n, S, _ptr(raw), _ptr(act, "act", True), 1, _stream()), "nerf_field_fwd_split")
+        return raw, act
     if precision in ("bf16x3", "mixed") and FWD_16PT:
         bf16_save = int(b16)
         ring = FWD_RING and (bf16_save or not save_act)
@@ -637,13 +657,21 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32", params=Non
 def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S, params):
     b3 = precision == "bf16x3"
     mx = precision == "mixed"
+    h3 = precision == "fp16x3"
     # what the forward wrote into `act` (the library's own record, nerf_buffer_layout): bf16 rows => bf16 deltas + the bf16
     # streaming GEMM; the weight-gradient call below passes datapath = -1 ("as recorded"), and a mismatched pairing is
     # refused by the library (NERF_E_BADARG)
     kind = buffer_layout(act)[0]
+    if precision in SPLIT and kind == -1:
+        raise NerfHipError("field_bwd: `act` is not a save buffer this library's forward wrote (no layout record): the split "
+                           "datapaths cannot guess its tiling and element type")
     b16 = b3 and kind in (2, 4)        # bf16x3 chain, bf16-stored GEMM operands (WGRAD_OPERANDS)
     P = n * S
-    if mx:
+    if h3:
+        with _timed("field_dgrad3r_kernel<fp16>", FLOP_DGRAD3_PER_POINT * P, BYTES_DELTA3_BF16_PER_POINT * P):
+            _check(L.nerf_field_dgrad_split(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta), 1, _stream()),
+                   "nerf_field_dgrad_split")
+    elif mx:
         with _timed("field_dgrad3_kernel<mixed>", FLOP_DGRAD3_PER_POINT * P, BYTES_DELTA3_BF16_PER_POINT * P):
             _check(L.nerf_field_dgrad_mixed(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
                                             _ptr(delta), _stream()), "nerf_field_dgrad_mixed")
@@ -658,7 +686,7 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
         with _timed("field_dgrad_kernel", FLOP_DGRAD_PER_POINT * P, BYTES_DELTA_PER_POINT * P):
             _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
                                       _stream()), "nerf_field_dgrad")
-    bf16_gemm = mx or b16
+    bf16_gemm = mx or b16 or h3
     datapath = -1
     args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),
             int(bool(accumulate)), datapath)
@@ -667,7 +695,7 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
         _check(L.nerf_field_wgrad_phase(*args, 7, *tail), "nerf_field_wgrad_phase")
         return grad
     if bf16_gemm:   # all 13 jobs stream bf16 operands straight into the MFMA
-        with _timed("wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD_MIXED_PER_POINT * P):
+        with _timed("wgrad1_kernel<fp16>" if h3 else "wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD_MIXED_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
     elif b3:    # all 12 jobs (full-width and narrow) run through the masked bf16x3 tile kernel
         with _timed("wgrad3_256_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD3_PER_POINT * P):

@@ -1,0 +1,209 @@
+"""GPU tests (-m gpu) of the fp16 three-term split ("fp16x3", round 4; csrc/split_types.h): the same kernels as bf16x3 with
+IEEE-half (hi, lo) parts -- ~2^-22 per product, 11-bit operands for the weight-gradient GEMM, deltas scaled by a power of two
+per launch.  The six reference-produced goldens, the PSNR gates, ragged batches, the one-call ABI, the one-launch inference and
+the train()-shaped loop run on this datapath through the parametrised tests of test_gpu_parity.py / test_gpu_round3.py /
+test_gpu_fuzz.py / test_train_loop_gpu.py; here are the bounds that are specific to it."""
+import numpy as np
+import pytest
+import torch
+
+import nerf_oracle as orc
+from test_gpu_parity import npa, dev, nets, maxdiff, _flat_grads_through_render      # noqa: F401  (fixtures)
+from test_gpu_round3 import _decode_masks, _field_with_forced_relu, GOLDEN_CASES, _golden_grads
+
+pytestmark = pytest.mark.gpu
+
+
+def _f16_split(x):
+    """hi = fp16(x), lo = fp16(x - hi) on the host (numpy, round to nearest even): csrc/split_types.h SplitF16"""
+    x = np.asarray(x, dtype=np.float32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def test_fp16_repack_is_the_host_split_of_every_weight(npa, dev, nets):
+    """nerf_pack_params_split(split = 1): every 16-bit element of the 16-point forward stream is the fp16 hi / lo part of the
+    parameter (or of the folded W' = Wv[:, :256] Wf) the gather table names -- the same table as the bf16 repack."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    L = hb.lib()
+    flat = nf.flat_params()
+    packed = hb.pack_params(flat, precision="fp16x3").cpu()
+    tab = hb.pack_table16()
+    off16 = 2 * (L.nerf_packed3_floats() - hb.N_DERIVED - hb.P16F_WORDS)          # P16F region, in 16-bit elements
+    got = packed.view(torch.int16).numpy().view(np.uint16)[off16:off16 + 2 * hb.P16F_WORDS]
+    derived = packed[-hb.N_DERIVED:].numpy()
+    src = np.concatenate([flat.detach().cpu().numpy(), derived])
+    idx, is_lo = tab >> 1, (tab & 1).astype(bool)
+    hi, lo = _f16_split(src[np.maximum(idx, 0)])
+    want = np.where(is_lo, lo.view(np.uint16), hi.view(np.uint16))
+    want[tab < 0] = 0
+    assert np.array_equal(got, want), int((got != want).sum())
+    # the folded layer itself: W' in fp64 from the canonical parameters, rounded once
+    Wv = Pf["views_linears.0.weight"].double()[:, :256]
+    Wp = (Wv @ Pf["feature_linear.weight"].double()).float().reshape(-1).numpy()
+    assert np.abs(derived[:128 * 256] - Wp).max() <= 1e-6 * max(1.0, np.abs(Wp).max())
+
+
+@pytest.mark.parametrize("n_rays,S", [(64, 64), (37, 192), (5, 3), (1, 1)])
+def test_field_forward_fp16x3(npa, dev, nets, n_rays, S):
+    """raw vs the fp64 oracle: fp32-class (bound 2e-5 of |raw|max: 15 x tighter than bf16x3's 3e-4); inference and the saving
+    forward are the same kernel (bit-identical raw); what is saved for the backward are the fp16 roundings of the activations."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    rays = orc.synthetic_rays(n_rays, seed=S)
+    z = torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0]
+    P = n_rays * S
+    packed = nf.packed_params("fp16x3")
+    raw, _ = hb.field_fwd(packed, rays.to(dev), z.to(dev), save_act=False, precision="fp16x3")
+    raw2, act = hb.field_fwd(packed, rays.to(dev), z.to(dev), save_act=True, precision="fp16x3")
+    assert torch.equal(raw, raw2)
+    assert hb.buffer_layout(act)[0] == 5
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None])
+    P64 = {k: v.double() for k, v in Pf.items()}
+    ref64 = orc.query_field(P64, pts.double(), rays[:, 8:11].double())
+    ref32 = orc.query_field(Pf, pts, rays[:, 8:11])
+    scale = max(1.0, float(ref64.abs().max()))
+    err, noise = maxdiff(raw, ref64), maxdiff(ref32, ref64)
+    print(f"fp16x3 raw vs fp64: {err:.2e} (reference fp32 vs fp64: {noise:.2e}), |raw|max {scale:.1f}")
+    assert err <= 2e-5 * scale, (err, noise, scale)
+    feats = torch.cat([orc.posenc(pts.reshape(-1, 3).double(), 10), orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3).double(), 4)], -1)
+    _, hidden, _, hv = orc.field_mlp(P64, feats, return_hidden=True)
+    for l in (0, 3, 7):
+        got = hb.saved_rows(act, P, f"h{l}", precision="fp16x3").cpu().double()
+        tol = 2.0 ** -11 * float(hidden[l].abs().max()) + 2e-5
+        assert maxdiff(got, hidden[l]) <= tol, (l, maxdiff(got, hidden[l]), tol)
+    got = hb.saved_rows(act, P, "hv", precision="fp16x3").cpu().double()
+    assert maxdiff(got, hv) <= 2.0 ** -11 * float(hv.abs().max()) + 2e-5
+    got = hb.saved_rows(act, P, "enc", precision="fp16x3").cpu().double()[:, :63]
+    assert maxdiff(got, feats[:, :63]) <= 2.0 ** -11 * float(feats[:, :63].abs().max()) + 1e-6
+    hb.WORKSPACE.give(act)
+
+
+@pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192), (70, 20), (3, 5)])
+def test_field_backward_fp16x3_arithmetic_and_flips(npa, dev, nets, n_rays, S):
+    """The round-3 separation of arithmetic error from ReLU-kink flips (test_gpu_round3.py), on the fp16 split with its 16-bit
+    operand storage: gradient vs fp64 autograd of the reference network evaluated with the kernel's OWN ReLU pattern, under a
+    RANDOM upstream gradient -- the worst case for the zero-mean 2^-12 rounding of the stored operands (incoherent sums do not
+    average it down relative to the result): <= 1e-3 of max|g| for every 256-wide tensor (measured <= 8.6e-4; bf16 storage:
+    5.4e-3, bound 8e-3), <= 2e-3 for the two heads' few-entry tensors (rgb_linear: 387 entries, measured 1.4e-3), and <= 5e-4
+    relative L2 per tensor.  Units on the other side of their kink only within 2e-5 of the layer's scale, and rare."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    g = torch.Generator().manual_seed(7 * n_rays + S)
+    rays = orc.synthetic_rays(n_rays, seed=S + 1)
+    z = torch.sort(torch.rand(n_rays, S, generator=g) * 4.0 + 2.0, -1)[0]
+    d_raw = torch.randn(n_rays, S, 4, generator=g) * 3e-6          # the size of a training loss's upstream gradient
+    P = n_rays * S
+    packed = nf.packed_params("fp16x3")
+    raw, act = hb.field_fwd(packed, rays.to(dev), z.to(dev), save_act=True, precision="fp16x3")
+    masks = _decode_masks(npa, act, P, n_rays)
+    grad = torch.full((595844,), float("nan"), device=dev)
+    hb.field_bwd(packed, act, d_raw.to(dev), grad, accumulate=False, precision="fp16x3", params=nf.flat_params())
+    hb.WORKSPACE.give(act)
+    grad = grad.cpu().double()
+    assert not torch.isnan(grad).any()
+    P64 = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3).double()
+    dirs = rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3).double()
+    feats = torch.cat([orc.posenc(pts, 10), orc.posenc(dirs, 4)], -1)
+    out, pres = _field_with_forced_relu(P64, feats, masks)
+    (out * d_raw.reshape(-1, 4).double()).sum().backward()
+    worst, rel2 = {}, {}
+    for nm, off, shape in hb.param_table():
+        gg = grad[off:off + int(np.prod(shape))].view(shape)
+        r = P64[nm].grad
+        worst[nm] = maxdiff(gg, r) / max(float(r.abs().max()), 1e-30)
+        rel2[nm] = float((gg - r).norm() / r.norm().clamp_min(1e-300))
+    n_units = flips = 0
+    worst_pre = 0.0
+    for pre, m in zip(pres, masks):
+        diff = (pre.detach() > 0) != m
+        n_units += diff.numel()
+        flips += int(diff.sum())
+        if diff.any():
+            worst_pre = max(worst_pre, float(pre.detach().abs()[diff].max()) / max(1.0, float(pre.detach().abs().max())))
+    print(f"fp16x3 backward vs fp64 with the kernel's own ReLU pattern: max|err|/max|g| {max(worst.values()):.1e} "
+          f"({max(worst, key=worst.get)}), worst relative L2 of a weight tensor {max(v for k, v in rel2.items() if not k.endswith('bias')):.1e}; units on the other side of their kink: {flips} of {n_units}, largest |pre| among them {worst_pre:.1e}")
+    small = ("rgb_linear.weight", "rgb_linear.bias", "alpha_linear.weight", "alpha_linear.bias")
+    assert max(v for k, v in worst.items() if k not in small) <= 1e-3, worst
+    assert max(worst.values()) <= 2e-3, worst
+    assert max(v for k, v in rel2.items() if not k.endswith("bias")) <= 5e-4, rel2
+    assert worst_pre <= 2e-5, worst_pre
+    assert flips <= 2e-4 * n_units, (flips, n_units)
+
+
+def test_delta_scale_makes_the_backward_exactly_homogeneous(npa, dev, nets):
+    """The chain runs on s * d_raw with s = 2^k chosen from max|d_raw| (delta_scale_kernel), and the reduction multiplies by 2^-k:
+    gradients of 2^j * d_raw are EXACTLY 2^j times the gradients of d_raw, for upstream gradients from 1e-12 to 1e+6; an all-zero
+    upstream gradient gives exact zeros (no 0 * inf)."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    n_rays, S = 33, 64
+    g = torch.Generator().manual_seed(3)
+    rays = orc.synthetic_rays(n_rays, seed=5).to(dev)
+    z = torch.sort(torch.rand(n_rays, S, generator=g) * 4.0 + 2.0, -1)[0].to(dev)
+    d_raw = (torch.randn(n_rays, S, 4, generator=g) * torch.exp(torch.randn(n_rays, S, 1, generator=g) * 3)).to(dev)
+    packed = nf.packed_params("fp16x3")
+    _, act = hb.field_fwd(packed, rays, z, save_act=True, precision="fp16x3")
+    grads = {}
+    for j in (0, -40, 20, -3):
+        grad = torch.full((595844,), float("nan"), device=dev)
+        hb.field_bwd(packed, act, (d_raw * 2.0 ** j).contiguous(), grad, accumulate=False, precision="fp16x3", params=nf.flat_params())
+        grads[j] = grad.clone()
+        assert bool(torch.isfinite(grad).all()) and float(grad.abs().max()) > 0
+    for j in (-40, 20, -3):
+        assert torch.equal(grads[j], grads[0] * 2.0 ** j), j
+    grad = torch.full((595844,), float("nan"), device=dev)
+    hb.field_bwd(packed, act, torch.zeros_like(d_raw), grad, accumulate=False, precision="fp16x3", params=nf.flat_params())
+    assert bool((grad == 0).all())
+    hb.WORKSPACE.give(act)
+
+
+def test_fp16_operand_storage_full_batch(npa, dev, monkeypatch):
+    """BASELINE configs[1] batch (4096 rays x (64+128)): the gradient of the training loss on the fp16 split (fp16 operand storage)
+    against the split-bf16 datapath with fp32 operand storage -- round 3's fp32-class gradient.  The difference contains the
+    fp16 operand rounding (2^-12, zero-mean, averaged over 262 k / 786 k points) AND the two chains' own product errors (2^-22 vs
+    2^-17); bf16 storage measured 9.3e-5 here."""
+    g16 = _flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch, precision="fp16x3")
+    g32 = _flat_grads_through_render(npa, dev, 4096, "fp32", monkeypatch)
+    gb16 = _flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch)
+    rel = float((g16 - g32).norm() / g32.norm())
+    rel_b = float((gb16 - g32).norm() / g32.norm())
+    cosdef = 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    print(f"4096 rays: fp16x3 vs bf16x3 with fp32 operand storage: relative L2 {rel:.2e}, cosine deficit {cosdef:.1e}  (bf16 storage: {rel_b:.2e})")
+    assert rel <= 2e-5 and cosdef <= 1e-9, (rel, cosdef)
+    assert rel < rel_b / 3
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_fp16_operand_storage_on_every_golden_configuration(npa, dev, nets, case, monkeypatch):
+    """The same comparison on the six golden configurations (256 rays: 16 k / 49 k points per contraction, where bf16 storage is
+    held to 1.5e-3): fp16x3 vs the split-bf16 chain with fp32 operand storage, relative L2 of the whole gradient <= 2e-4."""
+    name, kw, seed, through = GOLDEN_CASES[case]
+    render = {None: None, "fern": (orc.FERN, orc.fern_batch(256, seed=3)), "lego": (orc.LEGO, orc.lego_batch(256, seed=7))}[through]
+    g32 = _golden_grads(npa, dev, nets, kw, seed, "fp32", monkeypatch, render)
+    g16 = _golden_grads(npa, dev, nets, kw, seed, "bf16", monkeypatch, render, precision="fp16x3")
+    rel = float((g16 - g32).norm() / g32.norm())
+    cosdef = 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    print(f"{name}: fp16x3 vs bf16x3 / fp32 operand storage: relative L2 {rel:.2e}, cosine deficit {cosdef:.1e}")
+    assert rel <= 2e-4 and cosdef <= 5e-8, (name, rel, cosdef)
+
+
+def test_fp16x3_overflow_is_loud(npa, dev, nets):
+    """Range of the fp16 split: an activation above 65504 cannot be represented; it must surface as a non-finite `raw`, never as
+    a silently wrong finite value (docs: set_precision('bf16x3') is the unlimited-range datapath)."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    big = npa.NeRF(**kw).to(dev)
+    P = {k: v.clone() for k, v in Pf.items()}
+    P["pts_linears.0.bias"] = P["pts_linears.0.bias"] + 1.0e5           # every layer-0 activation ~1e5
+    big.load_state_dict(P)
+    rays = orc.synthetic_rays(8, seed=1).to(dev)
+    z = torch.sort(torch.rand(8, 16, generator=torch.Generator().manual_seed(1)) * 4.0 + 2.0, -1)[0].to(dev)
+    raw, _ = hb.field_fwd(big.packed_params("fp16x3"), rays, z, save_act=False, precision="fp16x3")
+    assert not bool(torch.isfinite(raw).all())
+    raw_b, _ = hb.field_fwd(big.packed_params("bf16x3"), rays, z, save_act=False, precision="bf16x3")
+    assert bool(torch.isfinite(raw_b).all())

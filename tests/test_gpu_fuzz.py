@@ -63,7 +63,7 @@ def test_random_shapes_against_the_oracle(npa, dev, nets, seed):
     rnd_dev = {k: v.to(dev) for k, v in rnd.items()}
     keys = ["rgb_map", "acc_map"] + (["rgb0", "acc0"] if n_f > 0 else [])
     coarse_keys = ("rgb0", "acc0") if n_f > 0 else ("rgb_map", "acc_map")
-    for precision, floor, psnr_db in (("fp32", 1e-5, 85.0), ("bf16x3", 3e-4, 70.0)):
+    for precision, floor, psnr_db in (("fp32", 1e-5, 85.0), ("bf16x3", 3e-4, 70.0), ("fp16x3", 3e-5, 80.0)):
         npa.set_precision(precision)
         try:
             with torch.no_grad():

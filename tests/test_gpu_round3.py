@@ -215,7 +215,7 @@ GOLDEN_CASES = [
 ]
 
 
-def _golden_grads(npa, dev, nets, kw, seed, operands, monkeypatch, render=None):
+def _golden_grads(npa, dev, nets, kw, seed, operands, monkeypatch, render=None, precision="bf16x3"):
     nc, nf, Pc, Pf = nets
     monkeypatch.setattr(npa.hip_backend, "WGRAD_OPERANDS", operands)
     target = torch.tensor(np.random.RandomState(99).rand(256, 3), dtype=torch.float32).to(dev)
@@ -224,7 +224,7 @@ def _golden_grads(npa, dev, nets, kw, seed, operands, monkeypatch, render=None):
     randoms = _golden_randoms(seed, 256, args)
     for m in (nc, nf):
         m.zero_grad()
-    npa.set_precision("bf16x3")
+    npa.set_precision(precision)
     try:
         if render is None:
             out = npa.render_rays(orc.synthetic_rays(256, seed=7).to(dev), nc, None, randoms=randoms, **args)
@@ -404,12 +404,15 @@ def _one_call_step(npa, dev, flat_c, flat_f, rays, rnd, target, precision, lr_st
     n = rays.shape[0]
     s = torch.cuda.current_stream().cuda_stream
     ptr = lambda t: None if t is None else t.data_ptr()
-    prec = {"fp32": 0, "bf16x3": 1, "mixed": 2}[precision]
+    prec = {"fp32": 0, "bf16x3": 1, "mixed": 2, "fp16x3": 3}[precision]
     cfg = hb.NerfRenderCfg(64, 128, 0, 1, 1.0 if "noise_c" in rnd else 0.0, prec, int(hb.WGRAD_OPERANDS == "bf16"))
     packed = []
     for flat in (flat_c, flat_f):
         p = torch.empty(L.nerf_packed3_floats() if prec else L.nerf_packed_floats(), device=dev)
-        assert (L.nerf_pack_params_bf16x3 if prec else L.nerf_pack_params)(flat.data_ptr(), p.data_ptr(), s) == 0
+        if prec == 3:
+            assert L.nerf_pack_params_split(flat.data_ptr(), p.data_ptr(), 15, 1, s) == 0
+        else:
+            assert (L.nerf_pack_params_bf16x3 if prec else L.nerf_pack_params)(flat.data_ptr(), p.data_ptr(), s) == 0
         packed.append(p)
     ws = torch.empty(L.nerf_render_workspace_floats(ctypes.byref(cfg), n, 1), device=dev)
     o = dict(rgb=torch.empty(n, 3, device=dev), disp=torch.empty(n, device=dev), acc=torch.empty(n, device=dev),
@@ -433,7 +436,7 @@ def _one_call_step(npa, dev, flat_c, flat_f, rays, rnd, target, precision, lr_st
     return o, gc, gf
 
 
-@pytest.mark.parametrize("precision,noise", [("fp32", False), ("bf16x3", True), ("mixed", False)])
+@pytest.mark.parametrize("precision,noise", [("fp32", False), ("bf16x3", True), ("mixed", False), ("fp16x3", True)])
 def test_one_call_abi_matches_the_binding(npa, dev, nets, precision, noise):
     """nerf_render_rays_fwd / _bwd (one C call per direction, caller-owned workspace) against the in-repo binding's
     render_rays + autograd on the same rays, draws and weights: the same launches in the same order, so outputs and both
@@ -522,7 +525,7 @@ def test_weight_gradient_refuses_mismatched_buffers_on_the_gpu(npa, dev, nets):
 
 # ---------------------------------------------------------------- render_rays without gradients in one launch
 @pytest.mark.parametrize("n_rays", [1, 17, 129, 1000])
-@pytest.mark.parametrize("case", ["det", "random_white_noise", "lindisp", "coarse_only", "small", "mixed_same_net"])
+@pytest.mark.parametrize("case", ["det", "random_white_noise", "lindisp", "coarse_only", "small", "mixed_same_net", "fp16x3_det", "fp16x3_random_white_noise"])
 def test_one_launch_inference_is_bit_identical_to_the_chain_of_launches(npa, dev, nets, n_rays, case, monkeypatch):
     """render_infer_kernel (csrc/render_fused.hip): a workgroup takes 16 rays from the coarse depths through both networks,
     raw2outputs and sample_pdf + sort to the colours, calling the SAME device code as the separate launches -- so every
@@ -534,6 +537,8 @@ def test_one_launch_inference_is_bit_identical_to_the_chain_of_launches(npa, dev
     n_c, n_f = {"coarse_only": (64, 0), "small": (8, 16)}.get(case, (64, 128))
     kw = dict(N_samples=n_c, N_importance=n_f, network_fine=nf, retraw=True)
     rnd = None
+    prec = "mixed" if case == "mixed_same_net" else ("fp16x3" if case.startswith("fp16x3") else "bf16x3")
+    case = case.replace("fp16x3_", "")
     if case == "random_white_noise":
         kw.update(white_bkgd=True, perturb=1.0, raw_noise_std=0.7)
         rnd = {k: v.to(dev) for k, v in orc.synthetic_randoms(n_rays, n_c, n_f, seed=11).items()}
@@ -542,7 +547,7 @@ def test_one_launch_inference_is_bit_identical_to_the_chain_of_launches(npa, dev
     elif case == "mixed_same_net":
         kw.update(network_fine=None, white_bkgd=True)
     rays = orc.synthetic_rays(n_rays, seed=91).to(dev)
-    npa.set_precision("mixed" if case == "mixed_same_net" else "bf16x3")
+    npa.set_precision(prec)
     try:
         assert hb.render_infer_supported(n_c, n_f, npa.get_precision())
         outs = {}

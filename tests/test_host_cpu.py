@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/nerf_hip.h but not exported"
     assert declared == set(npa.hip_backend.EXPORTS), declared ^ set(npa.hip_backend.EXPORTS)
     L = npa.hip_backend.lib()
-    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 6 and L.nerf_param_count() == 595844
+    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 7 and L.nerf_param_count() == 595844
     assert L.nerf_packed_floats() % 4 == 0
 
 
@@ -36,7 +36,7 @@ def test_argument_errors_are_codes_not_crashes():
         P = n * S
         Pp = (P + 31) // 32 * 32       # the bf16x3 datapath saves 32-point tiles; the sizes cover both layouts
         assert L.nerf_act_floats(n, S) == Pp * (9 * 256 + 128 + 64 + 32) + n * 32 + 9 * P * 8 + (-(Pp * 32 + n * 32) % 4) + 2048
-        assert L.nerf_delta_floats(n, S) == Pp * (9 * 256 + 128 + 4) + 2048
+        assert L.nerf_delta_floats(n, S) == Pp * (9 * 256 + 128 + 4) + 2048 + 4        # + the fp16 split's scale words
     assert (L.nerf_wgrad_partial_floats(n, S) - (128 * 256 + 128)) % 595844 == 0      # per-chunk partials + fold scratch (G | dbv)
 
 
@@ -226,9 +226,9 @@ def test_frame_sink_orders_frames_and_writes_the_same_pngs(tmp_path):
 
 
 def test_precision_selection_and_saved_row_views():
-    """set_precision accepts the three datapaths and rejects anything else; saved_rows inverts the tile layout of
+    """set_precision accepts the four datapaths and rejects anything else; saved_rows inverts the tile layout of
     csrc/nerf_common.h (element (p, f) of an F-wide region at (p/32)*F*32 + f*32 + p%32, fp32 or bf16)."""
-    assert npa.hip_backend.PRECISIONS == ("fp32", "bf16x3", "mixed")
+    assert npa.hip_backend.PRECISIONS == ("fp32", "bf16x3", "mixed", "fp16x3")
     prev = npa.get_precision()
     try:
         for mode in npa.hip_backend.PRECISIONS:

@@ -1,0 +1,208 @@
+"""CPU, oracle: which arithmetic classes of the field MLP's products pass the north-star gate (PSNR delta < 0.01 dB against
+the reference's image at a teacher target, tests/golden/gate_{lego,fern}.npz), WHERE their error comes from, and what a guard
+on the reference's one discontinuity buys.  Replaces tools/analysis_reduced_forward.py (round 3), whose conclusion
+("hierarchical sampling amplifies the coarse pass's rounding") was wrong: the error of a reduced class on the fern fixture is
+ONE ray whose LAST sample's sigma changes sign -- run_nerf.py:277-278 appends dists[-1] = 1e10, so alpha_last =
+1 - exp(-relu(sigma_last) * 1e10) is a step function of sign(sigma_last) (:293) and the ray's accumulated opacity jumps.
+
+Per class (every product W x of the 8x256 trunk + feature + view layers; heads exact, as in the kernels):
+  fp64        the reference algorithm in fp64: the yardstick (how far the REFERENCE's own fp32 run is from exact arithmetic)
+  bf16x3      W_hi x_hi + W_hi x_lo + W_lo x_hi, hi / lo = bf16 parts              (3 MFMAs per product; rounds 1-3)
+  fp16x3      the same with fp16 parts                                            (3 MFMAs; round 4 headline)
+  fp16+fp8c   fp16 main term + both correction terms as block-scaled fp8 e4m3 x fp8 e4m3 (MX, 32-element blocks, power-of-two
+              scales): ~2^-15 per product; 1 + 2 x 1/2 = 2 MFMA-equivalents (v_mfma_scale_f32_16x16x128_f8f6f4 runs K = 128 fp8
+              in the time of K = 64 fp16)
+  fp16+fp6c   corrections as fp6 e2m3 x fp6 e2m3 (4 significant bits, the fp4 rate on MI355X): 1 + 2 x 1/4 = 1.5 MFMA-equivalents
+  bf16+fp8c   bf16 main + fp8 corrections: ~2^-12
+  fp16        plain fp16 operands, one MFMA per product (2^-11)
+  tf32/bf16   input rounded to 10 / 7 mantissa bits, weights exact (round 3's table)
+each applied to the coarse network only, the fine network only, or both; with and without the GUARD: last samples with
+|sigma_last| < eps are re-evaluated with the three-term fp16 products (at most one point per ray).
+
+Reported per (fixture, class, where): PSNR delta (bar 0.01 dB), PSNR(our image, reference image), rays whose last-sample sigma
+has the other sign than in the reference's fp32 run, the share of the squared image error carried by the worst ray / by those
+flip rays, and the PSNR delta WITHOUT the flip rays.
+Usage: python tools/analysis_accuracy_classes.py [--quick]      (~10 min on 8 cores; --quick: both networks only)"""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import torch
+
+import nerf_oracle as orc
+import workloads as wl
+
+torch.set_num_threads(os.cpu_count() or 8)
+F = torch.nn.functional
+
+
+def split(x, dt):
+    hi = x.to(dt).float()
+    return hi, (x - hi).to(dt).float()
+
+
+def q_block(v, mant_bits, e_max, max_val, block=32):
+    """v [.., K] -> block-scaled small-float rounding along K (MX style): per block of `block` elements a power-of-two scale that
+    puts the block's largest magnitude at exponent e_max; elements rounded to `mant_bits` explicit mantissa bits, exponents
+    below 0 are subnormal (quantum 2^-mant_bits), magnitudes clamped to max_val.  fp8 e4m3: (3, 8, 448); fp6 e2m3: (3, 2, 7.5)."""
+    K = v.shape[-1]
+    pad = (-K) % block
+    if pad:
+        v = F.pad(v, (0, pad))
+    vb = v.reshape(*v.shape[:-1], -1, block).double()
+    amax = vb.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - e_max)
+    t = vb / scale
+    e = torch.floor(torch.log2(t.abs().clamp_min(1e-300))).clamp_min(0.0)          # exponent of each element, subnormal floor at 0
+    quantum = torch.exp2(e - mant_bits)
+    t = (torch.round(t / quantum) * quantum).clamp(-max_val, max_val)
+    out = (t * scale).reshape(*v.shape[:-1], -1)
+    return out[..., :K].float()
+
+
+def q8(v):
+    return q_block(v, 3, 8, 448.0)
+
+
+def q6(v):
+    return q_block(v, 3, 2, 7.5)
+
+
+def mm(a, b):
+    """x [M,K] (parts) times W [N,K]^T, accumulated exactly (fp64), as the MFMA's fp32 accumulator nearly does"""
+    return a.double() @ b.double().t()
+
+
+def product(x, W, cls):
+    if cls == "fp32":
+        return F.linear(x, W)
+    if cls == "fp64":
+        return mm(x, W)
+    if cls in ("bf16x3", "fp16x3"):
+        dt = torch.bfloat16 if cls == "bf16x3" else torch.float16
+        xh, xl = split(x, dt)
+        Wh, Wl = split(W, dt)
+        return mm(xh, Wh) + mm(xl, Wh) + mm(xh, Wl)
+    if cls in ("fp16+fp8c", "fp16+fp6c", "bf16+fp8c"):
+        dt = torch.bfloat16 if cls.startswith("bf16") else torch.float16
+        q = q6 if cls.endswith("fp6c") else q8
+        xh, xl = split(x, dt)
+        Wh, Wl = split(W, dt)
+        return mm(xh, Wh) + mm(q(xl), q(Wh)) + mm(q(xh), q(Wl))
+    if cls == "fp16":
+        return mm(x.half().float(), W.half().float())
+    if cls in ("tf32", "bf16"):
+        if cls == "bf16":
+            xr = x.bfloat16().float()
+        else:
+            xi = x.view(torch.int32)
+            xr = ((xi + 0x0FFF + ((xi >> 13) & 1)) & ~0x1FFF).view(torch.float32)
+        return mm(xr, W)
+    raise ValueError(cls)
+
+
+def mlp(P, feats, cls):
+    """oracle.field_mlp (run_nerf_helpers.py:96-119) with every MFMA-side product of the kernels in class `cls`; the two VALU heads
+    (alpha_linear, rgb_linear) stay fp32 as in the kernels"""
+    if cls == "fp32":
+        return orc_field_mlp(P, feats)
+    dt = torch.float64 if cls == "fp64" else torch.float32
+    xyz, dirs = feats[:, :63].to(dt), feats[:, 63:].to(dt)
+
+    def lin(x, name):
+        y = product(x.float() if cls != "fp64" else x, P[name + ".weight"], cls).to(torch.float64) + P[name + ".bias"].double()
+        return y.to(dt)
+    h = xyz
+    for i in range(8):
+        h = torch.relu(lin(h, f"pts_linears.{i}"))
+        if i == 4:
+            h = torch.cat([xyz, h], -1)
+    sigma = F.linear(h, P["alpha_linear.weight"].to(dt), P["alpha_linear.bias"].to(dt))
+    feat = lin(h, "feature_linear")
+    hv = torch.relu(lin(torch.cat([feat, dirs], -1), "views_linears.0"))
+    rgb = F.linear(hv, P["rgb_linear.weight"].to(dt), P["rgb_linear.bias"].to(dt))
+    return torch.cat([rgb, sigma], -1).to(feats.dtype)
+
+
+orc_field_mlp = orc.field_mlp
+
+
+def render(flat, Pc, Pf, cfg, cls_c, cls_f, guard_eps=None):
+    """the reference algorithm (oracle.trace_rays, fp32) with the coarse / fine network's products in class cls_c / cls_f; guard:
+    last-sample points of the fine pass with |sigma| < guard_eps re-evaluated with fp16x3 products"""
+    which = {id(Pc): (cls_c, 64), id(Pf): (cls_f, 192)}
+    n_rays = flat.shape[0]
+    row0 = {id(Pc): 0, id(Pf): 0}       # query_field evaluates the points of a pass in order, in netchunk slices
+
+    def patched(P, feats, **kw):
+        cls, S = which[id(P)]
+        out = mlp(P, feats, cls)
+        rows = row0[id(P)] + torch.arange(feats.shape[0])
+        row0[id(P)] = (row0[id(P)] + feats.shape[0]) % (n_rays * S)
+        if guard_eps is not None and cls not in ("fp32", "fp64", "fp16x3", "bf16x3"):
+            risky = (out[:, 3].abs() < guard_eps) & (rows % S == S - 1)         # LAST sample of its ray only
+            patched.guarded += int(risky.sum())
+            if risky.any():
+                out = out.clone()
+                out[risky] = mlp(P, feats[risky], "fp16x3")
+        return out
+    patched.guarded = 0
+    orc.field_mlp = patched
+    try:
+        with torch.no_grad():
+            out = orc.trace_rays(flat, Pc, Pf, 64, 128, perturb=0., white_bkgd=cfg["white_bkgd"], raw_noise_std=0., retraw=True)
+    finally:
+        orc.field_mlp = orc_field_mlp
+    out["_guarded_points"] = patched.guarded
+    return out
+
+
+def psnr_delta(rgb, ref, tgt, keep=None):
+    if keep is not None:
+        rgb, ref, tgt = rgb[keep], ref[keep], tgt[keep]
+    p_ref = wl.psnr(((ref.double() - tgt.double()) ** 2).mean())
+    p = wl.psnr(((rgb.double() - tgt.double()) ** 2).mean())
+    return abs(p - p_ref)
+
+
+def main():
+    quick = "--quick" in sys.argv
+    classes = ["fp64", "bf16x3", "fp16x3", "fp16+fp8c", "fp16+fp6c", "bf16+fp8c", "fp16", "tf32", "bf16"]
+    print("| fixture | class | applied to | guard | PSNR delta dB (bar 0.01) | PSNR(ours, ref) dB | sigma_last sign flips | worst ray's share of err^2 | "
+          "flip rays' share | PSNR delta without flip rays | guarded points |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    for name in ("lego", "fern"):
+        gold = np.load(os.path.join(ROOT, "tests", "golden", f"gate_{name}.npz"))
+        cfg = wl.LEGO if name == "lego" else wl.FERN
+        batch = wl.lego_batch(1024, seed=31) if name == "lego" else wl.fern_batch(1024, seed=32)
+        Pc, Pf = wl.scene_params()
+        flat = orc.assemble_render_rays(cfg["H"], cfg["W"], wl.intrinsics(cfg), batch[0], batch[1], cfg["ndc"], cfg["near"], cfg["far"])
+        ref_img, tgt = torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"])
+        base = render(flat, Pc, Pf, cfg, "fp32", "fp32")
+        assert torch.equal(base["rgb_map"], ref_img), "the oracle in fp32 IS the reference (pinned bit-identical)"
+        s_ref = base["raw"][:, -1, 3]
+        for cls in classes:
+            wheres = [("both", cls, cls)] if (quick or cls in ("fp64", "tf32", "bf16")) else [("coarse only", cls, "fp32"), ("fine only", "fp32", cls), ("both", cls, cls)]
+            for where, cc, cf in wheres:
+                for eps in ((None,) if cls in ("fp64", "bf16x3", "fp16x3") else (None, 0.05)):
+                    if eps is not None and where == "coarse only":
+                        continue
+                    out = render(flat, Pc, Pf, cfg, cc, cf, guard_eps=eps)
+                    rgb = out["rgb_map"].float()
+                    err2 = ((rgb.double() - ref_img.double()) ** 2).sum(-1)
+                    flips = (out["raw"][:, -1, 3] > 0) != (s_ref > 0)
+                    tot = float(err2.sum())
+                    d = psnr_delta(rgb, ref_img, tgt)
+                    d_wo = psnr_delta(rgb, ref_img, tgt, keep=~flips) if flips.any() else d
+                    pv = wl.psnr(max(float(err2.mean()) / 3, 1e-30))
+                    print(f"| {name} | {cls} | {where} | {'-' if eps is None else 'abs(sigma_last) < %g' % eps} | {d:.2e} | {pv:.1f} | {int(flips.sum())} | "
+                          f"{float(err2.max()) / max(tot, 1e-300):.3f} | {float(err2[flips].sum()) / max(tot, 1e-300):.3f} | {d_wo:.2e} | "
+                          f"{out['_guarded_points'] if eps is not None else '-'} |", flush=True)
+
+
+if __name__ == "__main__":
+    main()
