@@ -52,7 +52,7 @@ MAC_FWD, MAC_DGRAD, MAC_WGRAD, MAC_FOLD = 593408, 557696, 593408, 65536        #
 FLOP_FWD_PER_RAY = 2 * MAC_FWD * POINTS_PER_RAY                                  # 303.82 MFLOP
 FLOP_TRAIN_PER_RAY = 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) * POINTS_PER_RAY      # 893.19 MFLOP
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = vector rate; exact-fp32 datapath
-PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense 16-bit MFMA (bf16 and fp16 run at the same rate)
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (~6.3 TB/s achievable, MI355X_MICROARCH.md)
 DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products W_hi x_hi + W_hi x_lo + W_lo x_hi in the forward and the delta chain, f32 "
                                         "accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are stored as "
@@ -350,35 +350,45 @@ def _brief(tab):
                 "hbm_frac": v["hbm_frac"]} for k, v in tab.items()}
 
 
+def _profile_row_matches(timer_name, prof_name):
+    """does a kernel row of a rocprofv3 summary (`nerf::field_fwd16r_kernel<2, nerf::SplitF16>`) name the kernel instantiation the
+    in-process timer calls `timer_name` (`field_fwd16r_kernel<fp16, save>`)?"""
+    base, _, targs = prof_name.replace("void ", "").replace("nerf::", "").strip('"').partition("<")
+    targs = [a.strip() for a in targs.rstrip(">").split(",")] if targs else []
+    key = timer_name.split("<")[0].split("(")[0]
+    if base.split("(")[0] != key:
+        return False
+    f16 = "fp16" in timer_name
+    if any(a in ("SplitF16", "SplitBF16") for a in targs) and (("SplitF16" in targs) != f16):
+        return False
+    first = {"false": "0", "true": "1", "": "0"}.get(targs[0] if targs else "", targs[0] if targs else "")
+    if key in ("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd16r_kernel", "field_fwd_kernel"):
+        want = "2" if ("<save bf16>" in timer_name or (f16 and "save" in timer_name)) else ("1" if "<save" in timer_name else "0")
+        return first == want
+    if key in ("field_dgrad3_kernel", "field_dgrad3r_kernel"):
+        want = "1" if "<mixed>" in timer_name else ("2" if ("<bf16 out>" in timer_name or f16) else "0")
+        return first == want
+    return True
+
+
 def pmc_traffic(kernel_name, precision):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary of this same command (separate --pmc
     passes; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the
     process, so this is the profile of the same command committed under profiles/ (None if absent)."""
-    tag = {"bf16x3": "bf16x3_", "mixed": "mixed_"}.get(precision, "")
-    for rnd in ("r03", "r02", "r01"):
+    tag = {"bf16x3": "bf16x3_", "mixed": "mixed_", "fp16x3": "fp16x3_"}.get(precision, "")
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}pmc_summary.csv")
         if os.path.exists(path):
             break
     else:
         return None, None
-    key = kernel_name.split("<")[0].split("(")[0]
     fetch = write = None
     for line in open(path):
         if line.startswith("#") or "," not in line:
             continue
         kn, cn, _, val = line.rstrip().rsplit(",", 3)
-        base = kn.replace("void ", "").replace("nerf::", "").strip('"')
-        tmpl = base.split("<")[1].split(">")[0] if "<" in base else ""
-        if base.split("<")[0].split("(")[0] != key:
+        if not _profile_row_matches(kernel_name, kn):
             continue
-        if key in ("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd16r_kernel", "field_fwd_kernel"):
-            want = "2" if "<save bf16>" in kernel_name else ("1" if "<save" in kernel_name else "0")
-            if {"false": "0", "true": "1", "": "0"}.get(tmpl, tmpl) != want:
-                continue
-        if key in ("field_dgrad3_kernel", "field_dgrad3r_kernel"):
-            want = "1" if "<mixed>" in kernel_name else ("2" if "<bf16 out>" in kernel_name else "0")
-            if {"false": "0", "true": "1", "": "0"}.get(tmpl, tmpl) != want:
-                continue
         if cn == "FETCH_SIZE":
             fetch = float(val)
         elif cn == "WRITE_SIZE":

@@ -188,7 +188,7 @@ class DenseNeRF(nn.Module):
         """raw [N, S, 4 | output_ch] of the sample points o + d z of `rays` [N, 8 | 11]: nerf_build_inputs + the layer stack"""
         n, S = z_vals.shape
         C = self.input_ch + self.input_ch_views
-        x = torch.empty((n * S, C), dtype=torch.float32, device=rays.device)
+        x = torch.zeros((n * S, C), dtype=torch.float32, device=rays.device)      # (columns the kernel does not write stay defined)
         hb._check(hb.lib().nerf_build_inputs(hb._ptr(rays, "rays"), rays.shape[1], hb._ptr(z_vals, "z_vals"), n, S, self.multires,
                                              self.multires_views, int(self.use_viewdirs), x.data_ptr(), C, hb._stream()), "nerf_build_inputs")
         out = _DenseMLP.apply(self, x, *[p for _, p in self.named_parameters()])

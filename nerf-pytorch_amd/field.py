@@ -60,10 +60,12 @@ class NeRF(nn.Module):
         """whether these constructor arguments are the architecture of the fused kernels"""
         return bool(D == 8 and W == 256 and input_ch == 63 and input_ch_views == 27 and list(skips) == [4] and use_viewdirs)
 
-    def __new__(cls, *args, **kwargs):
+    def __new__(cls, *args, force_dense=False, **kwargs):
         # NeRF(...) with any other arguments the reference accepts builds the layer-by-layer module (dense.py): same constructor,
-        # attributes and state_dict; the reference's arithmetic on library GEMMs instead of the fused kernels
-        if cls is NeRF and not NeRF.fused(*args, **kwargs):
+        # attributes and state_dict; the reference's arithmetic on library GEMMs instead of the fused kernels.  force_dense
+        # (keyword-only, not in the reference): the layer-by-layer module also for the fused architecture -- create_nerf uses it
+        # when the OTHER network of the pair is outside the fused architecture (render_rays runs a pair on one path).
+        if cls is NeRF and (force_dense or not NeRF.fused(*args, **kwargs)):
             from .dense import DenseNeRF
             return DenseNeRF(*args, **kwargs)
         return super().__new__(cls)
@@ -71,7 +73,7 @@ class NeRF(nn.Module):
     def __getnewargs_ex__(self):        # copy.deepcopy / pickle re-create the object through __new__: keep it on this class
         return (), dict(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True)
 
-    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False, force_dense=False):
         super().__init__()
         if not (D == 8 and W == 256 and input_ch == 63 and input_ch_views == 27 and list(skips) == [4]
                 and use_viewdirs):
@@ -136,9 +138,9 @@ class NeRF(nn.Module):
         """Fragment repack of the current parameters for the given datapath (cached on the parameters' versions)."""
         flat = self.flat_params()
         # torch-side in-place updates advance the version counters of the parameters / of the flat vector; the fused
-        # Adam kernel advances hb.PARAM_EPOCH.  Writers that do neither (c10d collectives such as the DP parameter
+        # Adam kernel advances hb.param_epoch(flat).  Writers that do neither (c10d collectives such as the DP parameter
         # broadcast, `.data` writes, raw pointers) must call invalidate_packed().
-        key = tuple(p._version for p in self.parameters()) + (flat.data_ptr(), flat._version, hb.PARAM_EPOCH)
+        key = tuple(p._version for p in self.parameters()) + (flat.data_ptr(), flat._version, hb.param_epoch(flat))
         if self._packed is None or key != self._packed_key:
             self._packed = {}
             self._packed_key = key

@@ -714,13 +714,21 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
 
 # Bumped by every raw-pointer update of parameters (the fused Adam kernel writes through data_ptr(), which does not
 # advance the tensors' autograd version counters): NeRF.packed_params() keys its fragment-repack cache on it.
-PARAM_EPOCH = 0
+PARAM_EPOCH = 0             # total number of raw-pointer updates (any vector)
+_PARAM_EPOCHS = {}          # ... per updated vector (keyed by its device address)
+
+
+def param_epoch(flat):
+    """number of raw-pointer (fused Adam) updates of THIS flat parameter vector: an optimizer step on an unrelated network
+    neither invalidates another network's fragment repack nor trips the stale-parameter guard of its pending backward"""
+    return _PARAM_EPOCHS.get(flat.data_ptr(), 0)
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     """In-place fused Adam over flat fp32 vectors (one launch)."""
     global PARAM_EPOCH
     PARAM_EPOCH += 1
+    _PARAM_EPOCHS[params.data_ptr()] = _PARAM_EPOCHS.get(params.data_ptr(), 0) + 1
     n = params.numel()
     _check(lib().nerf_adam_step(_ptr(params, "params"), _ptr(grads, "grads"), _ptr(exp_avg, "exp_avg"),
                                 _ptr(exp_avg_sq, "exp_avg_sq"), n, float(lr), float(beta1), float(beta2), float(eps),

@@ -121,13 +121,19 @@ def create_nerf(args, device=None, fused_adam=False):
         embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
     output_ch = 5 if args.N_importance > 0 else 4
     skips = [4]
+    arch = lambda D, W: dict(D=D, W=W, input_ch=input_ch, output_ch=output_ch, skips=skips, input_ch_views=input_ch_views,
+                             use_viewdirs=args.use_viewdirs)
+    # render_rays evaluates a (coarse, fine) pair on ONE path: if only one of the two is the fused kernels' architecture
+    # (e.g. --netwidth_fine 128 next to the default coarse network), both are built layer by layer
+    mixed_pair = args.N_importance > 0 and (NeRF.fused(**arch(args.netdepth, args.netwidth)) !=
+                                            NeRF.fused(**arch(args.netdepth_fine, args.netwidth_fine)))
     model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
-                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, force_dense=mixed_pair).to(device)
     grad_vars = list(model.parameters())
     model_fine = None
     if args.N_importance > 0:
         model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
-                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, force_dense=mixed_pair).to(device)
         grad_vars += list(model_fine.parameters())
 
     netchunk = getattr(args, "netchunk", 1024 * 64)

@@ -109,7 +109,7 @@ def _param_slices(model):
 def _param_state(model):
     """Identity of the parameter values a forward saw: storage, in-place version, fused-Adam epoch."""
     flat = model.flat_params()
-    return (flat.data_ptr(), flat._version, tuple(p._version for p in model.parameters()), hb.PARAM_EPOCH)
+    return (flat.data_ptr(), flat._version, tuple(p._version for p in model.parameters()), hb.param_epoch(flat))
 
 
 def _grad_views(model, flat_grad):
@@ -171,7 +171,10 @@ class _RenderRays(torch.autograd.Function):
         if ctx.checkpoint:
             ceil_div = lambda a, b: -(-a // b)
             sub = min(sub, 64 * ceil_div(ceil_div(n, ceil_div(n, sub)), 64))        # equal sub-chunks, multiples of 64 rays
-            if hb.saved_bytes(sub, cfg["N_samples"], n_f) * ceil_div(n, sub) <= hb.SAVE_TOTAL_BYTES:
+            # resident sub-chunks only if they fit the budget AND what the device actually has free right now (the pool's own idle
+            # leases count as free: they are re-used); otherwise the forward is recomputed per sub-chunk in the backward
+            free_now = torch.cuda.mem_get_info(rays.device)[0] + 4 * sum(t.numel() for t in hb.WORKSPACE._free.get(str(rays.device), []))
+            if hb.saved_bytes(sub, cfg["N_samples"], n_f) * ceil_div(n, sub) <= min(hb.SAVE_TOTAL_BYTES, int(0.9 * free_now)):
                 ctx.checkpoint = False
                 ctx.tiles = [(lo, min(lo + sub, n)) for lo in range(0, n, sub)]
         ctx.sub_rays = sub
@@ -633,7 +636,7 @@ class _Img2Mse(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y):
         xc, yc = x.contiguous(), y.contiguous()
-        key = str(x.device)
+        key = (str(x.device), hb._stream())         # (per stream: the kernel's ticket word must not be shared by concurrent launches)
         if key not in _MSE_SCRATCH:
             _MSE_SCRATCH[key] = torch.zeros(hb.lib().nerf_mse_scratch_floats(), dtype=torch.float32, device=x.device)
         out = torch.empty((), dtype=torch.float32, device=x.device)

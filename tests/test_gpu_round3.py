@@ -463,6 +463,55 @@ def test_one_call_abi_matches_the_binding(npa, dev, nets, precision, noise):
     assert torch.equal(gc, nc.last_flat_grad) and torch.equal(gf, nf.last_flat_grad)
 
 
+def test_one_call_backward_writes_every_gradient_it_is_given(npa, dev, nets):
+    """nerf_render_rays_bwd(accumulate = 0) with upstream gradients for ONE of the two passes only: the other network's gradient
+    vector is WRITTEN (zeros), not left as it was; d_disp / d_acc without d_rgb is accepted (a zero d_rgb is
+    synthesised) instead of surfacing a raw HIP error code."""
+    import ctypes
+    import workloads as wl
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    L = hb.lib()
+    n = 96
+    s = torch.cuda.current_stream().cuda_stream
+    ptr = lambda t: None if t is None else t.data_ptr()
+    rays = orc.synthetic_rays(n, seed=4).to(dev)
+    rnd = {k: v.to(dev) for k, v in wl.synthetic_randoms(n, 64, 128, seed=2).items() if k in ("t_rand", "u")}
+    for precision, prec in (("fp16x3", 3), ("fp32", 0)):
+        cfg = hb.NerfRenderCfg(64, 128, 0, 1, 0.0, prec, 1)
+        packed = [m.packed_params(precision) for m in (nc, nf)]
+        ws = torch.empty(L.nerf_render_workspace_floats(ctypes.byref(cfg), n, 1), device=dev)
+        o = dict(rgb=torch.empty(n, 3, device=dev), disp=torch.empty(n, device=dev), acc=torch.empty(n, device=dev),
+                 raw=torch.empty(n, 192, 4, device=dev), rgb0=torch.empty(n, 3, device=dev), disp0=torch.empty(n, device=dev),
+                 acc0=torch.empty(n, device=dev), z_std=torch.empty(n, device=dev))
+        assert L.nerf_render_rays_fwd(ctypes.byref(cfg), ptr(packed[0]), ptr(packed[1]), ptr(rays), 11, n, ptr(rnd["t_rand"]), None, ptr(rnd["u"]), None,
+                                      ptr(o["rgb"]), ptr(o["disp"]), ptr(o["acc"]), ptr(o["raw"]), ptr(o["rgb0"]), ptr(o["disp0"]), ptr(o["acc0"]),
+                                      ptr(o["z_std"]), ptr(ws), 1, s) == 0, L.nerf_last_error()
+        g = torch.randn(n, 3, device=dev) * 1e-4
+        ga = torch.randn(n, device=dev) * 1e-4
+
+        def bwd(d_rgb, d_acc, d_rgb0, d_acc0):
+            gc, gf = torch.full((hb.N_PARAMS,), float("nan"), device=dev), torch.full((hb.N_PARAMS,), float("nan"), device=dev)
+            rc = L.nerf_render_rays_bwd(ctypes.byref(cfg), ptr(packed[0]), ptr(packed[1]), ptr(nc.flat_params()), ptr(nf.flat_params()), ptr(rays), 11, n,
+                                        None, None, ptr(o["raw"]), ptr(d_rgb), None, ptr(d_acc), None, ptr(d_rgb0), None, ptr(d_acc0),
+                                        ptr(ws), ptr(gc), ptr(gf), 0, s)
+            assert rc == 0, (rc, L.nerf_last_error())
+            return gc, gf
+        gc, gf = bwd(g, None, None, None)                   # fine pass only: the coarse network's gradient is zeros
+        assert bool((gc == 0).all()) and bool(torch.isfinite(gf).all()) and float(gf.abs().max()) > 0
+        gc2, gf2 = bwd(None, None, g, None)                 # coarse pass only
+        assert bool((gf2 == 0).all()) and bool(torch.isfinite(gc2).all()) and float(gc2.abs().max()) > 0
+        gc3, gf3 = bwd(None, ga, None, ga)                  # d_acc without d_rgb, both passes
+        assert bool(torch.isfinite(gc3).all()) and bool(torch.isfinite(gf3).all()) and float(gc3.abs().max()) > 0 and float(gf3.abs().max()) > 0
+        # ... and equals the same call with an explicit zero d_rgb
+        z3 = torch.zeros(n, 3, device=dev)
+        gc4, gf4 = bwd(z3, ga, z3, ga)
+        assert torch.equal(gc3, gc4) and torch.equal(gf3, gf4)
+    rc = L.nerf_render_rays_bwd(ctypes.byref(cfg), ptr(packed[0]), ptr(packed[1]), ptr(nc.flat_params()), ptr(nf.flat_params()), ptr(rays), 11, n,
+                                None, None, ptr(o["raw"]), None, None, None, None, None, None, None, ptr(ws), ptr(gc), ptr(gf), 0, s)
+    assert rc == -1 and b"no upstream gradient" in L.nerf_last_error()
+
+
 def test_one_call_abi_trains_two_steps(npa, dev, nets):
     """Two optimizer steps driven ONLY through the C entry points a foreign host would bind (pack -> render_rays_fwd ->
     render_rays_bwd -> adam_step), against the same two steps through the binding (render_rays + autograd + FlatAdam):

@@ -140,6 +140,23 @@ def test_create_nerf_builds_the_reference_kwargs(tmp_path):
     assert torch.equal(tr2["network_fn"].flat_params(), tr["network_fn"].flat_params())
 
 
+def test_create_nerf_builds_a_mixed_pair_on_one_path():
+    """A legal reference command line whose two networks differ in architecture (--netwidth_fine 128 next to the default
+    coarse network, run_nerf.py:435-442): render_rays evaluates a pair on ONE path, so create_nerf builds BOTH layer by layer;
+    two default networks stay on the fused kernels; force_dense is not needed for equal pairs."""
+    base = ["--expname", "t", "--basedir", "/nonexistent", "--use_viewdirs", "--N_importance", "64", "--no_reload"]
+    for extra, kinds in (([], ("NeRF", "NeRF")), (["--netwidth_fine", "128"], ("DenseNeRF", "DenseNeRF")),
+                         (["--netdepth", "6"], ("DenseNeRF", "DenseNeRF")), (["--netwidth", "128", "--netwidth_fine", "128"], ("DenseNeRF", "DenseNeRF"))):
+        args = npa.config_parser().parse_args(base + extra)
+        tr, _, _, grad_vars, _ = npa.create_nerf(args, device=torch.device("cpu"), fused_adam=False)
+        assert (type(tr["network_fn"]).__name__, type(tr["network_fine"]).__name__) == kinds, (extra, kinds)
+        assert len(grad_vars) == len(list(tr["network_fn"].parameters())) + len(list(tr["network_fine"].parameters()))
+    forced = npa.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True, force_dense=True)
+    fused = npa.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    assert type(forced).__name__ == "DenseNeRF" and type(fused) is npa.NeRF
+    assert list(forced.state_dict().keys()) == list(fused.state_dict().keys())
+
+
 def test_flat_adam_is_state_dict_compatible_with_torch_adam():
     """FlatAdam = torch.optim.Adam arithmetic on flat moment buffers; checkpoints round-trip both ways (run_nerf.py:792-800)."""
     kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)

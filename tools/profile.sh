@@ -3,7 +3,7 @@
 # busy, LDS, waits).  usage: tools/profile.sh <fp32|bf16x3|mixed> [extra bench flags]
 # Writes gpurun_out/prof_<prec>/ and the two summaries profiles/ expects:
 #   gpurun_out/prof_<prec>/kernel_stats.csv, gpurun_out/prof_<prec>/pmc_summary.csv
-PREC=${1:-bf16x3}; shift
+PREC=${1:-fp16x3}; shift
 TAG=${TAG:-$PREC}           # directory tag: TAG=bf16x3_render_only tools/profile.sh bf16x3 --mode render_only --steps 2 --warmup 1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
