@@ -236,7 +236,19 @@ class PowerSampler:
         self.period, self.samples, self._stop = period_s, [], threading.Event()
         self.cap_w, self.source = None, "none"
         self._power = self._freq = None
+        # a node exposes the hwmon directories of ALL its GPUs, also those of other tenants: take the one whose PCI address is
+        # the address of the device this process computes on (torch device 0)
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(0)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:               # noqa: BLE001
+            pass
+        self.pci = want
         for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if want is None or os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(hw)))).lower() != want:
+                continue
             pw = [f for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))]
             if pw:
                 self._power = os.path.join(hw, pw[0])
@@ -302,10 +314,10 @@ class PowerSampler:
     def summary(self, t0=None, t1=None):
         rows = [r for r in self.samples if (t0 is None or r[0] >= t0) and (t1 is None or r[0] <= t1)]
         if not rows:
-            return {"source": self.source, "samples": 0}
+            return {"source": self.source, "samples": 0, "pci": getattr(self, "pci", None)}
         w = sorted(r[1] for r in rows)
         f = [r[2] for r in rows if r[2] is not None]
-        return {"source": self.source, "samples": len(rows), "cap_w": self.cap_w, "mean_w": sum(w) / len(w), "p95_w": w[min(len(w) - 1, int(0.95 * len(w)))],
+        return {"source": self.source, "pci": getattr(self, "pci", None), "samples": len(rows), "cap_w": self.cap_w, "mean_w": sum(w) / len(w), "p95_w": w[min(len(w) - 1, int(0.95 * len(w)))],
                 "max_w": w[-1], "sclk_mhz_mean": (sum(f) / len(f)) if f else None, "sclk_mhz_min": min(f) if f else None,
                 "frac_of_cap": (sum(w) / len(w) / self.cap_w) if self.cap_w else None}
 

@@ -87,11 +87,12 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     const float* bias = ring_small_ptr(lds, SM_BIAS);
     f32x4 acc[16];
     float h[64];
+    auto relu = [](float x) __attribute__((always_inline)) { return SP::relu(x); };
     auto take = [&]() {
 #pragma unroll
         for (int nb = 0; nb < 16; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[4 * nb + r] = fmaxf(acc[nb][r], 0.0f);
+            for (int r = 0; r < 4; ++r) h[4 * nb + r] = relu(acc[nb][r]);
     };
     constexpr int NP = SAVE ? 4 : 0;        // row stores guaranteed behind the last fetch part (one per unit, positions 3..6)
     auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
@@ -199,7 +200,7 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[4 * nb + r] = fmaxf(av[nb][r], 0.0f);
+        for (int r = 0; r < 4; ++r) hv[4 * nb + r] = relu(av[nb][r]);
     if (SAVE) {
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb)

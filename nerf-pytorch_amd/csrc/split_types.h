@@ -35,6 +35,7 @@ struct SplitBF16 {
         lo = cvt_pk(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
     }
     __device__ static __forceinline__ unsigned short cvt1(float a) { return __builtin_bit_cast(unsigned short, (__bf16)a); }
+    __device__ static __forceinline__ float relu(float x) { return fmaxf(x, 0.0f); }
     __device__ static __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {       // 16 points / wave
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
@@ -65,6 +66,14 @@ struct SplitF16 {
         lo = cvt_pk(l0, l1);
     }
     __device__ static __forceinline__ unsigned short cvt1(float a) { return __builtin_bit_cast(unsigned short, (_Float16)a); }
+    // ReLU that PROPAGATES NaN (IEEE-754-2019 maximum; v_max_f32 returns its non-NaN operand): an activation beyond fp16's range
+    // becomes inf in the next operand split and inf - inf = NaN in the contraction -- that NaN must reach `raw`, not turn into a
+    // zero activation.  Identical to fmaxf(x, 0) for every non-NaN x; one VALU operation.
+    __device__ static __forceinline__ float relu(float x) {
+        float r;
+        asm("v_maximum3_f32 %0, %1, 0, 0" : "=v"(r) : "v"(x));
+        return r;
+    }
     __device__ static __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }

@@ -87,8 +87,10 @@ def test_field_backward_fp16x3_arithmetic_and_flips(npa, dev, nets, n_rays, S):
     operand storage: gradient vs fp64 autograd of the reference network evaluated with the kernel's OWN ReLU pattern, under a
     RANDOM upstream gradient -- the worst case for the zero-mean 2^-12 rounding of the stored operands (incoherent sums do not
     average it down relative to the result): <= 1e-3 of max|g| for every 256-wide tensor (measured <= 8.6e-4; bf16 storage:
-    5.4e-3, bound 8e-3), <= 2e-3 for the two heads' few-entry tensors (rgb_linear: 387 entries, measured 1.4e-3), and <= 5e-4
-    relative L2 per tensor.  Units on the other side of their kink only within 2e-5 of the layer's scale, and rare."""
+    5.4e-3, bound 8e-3), <= 2e-3 for the two heads' few-entry tensors (rgb_linear: 387 entries, measured 1.4e-3); relative L2 of
+    the WHOLE gradient <= 5e-4 (2^-12 sqrt(2) = 3.5e-4 is the operand rounding's size for an incoherent sum: measured 2.6e-4 .. 3.5e-4;
+    bf16 storage: 2.1e-3) and
+    <= 1e-3 for any single weight tensor.  Units on the other side of their kink only within 2e-5 of the layer's scale, and rare."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
     g = torch.Generator().manual_seed(7 * n_rays + S)
@@ -111,6 +113,8 @@ def test_field_backward_fp16x3_arithmetic_and_flips(npa, dev, nets, n_rays, S):
     out, pres = _field_with_forced_relu(P64, feats, masks)
     (out * d_raw.reshape(-1, 4).double()).sum().backward()
     worst, rel2 = {}, {}
+    ref_all = torch.cat([P64[nm].grad.reshape(-1) for nm, _, _ in hb.param_table()])
+    rel_all = float((grad - ref_all).norm() / ref_all.norm())
     for nm, off, shape in hb.param_table():
         gg = grad[off:off + int(np.prod(shape))].view(shape)
         r = P64[nm].grad
@@ -125,13 +129,59 @@ def test_field_backward_fp16x3_arithmetic_and_flips(npa, dev, nets, n_rays, S):
         if diff.any():
             worst_pre = max(worst_pre, float(pre.detach().abs()[diff].max()) / max(1.0, float(pre.detach().abs().max())))
     print(f"fp16x3 backward vs fp64 with the kernel's own ReLU pattern: max|err|/max|g| {max(worst.values()):.1e} "
-          f"({max(worst, key=worst.get)}), worst relative L2 of a weight tensor {max(v for k, v in rel2.items() if not k.endswith('bias')):.1e}; units on the other side of their kink: {flips} of {n_units}, largest |pre| among them {worst_pre:.1e}")
+          f"({max(worst, key=worst.get)}), relative L2 of the whole gradient {rel_all:.1e} / of the worst weight tensor {max(v for k, v in rel2.items() if not k.endswith('bias')):.1e}; units on the other side of their kink: {flips} of {n_units}, largest |pre| among them {worst_pre:.1e}")
     small = ("rgb_linear.weight", "rgb_linear.bias", "alpha_linear.weight", "alpha_linear.bias")
     assert max(v for k, v in worst.items() if k not in small) <= 1e-3, worst
     assert max(worst.values()) <= 2e-3, worst
-    assert max(v for k, v in rel2.items() if not k.endswith("bias")) <= 5e-4, rel2
+    assert rel_all <= 5e-4, rel_all
+    assert max(v for k, v in rel2.items() if not k.endswith("bias")) <= 1e-3, rel2
     assert worst_pre <= 2e-5, worst_pre
     assert flips <= 2e-4 * n_units, (flips, n_units)
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16x3"])
+def test_split_backward_under_a_training_losss_upstream_gradient(npa, dev, nets, precision, monkeypatch):
+    """The same fp64 comparison (the kernel's own ReLU pattern forced) with the upstream gradient a training step produces:
+    d_raw = the adjoint of raw2outputs for an MSE loss on 512 rays x 192 samples (98 k points).  Its sums over points are
+    COHERENT, so the zero-mean rounding of the stored weight-gradient operands averages down relative to the result: whole-gradient
+    relative L2 <= 5e-5 with fp16 operands (2^-12 per element), <= 4e-4 with bf16 operands (2^-9) -- the isolated, same-forward
+    measurement of what the operand storage costs (a cross-datapath comparison would measure the hierarchical
+    sampling's sensitivity to forward rounding instead, see test_fp16x3_training_gradient_full_batch_vs_the_fp32_datapath)."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    monkeypatch.setattr(hb, "WGRAD_OPERANDS", "bf16")
+    n_rays, S = 512, 192
+    P = n_rays * S
+    g = torch.Generator().manual_seed(11)
+    rays = orc.synthetic_rays(n_rays, seed=29)
+    z = torch.sort(torch.rand(n_rays, S, generator=g) * 4.0 + 2.0, -1)[0]
+    target = torch.rand(n_rays, 3, generator=g)
+    packed = nf.packed_params(precision)
+    rd, zd = rays.to(dev), z.to(dev)
+    raw, act = hb.field_fwd(packed, rd, zd, save_act=True, precision=precision)
+    rgb, _, _, _, _ = hb.raw2outputs(raw, zd, rd, 11, None, 0.0, True, rays_d_offset=3)
+    d_rgb = (2.0 / (3 * n_rays)) * (rgb - target.to(dev))
+    d_raw = hb.raw2outputs_bwd(raw, zd, rd, 11, None, 0.0, True, d_rgb.contiguous(), None, None, rays_d_offset=3)
+    masks = _decode_masks(npa, act, P, n_rays)
+    grad = torch.full((595844,), float("nan"), device=dev)
+    hb.field_bwd(packed, act, d_raw, grad, accumulate=False, precision=precision, params=nf.flat_params())
+    hb.WORKSPACE.give(act)
+    grad = grad.cpu().double()
+    P64 = {k: v.double().requires_grad_(True) for k, v in Pf.items()}
+    d64 = d_raw.cpu().double().reshape(-1, 4)
+    for lo in range(0, n_rays, 64):         # (chunks: the fp64 autograd graph of 98 k points at once is ~3 GB)
+        r = rays[lo:lo + 64]
+        pts = (r[:, None, 0:3] + r[:, None, 3:6] * z[lo:lo + 64, :, None]).reshape(-1, 3).double()
+        dirs = r[:, None, 8:11].expand(r.shape[0], S, 3).reshape(-1, 3).double()
+        feats = torch.cat([orc.posenc(pts, 10), orc.posenc(dirs, 4)], -1)
+        out, _ = _field_with_forced_relu(P64, feats, [m[lo * S:(lo + 64) * S] for m in masks])
+        (out * d64[lo * S:(lo + 64) * S]).sum().backward()
+    ref = torch.cat([P64[nm].grad.reshape(-1) for nm, _, _ in hb.param_table()])
+    rel = float((grad - ref).norm() / ref.norm())
+    worst = max(maxdiff(grad[off:off + int(np.prod(shape))], P64[nm].grad.reshape(-1)) / float(P64[nm].grad.abs().max()) for nm, off, shape in hb.param_table())
+    print(f"{precision}, training-loss upstream gradient, 98 k points: whole-gradient relative L2 vs fp64 (own ReLU pattern) {rel:.2e}; worst tensor max|err|/max|g| {worst:.1e}")
+    assert rel <= (5e-5 if precision == "fp16x3" else 4e-4), rel
+    assert worst <= (2e-4 if precision == "fp16x3" else 1.5e-3), worst
 
 
 def test_delta_scale_makes_the_backward_exactly_homogeneous(npa, dev, nets):
@@ -161,34 +211,40 @@ def test_delta_scale_makes_the_backward_exactly_homogeneous(npa, dev, nets):
     hb.WORKSPACE.give(act)
 
 
-def test_fp16_operand_storage_full_batch(npa, dev, monkeypatch):
+def _compare_with_the_fp32_datapath(g, g32, label):
+    rel = float((g - g32).norm() / g32.norm())
+    cosdef = 1.0 - float((g * g32).sum() / (g.norm() * g32.norm()))
+    print(f"{label}: relative L2 {rel:.2e}, cosine deficit {cosdef:.1e}")
+    return rel, cosdef
+
+
+def test_fp16x3_training_gradient_full_batch_vs_the_fp32_datapath(npa, dev, monkeypatch):
     """BASELINE configs[1] batch (4096 rays x (64+128)): the gradient of the training loss on the fp16 split (fp16 operand storage)
-    against the split-bf16 datapath with fp32 operand storage -- round 3's fp32-class gradient.  The difference contains the
-    fp16 operand rounding (2^-12, zero-mean, averaged over 262 k / 786 k points) AND the two chains' own product errors (2^-22 vs
-    2^-17); bf16 storage measured 9.3e-5 here."""
-    g16 = _flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch, precision="fp16x3")
-    g32 = _flat_grads_through_render(npa, dev, 4096, "fp32", monkeypatch)
-    gb16 = _flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch)
-    rel = float((g16 - g32).norm() / g32.norm())
-    rel_b = float((gb16 - g32).norm() / g32.norm())
-    cosdef = 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm()))
-    print(f"4096 rays: fp16x3 vs bf16x3 with fp32 operand storage: relative L2 {rel:.2e}, cosine deficit {cosdef:.1e}  (bf16 storage: {rel_b:.2e})")
-    assert rel <= 2e-5 and cosdef <= 1e-9, (rel, cosdef)
-    assert rel < rel_b / 3
+    against the EXACT-fp32 datapath's, next to round 3's two split-bf16 variants (bf16 / fp32 operand storage) against the same
+    reference.  (Not against another split datapath: the hierarchical samples depend on the coarse pass's rounding, so two
+    different forwards differ by sample positions, not by gradient arithmetic -- measured 6.6e-4 between fp16x3 and bf16x3.)
+    What the distance contains: the fp16 operand rounding (2^-12, zero-mean, averaged over 262 k / 786 k points), the chain's
+    2^-22 products and the sampling's sensitivity to forward rounding at the 2^-22 level."""
+    g32 = _flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch, precision="fp32")
+    rel, cosdef = _compare_with_the_fp32_datapath(_flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch, precision="fp16x3"), g32, "4096 rays, fp16x3 vs fp32 datapath")
+    rel_b, _ = _compare_with_the_fp32_datapath(_flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch), g32, "4096 rays, bf16x3 (bf16 operands) vs fp32 datapath")
+    rel_b32, _ = _compare_with_the_fp32_datapath(_flat_grads_through_render(npa, dev, 4096, "fp32", monkeypatch), g32, "4096 rays, bf16x3 (fp32 operands) vs fp32 datapath")
+    assert rel <= 6e-4 and cosdef <= 2e-7, (rel, cosdef)          # measured 3.5e-4 (bf16x3: 8.4e-4 / 8.3e-4 with bf16 / fp32 operand storage)
+    assert rel < rel_b and rel < rel_b32, (rel, rel_b, rel_b32)
 
 
 @pytest.mark.parametrize("case", range(6))
-def test_fp16_operand_storage_on_every_golden_configuration(npa, dev, nets, case, monkeypatch):
-    """The same comparison on the six golden configurations (256 rays: 16 k / 49 k points per contraction, where bf16 storage is
-    held to 1.5e-3): fp16x3 vs the split-bf16 chain with fp32 operand storage, relative L2 of the whole gradient <= 2e-4."""
+def test_fp16x3_gradient_on_every_golden_configuration_vs_the_fp32_datapath(npa, dev, nets, case, monkeypatch):
+    """The same comparison on the six golden configurations (256 rays: 16 k / 49 k points per contraction): fp16x3 vs the exact-fp32
+    datapath, whole-gradient relative L2, next to bf16x3 with fp32 operand storage."""
     name, kw, seed, through = GOLDEN_CASES[case]
     render = {None: None, "fern": (orc.FERN, orc.fern_batch(256, seed=3)), "lego": (orc.LEGO, orc.lego_batch(256, seed=7))}[through]
-    g32 = _golden_grads(npa, dev, nets, kw, seed, "fp32", monkeypatch, render)
-    g16 = _golden_grads(npa, dev, nets, kw, seed, "bf16", monkeypatch, render, precision="fp16x3")
-    rel = float((g16 - g32).norm() / g32.norm())
-    cosdef = 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm()))
-    print(f"{name}: fp16x3 vs bf16x3 / fp32 operand storage: relative L2 {rel:.2e}, cosine deficit {cosdef:.1e}")
-    assert rel <= 2e-4 and cosdef <= 5e-8, (name, rel, cosdef)
+    g32 = _golden_grads(npa, dev, nets, kw, seed, "bf16", monkeypatch, render, precision="fp32")
+    rel, cosdef = _compare_with_the_fp32_datapath(_golden_grads(npa, dev, nets, kw, seed, "bf16", monkeypatch, render, precision="fp16x3"), g32, f"{name}: fp16x3 vs fp32 datapath")
+    rel_b, _ = _compare_with_the_fp32_datapath(_golden_grads(npa, dev, nets, kw, seed, "fp32", monkeypatch, render), g32, f"{name}: bf16x3 (fp32 operands) vs fp32 datapath")
+    # measured 3.9e-5 .. 2.8e-4, and 2.0e-3 on the two lego_train configurations (bf16x3 there: 3.0e-3): one ray with fine samples in bins
+    # the coarse pass found empty (helpers:234-236) moves under any forward rounding -- the reference's own fp32 and fp64 runs differ likewise
+    assert rel <= 3e-3 and cosdef <= 3e-6 and rel <= 1.2 * rel_b, (name, rel, cosdef, rel_b)
 
 
 def test_fp16x3_overflow_is_loud(npa, dev, nets):
