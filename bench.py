@@ -58,6 +58,7 @@ DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products W_hi x_
                                         "accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are stored as "
                                         "bf16 and multiplied exactly, f32 accumulate — NERF_WGRAD_OPERANDS=fp32 stores and splits fp32)",
               "mixed": "bf16x3 forward + bf16 backward (mixed-precision training option)",
+              "fp16_fp8c": "fp16 main term + fp8 (e4m3) correction terms per product, inference only (gradients: fp16x3)",
               "fp16x3": "fp16x3 (split-fp16 MFMA products W_hi x_hi + W_hi x_lo + W_lo x_hi, hi = fp16(v), lo = fp16(v - hi): ~2^-22 per product, in the "
                         "forward and the delta chain, f32 accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are the "
                         "fp16 hi words (11 significant bits), multiplied exactly, f32 accumulate; deltas scaled by a power of two per launch)"}
@@ -74,7 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--rays", type=int, default=N_RAND, help="rays per GPU per step (weak scaling)")
     ap.add_argument("--frame", type=int, default=800, help="render_only: frame side in pixels")
     ap.add_argument("--chunk", type=int, default=1024 * 32)
-    ap.add_argument("--precision", choices=["fp32", "bf16x3", "mixed", "fp16x3"], default=os.environ.get("NERF_BENCH_PRECISION", "fp16x3"),
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "mixed", "fp16x3", "fp16_fp8c"], default=os.environ.get("NERF_BENCH_PRECISION", "fp16x3"),
                     help="headline field datapath.  fp16x3 (default) = three-term split with fp16 parts (3 MFMAs per product, ~2^-22 per product, "
                          "fp32 accumulate / activations / gradients, 11-bit operands for the weight-gradient GEMM); bf16x3 = the same with bf16 parts "
                          "(2^-17, 8-bit operands: rounds 1-3); both admitted by the north-star PSNR criterion, which this run re-measures and "
@@ -329,7 +330,7 @@ def _kernel_class(name):
     if name.startswith(("field_fwd_kernel", "field_dgrad_kernel", "wgrad256_kernel", "wgrad_kernel")):
         return 1.0, 1.0, PEAK_FP32_MFMA_TFLOPS                                  # exact-fp32 datapath
     if fwd:
-        return 3.0, (MAC_FWD - MAC_FOLD) / MAC_FWD, PEAK_BF16_MFMA_TFLOPS
+        return (2.0 if "fp8c" in name else 3.0), (MAC_FWD - MAC_FOLD) / MAC_FWD, PEAK_BF16_MFMA_TFLOPS
     if name.startswith(("field_dgrad3_kernel", "field_dgrad3r_kernel")):
         return (1.0 if "<mixed>" in name else 3.0), (MAC_DGRAD - MAC_FOLD) / MAC_DGRAD, PEAK_BF16_MFMA_TFLOPS
     if name.startswith("wgrad1_kernel"):
@@ -914,6 +915,31 @@ def main():
             return out
         sustained = _guarded(errors, "sustained", _sus)
 
+    # ---- the reduced INFERENCE class (fp16 main term + fp8 correction terms, csrc/field_ring8.h): never the headline; measured
+    # alternately with the headline's inference, with its own north-star gate
+    reduced_infer = None
+    if not args.single_datapath and args.mode == "train" and args.precision == "fp16x3" and rank == 0:
+        def _red():
+            k_inf = max(5, args.steps // 2)
+            best = {"fp16x3": None, "fp16_fp8c": None}
+            for _ in range(2):
+                for prec in ("fp16_fp8c", "fp16x3"):
+                    e, _k = measure(prec, k_inf, 2, ses.infer_step, with_kernels=False)
+                    best[prec] = e if best[prec] is None else min(best[prec], e)
+            _e, kern_r = measure("fp16_fp8c", 4, 1, ses.infer_step, with_kernels=True)
+            out = {"dtype": DTYPE_NAME["fp16_fp8c"], "rays_per_s": n * world * k_inf / best["fp16_fp8c"],
+                   "headline_datapath_rays_per_s_same_interleaving": n * world * k_inf / best["fp16x3"],
+                   "kernels": {k: round(v["avg_ms"], 4) for k, v in kernel_table(kern_r).items()},
+                   "what": "no_grad render() of the same 4096-ray batches under set_precision('fp16_fp8c'): every product of the 256-wide layers = "
+                           "W_hi16 x_hi16 (fp16 MFMA) + W_hi8 x_lo8 + W_lo8 x_hi8 (fp8 e4m3 MFMAs, K = 128), ~2^-15 per product, 2 instead of 3 "
+                           "MFMA-equivalents; every ray's last sample re-evaluated with the three-term fp16 products; chain of launches"}
+            if not args.no_gate:
+                g = ses.gate("fp16_fp8c", with_operands=False)
+                out["precision_gate"] = None if g is None else {k: g[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed")}
+            return out
+        reduced_infer = _guarded(errors, "reduced_inference", _red)
+        npa.set_precision(args.precision)
+
     bf16x3_leg = None
     if not args.single_datapath and args.mode == "train" and args.precision == "fp16x3":
         # rounds 1-3's headline datapath in the same run (bf16 parts: 2^-17 products, 8-bit weight-gradient operands)
@@ -1051,6 +1077,8 @@ def main():
             line["fp32_operand_storage"] = fp32_operands
         if bf16x3_leg is not None:
             line["bf16x3_datapath"] = bf16x3_leg
+        if reduced_infer is not None:
+            line["reduced_inference"] = reduced_infer
         if sustained is not None:
             line["sustained"] = sustained
             line["sustained_rays_per_s"] = sustained["train"]["rays_per_s"]
@@ -1071,6 +1099,8 @@ def main():
                 line["speedup_vs_rocm_eager"]["bf16x3_fp32_operands"] = bf16x3_leg["fp32_operand_storage"]["value"] / ref
             if sustained is not None:
                 line["speedup_vs_rocm_eager"]["sustained"] = sustained["train"]["rays_per_s"] / ref
+            if reduced_infer is not None:
+                line["speedup_vs_rocm_eager"]["reduced_inference"] = reduced_infer["rays_per_s"] / eb["infer_rays_per_s"]
             if other_infer is not None:
                 line["speedup_vs_rocm_eager"]["inference"] = other_infer / eb["infer_rays_per_s"]
         if world == 1 and not args.no_cpu_baseline:

@@ -184,6 +184,17 @@ int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride
                          int n_samples, float* raw, float* act /* nullable: inference */, int split, void* stream);
 int nerf_field_dgrad_split(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
                            float* delta, int split, void* stream);
+/* ---- reduced product class for INFERENCE: split = 2 of nerf_pack_params_split / nerf_field_fwd_split (act must be NULL).
+ * Every product of the 256-wide contractions (layers 1..7, the trunk part of the view branch) is  W_hi16 x_hi16  on the fp16 MFMA
+ * plus the two correction terms  W_hi8 x_lo8 + W_lo8 x_hi8  as block-scaled fp8 e4m3 MFMAs of K = 128 (v_mfma_scale_f32_16x16x128_
+ * f8f6f4): ~2^-15 per product at 2 instead of 3 MFMA-equivalents (csrc/field_ring8.h).  Admitted for inference by the north-star
+ * gate with >= 30x margin on both fixtures (profiles/r04_accuracy_classes.md), never used for training.  Activations must stay
+ * below 224 in magnitude (NaN beyond).  nerf_field_fwd_last_sample re-evaluates every ray's LAST sample of a pass with the
+ * three-term fp16 products (packed3 = the split = 1 repack of the same parameters) into the pass's raw: the reference's
+ * dists[-1] = 1e10 (run_nerf.py:277-278) makes that sample's alpha a step function of the sign of its density (:293), the one
+ * place where a 2^-15 error can move a ray's opacity by O(1); call it after the reduced pass, before raw2outputs. */
+int nerf_field_fwd_last_sample(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
+                               int n_samples, float* raw, void* stream);
 /* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  dgrad also leaves a tiled
  * copy of d_raw inside delta, which is what wgrad contracts with: nerf_field_wgrad_bf16x3 must be given the delta
  * buffer of nerf_field_dgrad_bf16x3 for the same d_raw (its own d_raw argument is not read).  All weight-gradient

@@ -10,33 +10,47 @@
 
 namespace nerf {
 
-template <int SAVE, typename SP>
+template <int SAVE, typename SP, bool RED = false>
 __global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_kernel(FieldFwdRingArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    field_fwd16r_tile<SAVE, SP>(a, lds, (long)blockIdx.x);
+    field_fwd16r_tile<SAVE, SP, RED>(a, lds, (long)blockIdx.x);
 }
 
-template <int SAVE, typename SP>
+template <int SAVE, typename SP, bool RED = false>
 static hipError_t launch_one(const FieldFwdRingArgs& a, unsigned blocks, hipStream_t stream) {
     static bool attr_set = false;       // (one flag per instantiation)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)field_fwd16r_kernel<SAVE, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)field_fwd16r_kernel<SAVE, SP, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((field_fwd16r_kernel<SAVE, SP>), dim3(blocks), dim3(FIELD_WAVES * 64), RING_LDS_FLOATS * 4, stream, a);
+    hipLaunchKernelGGL((field_fwd16r_kernel<SAVE, SP, RED>), dim3(blocks), dim3(FIELD_WAVES * 64), RING_LDS_FLOATS * 4, stream, a);
     return hipGetLastError();
 }
 
 // split: 0 = bf16 (packed3 from the bf16 repack), 1 = fp16 (packed3 from the fp16 repack); split_types.h
+// 2 = fp16 main term + fp8 correction terms (field_ring8.h; inference only: act must be null; packed3 from the reduced repack)
 hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                                int n_rays, int S, float* raw, float* act, int split, hipStream_t stream) {
-    FieldFwdRingArgs a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S};
+    FieldFwdRingArgs a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S, S, 0};
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((P + PTS_PER_WG - 1) / PTS_PER_WG);
+    if (split == 2) return act ? hipErrorInvalidValue : launch_one<0, SplitF16, true>(a, blocks, stream);
     if (split) return act ? launch_one<2, SplitF16>(a, blocks, stream) : launch_one<0, SplitF16>(a, blocks, stream);
     return act ? launch_one<2, SplitBF16>(a, blocks, stream) : launch_one<0, SplitBF16>(a, blocks, stream);
+}
+
+// every ray's LAST sample of a pass of S samples, three-term fp16 products, written into the pass's raw[n_rays][S][4]: the guard of
+// the reduced inference class.  The reference appends dists[-1] = 1e10 (run_nerf.py:277-278), so alpha of the last sample is a STEP
+// function of the sign of its density (:293): a density within the product class's error of zero flips a ray's opacity
+// (tools/analysis_accuracy_classes.py).  Evaluating those n_rays points (1/64 and 1/192 of the passes) in the fp32-class products
+// makes flips as rare as on the fp16x3 datapath.  packed3: the fp16 three-term repack of the same parameters.
+hipError_t launch_field_fwd16r_last(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
+                                    int n_rays, int S, float* raw, hipStream_t stream) {
+    if (n_rays <= 0) return hipSuccess;
+    FieldFwdRingArgs a{packed3, rays, z_vals, raw, nullptr, ray_stride, n_rays, 1, S, S - 1};
+    return launch_one<0, SplitF16>(a, (unsigned)((n_rays + PTS_PER_WG - 1) / PTS_PER_WG), stream);
 }
 
 }  // namespace nerf

@@ -4,7 +4,7 @@
 // fine pass, inside one launch): same code, bit-identical results.
 #pragma once
 #include <type_traits>
-#include "field_ring.h"
+#include "field_ring8.h"
 #include "launchers.h"
 
 namespace nerf {
@@ -16,6 +16,10 @@ struct FieldFwdRingArgs {
     float* raw;
     float* act;             // nullable: act_layout3, rows in 16-point bf16 tiles (row16h order)
     int ray_stride, n_rays, S;
+    // sample s of ray r reads z_vals[r * z_stride + s_off + s] and writes raw[(r * z_stride + s_off + s) * 4]: z_stride = S, s_off = 0
+    // for a whole pass; S = 1, z_stride = the pass's sample count, s_off = z_stride - 1 evaluates ONLY every ray's last sample into
+    // the pass's raw (the guard of the reduced inference class: launch_field_fwd16r_last).  Saving needs the whole-pass form.
+    int z_stride, s_off;
 };
 
 // units of the P16F stream in consumption order: L0 8 | L1..L4 4 x 32 | L5 40 | L6 L7 2 x 32 | (feature_linear 32: skipped)
@@ -29,9 +33,12 @@ static_assert((FWD16_UNITS_TRUNK + FWD16_UNITS_SKIP) * UNIT_WORDS == P16F_VIEWS,
 // One workgroup tile (8 waves x 16 points = 128 consecutive sample points, tile index `wg`) through the whole network.
 // The workgroup must have passed a barrier since its last use of `lds` (kernel start, or the caller's own __syncthreads()).
 // SP: the 16-bit type of the three-term split (split_types.h) -- of the products AND of the rows saved for the backward.
-template <int SAVE, typename SP>
+// RED (inference only, SP = SplitF16): the 256-wide contractions run as fp16 main term + fp8 correction terms (field_ring8.h) on a
+// packed buffer made by the reduced repack (nerf_pack_params_split(split = 2)).
+template <int SAVE, typename SP, bool RED = false>
 __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, float* lds, long wg) {
     static_assert(SAVE == 0 || SAVE == 2, "inference or 16-bit rows");
+    static_assert(!RED || (SAVE == 0 && SP::F16), "the reduced products are an inference form of the fp16 split");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4;
@@ -46,7 +53,8 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     stage_small_ring(a.packed3 + P3_SMALL, lds, FIELD_WAVES * 64);
 
     const float* rp = a.rays + (long)ray * a.ray_stride;
-    const float z = a.z_vals[p];
+    const long zi = (long)ray * a.z_stride + a.s_off + (p - (long)ray * a.S);
+    const float z = a.z_vals[zi];
     const float x0 = rp[0] + rp[3] * z;
     const float x1 = rp[1] + rp[4] * z;
     const float x2 = rp[2] + rp[5] * z;
@@ -137,6 +145,11 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     ring.ready();
     Frag fa, fb, fl;
     ring.request_first(fa);
+    // E8M0 scale bytes (W_hi8, W_lo8) of reduced matrix m, from the pads of the small parameters (pack8_kernel)
+    auto red_scale = [&](int m, int part) __attribute__((always_inline)) {
+        const unsigned char* sb = reinterpret_cast<const unsigned char*>(ring_small_ptr(lds, SM_BALPHA));
+        return __builtin_amdgcn_readfirstlane((int)sb[(m < 6 ? 4 + 2 * m : 28 + 2 * (m - 6)) + part]);
+    };
 
     // ---- layer 0: 63 -> 256 (2 k-steps of the xyz encoding)
     load_bias<16>(acc, bias, q);
@@ -148,7 +161,8 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
         load_bias<16>(acc, bias + l * W, q);
         if (l == SKIP + 1) ring_units<SP, 8, 4, 0, false, 0>(ring, fa, fb, fl, acc, e, no_store);
         row_region = (size_t)(l - 1) * layer_floats;
-        ring_units<SP, 32, 4, 0, false, NP>(ring, fa, fb, fl, acc, h, store_rows);
+        if constexpr (RED) ring_units8<32>(ring, fa, fb, fl, acc, h, red_scale(l - 1, 0), red_scale(l - 1, 1));
+        else ring_units<SP, 32, 4, 0, false, NP>(ring, fa, fb, fl, acc, h, store_rows);
         finish_mask(l - 1);
         take();
     }
@@ -192,7 +206,8 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
             store_word(row_region, W, nb, 2, bhi[2 * decltype(gg)::value + 1]);
             static_for<0, 4>([&](auto rc) __attribute__((always_inline)) { mask_bits(std::integral_constant<int, nb>{}, rc); });
         };
-        ring_units<SP, 16, 2, 0, false, NP>(ring, fa, fb, fl, av, h, store_rows_v);
+        if constexpr (RED) ring_units8<16>(ring, fa, fb, fl, av, h, red_scale(7, 0), red_scale(7, 1));
+        else ring_units<SP, 16, 2, 0, false, NP>(ring, fa, fb, fl, av, h, store_rows_v);
         finish_mask(D - 1);
         ring_units<SP, 2, 2, 0, false, 0>(ring, fa, fb, fl, av, dv, no_store);
     }
@@ -236,7 +251,7 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
         c1 = quarter_sum(c1) + ring_small_ptr(lds, SM_BRGB)[1];
         c2 = quarter_sum(c2) + ring_small_ptr(lds, SM_BRGB)[2];
     }
-    if (valid && q == 0) *reinterpret_cast<f32x4*>(a.raw + (size_t)p * 4) = f32x4{c0, c1, c2, sigma};
+    if (valid && q == 0) *reinterpret_cast<f32x4*>(a.raw + (size_t)zi * 4) = f32x4{c0, c1, c2, sigma};
 }
 
 }  // namespace nerf

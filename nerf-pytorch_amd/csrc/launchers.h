@@ -95,6 +95,8 @@ hipError_t launch_field_fwd16(const float* packed3, const float* rays, int ray_s
 // split (ring kernels, repack, streaming weight-gradient GEMM): 0 = bf16 three-term split, 1 = fp16 (csrc/split_types.h)
 hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                                int n_rays, int S, float* raw, float* act, int split, hipStream_t stream);
+hipError_t launch_field_fwd16r_last(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
+                                    int n_rays, int S, float* raw, hipStream_t stream);
 hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
                                 float* delta, int out16, int split, hipStream_t stream);
 

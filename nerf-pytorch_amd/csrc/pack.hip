@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include "nerf_common.h"
 #include "split_types.h"
+#include "field_ring8.h"
 
 #include "launchers.h"
 
@@ -252,6 +253,111 @@ __global__ void pack3_all_kernel(const float* __restrict__ canon_params, const f
     }
 }
 
+// ---- reduced inference stream ("fp16 main + fp8 corrections", field_ring8.h): the P16F region with the units of the 256-wide
+// contractions (layers 1..7 over their hidden inputs, the trunk part of the view branch) re-filled KIND-major per 128 contraction
+// slots; everything else in the region keeps the three-term fp16 content.
+// matrix m = 0..6: layer m + 1 (hidden-input columns), m = 7: the folded view matrix W' (derived)
+struct RedSeg { int unit0, n_units, ng, m; };
+__host__ __device__ inline bool red_segment(int unit, RedSeg* seg) {
+    // units of the P16F region: L0 [0, 8) | L1..L4 [8, 136) | L5 enc [136, 144), L5 hidden [144, 176) | L6 L7 [176, 240) | FEAT [240, 272) |
+    // VIEWS trunk [272, 288), direction [288, 290)
+    if (unit >= 8 && unit < 136) { const int l = 1 + (unit - 8) / 32; *seg = RedSeg{8 + 32 * (l - 1), 32, 4, l - 1}; return true; }
+    if (unit >= 144 && unit < 176) { *seg = RedSeg{144, 32, 4, 4}; return true; }
+    if (unit >= 176 && unit < 240) { const int l = 6 + (unit - 176) / 32; *seg = RedSeg{176 + 32 * (l - 6), 32, 4, l - 1}; return true; }
+    if (unit >= 272 && unit < 288) { *seg = RedSeg{272, 16, 2, 7}; return true; }
+    return false;
+}
+constexpr int RED_SCALE_WORD = P16F + P16F_FEAT;         // 4 words = 16 scale bytes, parked in the (skipped) feature_linear units
+// canonical (or derived) index of W_m[row][feature]
+__host__ __device__ inline int red_source(int m, int row, int feature) {
+    constexpr Canon c = canon();
+    if (m == 7) return DERIVED_WVF + row * W + feature;
+    const int l = m + 1;
+    return l == SKIP + 1 ? c.w[l] + row * (W + IN_XYZ) + IN_XYZ + feature : c.w[l] + row * W + feature;
+}
+__device__ inline float f16_hi(float x) { return (float)(_Float16)x; }
+// largest |hi16| and |x - hi16| of every reduced matrix -> E8M0 scale bytes (what the MFMA multiplies the fp8 values by):
+// byte = 127 - k, fp8 value = part * 2^k with k = 7 - floor(log2(max)): the maximum lands in [128, 256)
+__global__ __launch_bounds__(1024) void weight_scale_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived,
+                                                             float* __restrict__ packed) {
+    const int m = blockIdx.x;
+    const int rows = m == 7 ? WV : W;
+    float mh = 0.0f, ml = 0.0f;
+    for (int i = threadIdx.x; i < rows * W; i += 1024) {
+        const float x = param_or_derived(canon_params, derived, red_source(m, i / W, i % W));
+        const float h = f16_hi(x);
+        mh = fmaxf(mh, fabsf(h));
+        ml = fmaxf(ml, fabsf(x - h));
+    }
+    __shared__ float sh[16], sl[16];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, o)); ml = fmaxf(ml, __shfl_xor(ml, o)); }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = mh; sl[threadIdx.x >> 6] = ml; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) { mh = fmaxf(mh, sh[i]); ml = fmaxf(ml, sl[i]); }
+        auto scale_byte = [](float mx) {
+            const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);          // biased exponent; 0 = zero / subnormal maximum
+            const int k = e == 0 ? 0 : 7 - (e - 127);
+            return (unsigned char)max(1, min(254, 127 - k));
+        };
+        unsigned char* dst = reinterpret_cast<unsigned char*>(packed + RED_SCALE_WORD);
+        dst[2 * m] = scale_byte(mh);
+        dst[2 * m + 1] = scale_byte(ml);
+    }
+}
+// 16-bit element e16 of the P16F region of a REDUCED buffer: true if it belongs to a reduced unit (*out = its value)
+__device__ inline bool pack8_element(int e16, const float* canon_params, const float* derived, const float* packed, unsigned short* out) {
+    const int unit = e16 / 4096, r = e16 % 4096;
+    RedSeg sg;
+    if (!red_segment(unit, &sg)) return false;
+    const int v = unit - sg.unit0;
+    const int T = v / (4 * sg.ng), k = (v % (4 * sg.ng)) / sg.ng, g = v % sg.ng;
+    const int f = r / 512, lane = (r >> 3) & 63, j = r & 7;
+    const int kq = lane >> 4;
+    if (k < 2) {                        // main: frag f = 2 i + k-step of the pair, 16-bit element j of the k-step's eight
+        const int i = f >> 1, ksl = f & 1;
+        const int row = 16 * (4 * g + i) + (lane & 15);
+        const int vi = 8 * (4 * T + 2 * k + ksl) + j;
+        *out = split_hi<SplitF16>(param_or_derived(canon_params, derived, red_source(sg.m, row, hcol(vi, kq))));
+        return true;
+    }
+    // fp8: frag f = 2 jj + half; block = 2 half + (jj >> 1); 16-byte part jj & 1; this 16-bit element = bytes 2 j, 2 j + 1 of the part
+    const int half = f & 1, jj = f >> 1;
+    const int row = 16 * (4 * g + 2 * half + (jj >> 1)) + (lane & 15);
+    const int b0 = 16 * (jj & 1) + 2 * j;
+    const unsigned char sbyte = reinterpret_cast<const unsigned char*>(packed + RED_SCALE_WORD)[2 * sg.m + (k - 2)];
+    const float inv_scale = __uint_as_float((unsigned)sbyte << 23);          // 2^(byte - 127) = 2^-k: value / inv_scale = value * 2^k
+    float part[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float x = param_or_derived(canon_params, derived, red_source(sg.m, row, hcol(32 * T + b0 + t, kq)));
+        const float h = f16_hi(x);
+        part[t] = k == 2 ? h : x - h;
+    }
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    const i16x2 pk = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(i16x2{0, 0}, part[0], part[1], inv_scale, false);
+    *out = (unsigned short)pk[0];
+    return true;
+}
+// the reduced units of the P16F region + the scale bytes into the small-parameter pads the forward stages into LDS
+__global__ void pack8_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived, float* __restrict__ packed) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 2L * P16F_WORDS) {
+        unsigned short v;
+        if (pack8_element((int)idx, canon_params, derived, packed, &v)) reinterpret_cast<unsigned short*>(packed)[2L * P16F + idx] = v;
+        return;
+    }
+    if (idx == 2L * P16F_WORDS) {       // 12 + 4 scale bytes: pads behind alpha_linear.bias and rgb_linear.bias (nerf_common.h SM_*)
+        const unsigned* src = reinterpret_cast<const unsigned*>(packed + RED_SCALE_WORD);
+        unsigned* small = reinterpret_cast<unsigned*>(packed + P3_SMALL);
+        small[SM_BALPHA - SM_BIAS + 1] = src[0];
+        small[SM_BALPHA - SM_BIAS + 2] = src[1];
+        small[SM_BALPHA - SM_BIAS + 3] = src[2];
+        small[SM_BRGB - SM_BIAS + 3] = src[3];
+    }
+}
+
 hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream, int split) {
     const int threads = 256;
     float* derived = packed + P3_DERIVED;
@@ -262,6 +368,11 @@ hipError_t launch_pack3_sel(const float* canon_params, float* packed, int stream
     const dim3 grid((unsigned)((total + threads - 1) / threads));
     if (split) hipLaunchKernelGGL(pack3_all_kernel<SplitF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3f, n3b, n1b);
     else hipLaunchKernelGGL(pack3_all_kernel<SplitBF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3f, n3b, n1b);
+    if (split == 2) {       // reduced inference stream on top of the fp16 three-term stream (its narrow units and small parameters stay)
+        hipLaunchKernelGGL(weight_scale_kernel, dim3(N_RED_MATRICES), dim3(1024), 0, stream, canon_params, (const float*)derived, packed);
+        const long n8 = 2L * P16F_WORDS + 1;
+        hipLaunchKernelGGL(pack8_kernel, dim3((unsigned)((n8 + threads - 1) / threads)), dim3(threads), 0, stream, canon_params, (const float*)derived, packed);
+    }
     return hipGetLastError();
 }
 

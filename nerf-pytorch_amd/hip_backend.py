@@ -64,6 +64,7 @@ def _declare(lib):
         "nerf_pack_params_split": (i, [p, p, i, i, p]),
         "nerf_field_fwd_split": (i, [p, p, i, p, i, i, p, p, i, p]),
         "nerf_field_dgrad_split": (i, [p, p, p, i, i, p, i, p]),
+        "nerf_field_fwd_last_sample": (i, [p, p, i, p, i, i, p, p]),
         "nerf_debug_pack16_table": (i, [p]),
         "nerf_field_dgrad_mixed": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p, p]),
@@ -95,7 +96,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_pack_params_bf16x3_sel", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
            "nerf_field_dgrad_bf16x3", "nerf_field_dgrad3r_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_field_fwd16r_bf16x3", "nerf_debug_pack16_table",
-           "nerf_pack_params_split", "nerf_field_fwd_split", "nerf_field_dgrad_split",
+           "nerf_pack_params_split", "nerf_field_fwd_split", "nerf_field_dgrad_split", "nerf_field_fwd_last_sample",
            "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step",
            "nerf_render_workspace_floats", "nerf_render_rays_fwd", "nerf_render_rays_bwd", "nerf_render_infer_supported",
            "nerf_render_rays_infer", "nerf_mse_scratch_floats", "nerf_mse_fwd", "nerf_mse_bwd", "nerf_build_inputs", "nerf_dense_fwd", "nerf_dense_dgrad", "nerf_dense_wgrad_scratch_floats",
@@ -233,8 +234,11 @@ def pack_table():
 # one bf16 MFMA per product in dgrad and wgrad (fp32 accumulation).  A training-speed option, not a parity datapath.
 # "fp16x3" (round 4) = the same three-term split with IEEE-half parts (csrc/split_types.h): ~2^-22 per product instead of 2^-17
 # and 11-bit instead of 8-bit operands for the weight-gradient GEMM, at the bf16 MFMA count; needs |activations| < 65520.
-PRECISIONS = ("fp32", "bf16x3", "mixed", "fp16x3")
-SPLIT = ("bf16x3", "mixed", "fp16x3")       # datapaths on the three-term-split kernels (folded feature layer, tiled saves)
+# "fp16_fp8c" (round 4, INFERENCE class): no_grad rendering with every product of the 256-wide layers as fp16 main term + two fp8
+# correction terms (csrc/field_ring8.h: ~2^-15 per product, 2 instead of 3 MFMA-equivalents; every ray's last sample re-evaluated
+# with the three-term fp16 products); anything that needs gradients runs the fp16x3 datapath unchanged.  Never the bench headline.
+PRECISIONS = ("fp32", "bf16x3", "mixed", "fp16x3", "fp16_fp8c")
+SPLIT = ("bf16x3", "mixed", "fp16x3", "fp16_fp8c")       # datapaths on the three-term-split kernels (folded feature layer, tiled saves)
 
 
 def pack_table3():
@@ -300,6 +304,11 @@ def _small_offset():
 
 def pack_params(flat, out=None, precision="fp32"):
     L = lib()
+    if precision == "fp16_fp8c":    # the reduced inference stream (fp16 main + fp8 correction fragments) in the 16-point forward stream's slot
+        if out is None:
+            out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
+        _check(L.nerf_pack_params_split(_ptr(flat, "params"), _ptr(out, "packed"), 1, 2, _stream()), "nerf_pack_params_split")
+        return out
     if precision == "fp16x3":       # fp16 (hi, lo) fragments: the 16-point forward stream and the transposed streams of the delta chain
         if out is None:
             out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
@@ -501,12 +510,12 @@ INFER_ONE_LAUNCH = os.environ.get("NERF_INFER_ONE_LAUNCH", "1") != "0"
 
 def render_cfg(n_coarse, n_fine, lindisp, white_bkgd, raw_noise_std, precision):
     return NerfRenderCfg(int(n_coarse), int(n_fine), int(bool(lindisp)), int(bool(white_bkgd)), float(raw_noise_std),
-                         {"fp32": 0, "bf16x3": 1, "mixed": 2, "fp16x3": 3}[precision], int(WGRAD_OPERANDS == "bf16"))
+                         {"fp32": 0, "bf16x3": 1, "mixed": 2, "fp16x3": 3, "fp16_fp8c": 3}[precision], int(WGRAD_OPERANDS == "bf16"))
 
 
 def render_infer_supported(n_coarse, n_fine, precision):
     """whether nerf_render_rays_infer takes these sample counts on this datapath"""
-    if precision == "fp32":
+    if precision in ("fp32", "fp16_fp8c"):      # (the reduced class runs the chain of launches: its last-sample guard sits between them)
         return False
     cfg = render_cfg(n_coarse, n_fine, 0, 0, 0.0, precision)
     return bool(lib().nerf_render_infer_supported(ctypes.byref(cfg)))
@@ -540,7 +549,8 @@ def render_rays_infer(packed_c, packed_f, rays, n_coarse, n_fine, lindisp, white
     return {"rgb_f": rgb, "disp_f": disp, "acc_f": acc, "raw_f": raw, "rgb_c": rgb0, "disp_c": disp0, "acc_c": acc0, "z_std": z_std}
 
 
-def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
+def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32", guard_packed=None):
+    """guard_packed (precision "fp16_fp8c"): the fp16x3 repack of the same parameters for the last-sample guard"""
     n, stride = rays.shape
     S = z_vals.shape[1]
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
@@ -549,6 +559,18 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32"):
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in SPLIT:
         nbytes = BYTES_ACT3_PER_POINT * n * S if save_act else 16.0 * n * S
+    if precision == "fp16_fp8c":
+        if save_act:
+            raise NerfHipError("field_fwd: \"fp16_fp8c\" is an inference class (no saved activations); train on \"fp16x3\"")
+        if guard_packed is None:
+            raise NerfHipError("field_fwd: \"fp16_fp8c\" needs guard_packed= (the fp16x3 repack) for the last-sample guard")
+        with _timed("field_fwd16r_kernel<fp16 + fp8c>", FLOP_FWD3_PER_POINT * n * S, nbytes):
+            _check(lib().nerf_field_fwd_split(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                              n, S, _ptr(raw), None, 2, _stream()), "nerf_field_fwd_split")
+        with _timed("field_fwd16r_kernel<fp16> (last samples)", FLOP_FWD3_PER_POINT * n, 16.0 * n):
+            _check(lib().nerf_field_fwd_last_sample(_ptr(guard_packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                                    n, S, _ptr(raw), _stream()), "nerf_field_fwd_last_sample")
+        return raw, act
     if precision == "fp16x3":
         with _timed("field_fwd16r_kernel<fp16" + (", save>" if save_act else ">"), FLOP_FWD3_PER_POINT * n * S,
                     BYTES_ACT3_BF16_PER_POINT * n * S if save_act else nbytes):

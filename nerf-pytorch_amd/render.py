@@ -18,7 +18,9 @@ _PRECISION = __import__("os").environ.get("NERF_PRECISION", "fp32")
 
 
 def set_precision(mode):
-    """Select the field datapath: "fp32" (exact fp32 MFMA, the parity anchor), "bf16x3" (split-bf16 MFMA,
+    """Select the field datapath ("fp16x3": the three-term split with fp16 parts, fp32-class, the bench headline; "fp16_fp8c":
+    fp16x3 for everything that needs gradients and the reduced fp16 + fp8-correction products for no_grad rendering; see
+    hip_backend.PRECISIONS): "fp32" (exact fp32 MFMA, the parity anchor), "bf16x3" (split-bf16 MFMA,
     fp32 accumulate, ~1e-5 relative error; judged by the PSNR-delta criterion) or "mixed" (the bf16x3 forward,
     bit-identical outputs, with a bf16 backward: saved activations / deltas rounded to bf16, single bf16 MFMA
     products in dgrad / wgrad -- a mixed-precision training option)."""
@@ -76,8 +78,11 @@ class _FieldQuery(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, z_vals, need, *params):
         prec = _PRECISION
+        if prec == "fp16_fp8c" and need:        # the reduced class is an inference form; gradients: the fp16x3 datapath
+            prec = "fp16x3"
         packed = model.packed_params(prec)
-        raw, act = hb.field_fwd(packed, rays, z_vals, save_act=need, precision=prec)
+        raw, act = hb.field_fwd(packed, rays, z_vals, save_act=need, precision=prec,
+                                guard_packed=model.packed_params("fp16x3") if prec == "fp16_fp8c" else None)
         ctx.model, ctx.packed, ctx.act, ctx.prec, ctx.saved_any = model, packed, act, prec, bool(need)
         ctx.param_state = _param_state(model)
         ctx.set_materialize_grads(False)
@@ -124,9 +129,10 @@ def _field_pass(cfg, rays, rnd, model_c, model_f, save):
     dev = rays.device
     std, wb, prec = cfg["raw_noise_std"], cfg["white_bkgd"], cfg.get("precision", "fp32")
     r = {}
+    guard = (lambda m: m.packed_params("fp16x3")) if prec == "fp16_fp8c" else (lambda m: None)
     r["packed_c"] = model_c.packed_params(prec)
     r["z_c"] = hb.sample_coarse(rays, _linspace01(n_c, dev), cfg["lindisp"], rnd.get("t_rand"))
-    r["raw_c"], r["act_c"] = hb.field_fwd(r["packed_c"], rays, r["z_c"], save_act=save, precision=prec)
+    r["raw_c"], r["act_c"] = hb.field_fwd(r["packed_c"], rays, r["z_c"], save_act=save, precision=prec, guard_packed=guard(model_c))
     r["rgb_c"], r["disp_c"], r["acc_c"], w_c, _ = hb.raw2outputs(r["raw_c"], r["z_c"], rays, rays.shape[1], rnd.get("noise_c"), std, wb,
                                                               want_weights=n_f > 0, want_depth=False, rays_d_offset=3)
     if n_f <= 0:
@@ -135,7 +141,7 @@ def _field_pass(cfg, rays, rnd, model_c, model_f, save):
     r["z_f"], r["z_std"], _ = hb.sample_fine(r["z_c"], w_c, n_f, u, None if u is not None else _linspace01(n_f, dev))
     mf = model_c if (model_f is None or model_f is model_c) else model_f
     r["packed_f"] = mf.packed_params(prec)
-    r["raw_f"], r["act_f"] = hb.field_fwd(r["packed_f"], rays, r["z_f"], save_act=save, precision=prec)
+    r["raw_f"], r["act_f"] = hb.field_fwd(r["packed_f"], rays, r["z_f"], save_act=save, precision=prec, guard_packed=guard(mf))
     r["rgb_f"], r["disp_f"], r["acc_f"], _, _ = hb.raw2outputs(r["raw_f"], r["z_f"], rays, rays.shape[1], rnd.get("noise_f"), std, wb,
                                                              want_weights=False, want_depth=False, rays_d_offset=3)
     return r
@@ -514,6 +520,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         params = params + network_fine.param_list()
     # activations are saved only when a backward can follow (Function.forward itself always runs in no-grad mode)
     cfg["need_grad"] = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    if cfg["precision"] == "fp16_fp8c" and cfg["need_grad"]:
+        cfg["precision"] = "fp16x3"         # the reduced class is an inference form; gradients: the fp16x3 datapath, unchanged
     outs = _RenderRays.apply(cfg, rays, rnd, network_fn, None if (same or n_f <= 0) else network_fine, *params)
     if n_f <= 0:
         rgb_map, disp_map, acc_map, raw = outs

@@ -263,3 +263,58 @@ def test_fp16x3_overflow_is_loud(npa, dev, nets):
     assert not bool(torch.isfinite(raw).all())
     raw_b, _ = hb.field_fwd(big.packed_params("bf16x3"), rays, z, save_act=False, precision="bf16x3")
     assert bool(torch.isfinite(raw_b).all())
+
+
+# ---------------------------------------------------------------- reduced inference class: fp16 main term + fp8 correction terms
+@pytest.mark.parametrize("n_rays,S", [(64, 64), (37, 192), (5, 3), (1, 1), (129, 70)])
+def test_reduced_forward_against_fp64_and_the_last_sample_guard(npa, dev, nets, n_rays, S):
+    """set_precision("fp16_fp8c"), no_grad: every product of the 256-wide layers = W_hi16 x_hi16 (fp16 MFMA) + W_hi8 x_lo8 +
+    W_lo8 x_hi8 (fp8 e4m3 MFMAs of K = 128, power-of-two scales) -- csrc/field_ring8.h.  raw vs the fp64 oracle within 2e-4 of
+    |raw|max (the class: ~2^-15 per product; fp16x3 holds 2e-5, bf16x3 3e-4), and every ray's LAST sample is the fp16x3 value bit
+    for bit (nerf_field_fwd_last_sample: the reference's dists[-1] = 1e10 turns that sample's sign into a step of the opacity)."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    rays = orc.synthetic_rays(n_rays, seed=S)
+    z = torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4.0 + 2.0, -1)[0]
+    raw3, _ = hb.field_fwd(nf.packed_params("fp16x3"), rays.to(dev), z.to(dev), save_act=False, precision="fp16x3")
+    raw8, _ = hb.field_fwd(nf.packed_params("fp16_fp8c"), rays.to(dev), z.to(dev), save_act=False, precision="fp16_fp8c",
+                           guard_packed=nf.packed_params("fp16x3"))
+    assert torch.equal(raw8[:, -1], raw3[:, -1])
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None])
+    ref64 = orc.query_field({k: v.double() for k, v in Pf.items()}, pts.double(), rays[:, 8:11].double())
+    scale = max(1.0, float(ref64.abs().max()))
+    err8, err3 = maxdiff(raw8, ref64), maxdiff(raw3, ref64)
+    print(f"reduced class raw vs fp64: {err8:.2e} (fp16x3: {err3:.2e}), |raw|max {scale:.1f}")
+    assert err8 <= 2e-4 * scale, (err8, scale)
+    if S > 1:
+        assert not torch.equal(raw8[:, :-1], raw3[:, :-1])          # (it IS another product class)
+    with pytest.raises(hb.NerfHipError):
+        hb.field_fwd(nf.packed_params("fp16_fp8c"), rays.to(dev), z.to(dev), save_act=True, precision="fp16_fp8c", guard_packed=nf.packed_params("fp16x3"))
+
+
+def test_reduced_class_renders_without_gradients_and_trains_on_fp16x3(npa, dev, nets):
+    """render_rays under set_precision("fp16_fp8c"): no_grad -> the reduced products (close to, not equal to, fp16x3's image);
+    with gradients enabled -> the fp16x3 datapath itself: outputs and both networks' gradients bit-identical to fp16x3's."""
+    nc, nf, Pc, Pf = nets
+    rays = orc.synthetic_rays(200, seed=77).to(dev)
+    target = torch.rand(200, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    kw = dict(N_samples=64, N_importance=128, network_fine=nf, white_bkgd=True, retraw=True)
+    out, grads = {}, {}
+    for prec in ("fp16x3", "fp16_fp8c"):
+        npa.set_precision(prec)
+        try:
+            with torch.no_grad():
+                out[prec] = npa.render_rays(rays, nc, None, **kw)
+            for m in (nc, nf):
+                m.zero_grad()
+            o = npa.render_rays(rays, nc, None, **kw)
+            (npa.img2mse(o["rgb_map"], target) + npa.img2mse(o["rgb0"], target)).backward()
+            grads[prec] = (o["rgb_map"].detach().clone(), nc.last_flat_grad.clone(), nf.last_flat_grad.clone())
+        finally:
+            npa.set_precision("fp32")
+    for a, b in zip(grads["fp16x3"], grads["fp16_fp8c"]):
+        assert torch.equal(a, b)
+    d = maxdiff(out["fp16_fp8c"]["rgb0"], out["fp16x3"]["rgb0"])
+    assert 0.0 < d <= 3e-4, d
+    ref = orc.trace_rays(rays.cpu(), Pc, Pf, 64, 128, white_bkgd=True)
+    assert maxdiff(out["fp16_fp8c"]["rgb0"], ref["rgb0"]) <= 3e-4

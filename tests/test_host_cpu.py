@@ -243,9 +243,9 @@ def test_frame_sink_orders_frames_and_writes_the_same_pngs(tmp_path):
 
 
 def test_precision_selection_and_saved_row_views():
-    """set_precision accepts the four datapaths and rejects anything else; saved_rows inverts the tile layout of
+    """set_precision accepts the five datapaths and rejects anything else; saved_rows inverts the tile layout of
     csrc/nerf_common.h (element (p, f) of an F-wide region at (p/32)*F*32 + f*32 + p%32, fp32 or bf16)."""
-    assert npa.hip_backend.PRECISIONS == ("fp32", "bf16x3", "mixed", "fp16x3")
+    assert npa.hip_backend.PRECISIONS == ("fp32", "bf16x3", "mixed", "fp16x3", "fp16_fp8c")
     prev = npa.get_precision()
     try:
         for mode in npa.hip_backend.PRECISIONS:

@@ -14,6 +14,9 @@ Per class (every product W x of the 8x256 trunk + feature + view layers; heads e
               in the time of K = 64 fp16)
   fp16+fp6c   corrections as fp6 e2m3 x fp6 e2m3 (4 significant bits, the fp4 rate on MI355X): 1 + 2 x 1/4 = 1.5 MFMA-equivalents
   fp16+fp8c-fixed  the same with ONE fixed power-of-two scale per operand kind instead of per-block scales (no maxima to compute)
+  fp16+f8c-kernel  the variant the reduced inference forward computes: activation parts e4m3 with fixed scales (x_hi * 2, x_lo * 2^12),
+              weight parts e4m3 with one power-of-two scale per matrix and part
+  fp16+e5m2c  activation parts as e5m2 instead (cannot overflow, 3 significant bits): measured too coarse (83 dB, a flip on lego)
   bf16+fp8c   bf16 main + fp8 corrections: ~2^-12
   fp16        plain fp16 operands, one MFMA per product (2^-11)
   tf32/bf16   input rounded to 10 / 7 mantissa bits, weights exact (round 3's table)
@@ -80,6 +83,18 @@ def q8_fixed(v, log2_scale):
     return t.to(torch.float8_e4m3fn).float() * 2.0 ** -log2_scale
 
 
+def q5_fixed(v, log2_scale):
+    """bf8 = fp8 e5m2 (3 significant bits, fp16's exponent range) with one fixed power-of-two scale"""
+    t = (v.float() * 2.0 ** log2_scale).clamp(-57344.0, 57344.0)
+    return t.to(torch.float8_e5m2).float() * 2.0 ** -log2_scale
+
+
+def q8_layer(W):
+    """e4m3 with ONE power-of-two scale per weight matrix, from its largest magnitude (computed at pack time): max -> [128, 256)"""
+    k = 7 - int(torch.floor(torch.log2(W.abs().max().clamp_min(1e-30))))
+    return q8_fixed(W, k)
+
+
 def mm(a, b):
     """x [M,K] (parts) times W [N,K]^T, accumulated exactly (fp64), as the MFMA's fp32 accumulator nearly does"""
     return a.double() @ b.double().t()
@@ -106,6 +121,17 @@ def product(x, W, cls):
         xh, xl = split(x, torch.float16)
         Wh, Wl = split(W, torch.float16)
         return mm(xh, Wh) + mm(q8_fixed(xl, 14), q8_fixed(Wh, 6)) + mm(q8_fixed(xh, 2), q8_fixed(Wl, 18))
+    if cls == "fp16+f8c-kernel":
+        # what the reduced inference forward computes: activation parts as e4m3 with FIXED scales (x_hi * 2, x_lo * 2^12: defined for
+        # |x| < 224, NaN beyond), weight parts as e4m3 with one power-of-two scale per matrix and part (from its maximum, at pack time)
+        xh, xl = split(x, torch.float16)
+        Wh, Wl = split(W, torch.float16)
+        return mm(xh, Wh) + mm(q8_fixed(xl, 12), q8_layer(Wh)) + mm(q8_fixed(xh, 1), q8_layer(Wl))
+    if cls == "fp16+e5m2c":
+        # activation parts as e5m2 (3 significant bits; fp16's exponent range, nothing can overflow): too coarse -- 83 dB on lego
+        xh, xl = split(x, torch.float16)
+        Wh, Wl = split(W, torch.float16)
+        return mm(xh, Wh) + mm(q5_fixed(xl, 4), q8_layer(Wh)) + mm(q5_fixed(xh, 0), q8_layer(Wl))
     if cls == "fp16":
         return mm(x.half().float(), W.half().float())
     if cls in ("tf32", "bf16"):
@@ -184,7 +210,7 @@ def psnr_delta(rgb, ref, tgt, keep=None):
 
 def main():
     quick = "--quick" in sys.argv
-    classes = ["fp64", "bf16x3", "fp16x3", "fp16+fp8c", "fp16+fp8c-fixed", "fp16+fp6c", "bf16+fp8c", "fp16", "tf32", "bf16"]
+    classes = ["fp64", "bf16x3", "fp16x3", "fp16+fp8c", "fp16+fp8c-fixed", "fp16+f8c-kernel", "fp16+fp6c", "bf16+fp8c", "fp16", "tf32", "bf16"]
     only = [a.split("=")[1] for a in sys.argv if a.startswith("--only=")]
     if only:
         classes = [c for c in classes if c in only[0].split(",")]
