@@ -56,8 +56,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense 16-bit MFMA (bf16 and fp16 run at th
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (~6.3 TB/s achievable, MI355X_MICROARCH.md)
 DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products W_hi x_hi + W_hi x_lo + W_lo x_hi in the forward and the delta chain, f32 "
                                         "accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are stored as "
-                                        "bf16 and multiplied exactly, f32 accumulate — NERF_WGRAD_OPERANDS=fp32 stores and splits fp32)",
-              "mixed": "bf16x3 forward + bf16 backward (mixed-precision training option)",
+                                        "bf16 (8 significant bits) and multiplied exactly, f32 accumulate)",
               "fp16_fp8c": "fp16 main term + fp8 (e4m3) correction terms per product, inference only (gradients: fp16x3)",
               "fp16x3": "fp16x3 (split-fp16 MFMA products W_hi x_hi + W_hi x_lo + W_lo x_hi, hi = fp16(v), lo = fp16(v - hi): ~2^-22 per product, in the "
                         "forward and the delta chain, f32 accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are the "
@@ -75,7 +74,7 @@ def parse_args(argv=None):
     ap.add_argument("--rays", type=int, default=N_RAND, help="rays per GPU per step (weak scaling)")
     ap.add_argument("--frame", type=int, default=800, help="render_only: frame side in pixels")
     ap.add_argument("--chunk", type=int, default=1024 * 32)
-    ap.add_argument("--precision", choices=["fp32", "bf16x3", "mixed", "fp16x3", "fp16_fp8c"], default=os.environ.get("NERF_BENCH_PRECISION", "fp16x3"),
+    ap.add_argument("--precision", choices=["fp32", "fp16x3", "bf16x3", "fp16_fp8c"], default=os.environ.get("NERF_BENCH_PRECISION", "fp16x3"),
                     help="headline field datapath.  fp16x3 (default) = three-term split with fp16 parts (3 MFMAs per product, ~2^-22 per product, "
                          "fp32 accumulate / activations / gradients, 11-bit operands for the weight-gradient GEMM); bf16x3 = the same with bf16 parts "
                          "(2^-17, 8-bit operands: rounds 1-3); both admitted by the north-star PSNR criterion, which this run re-measures and "
@@ -332,7 +331,7 @@ def _kernel_class(name):
     if fwd:
         return (2.0 if "fp8c" in name else 3.0), (MAC_FWD - MAC_FOLD) / MAC_FWD, PEAK_BF16_MFMA_TFLOPS
     if name.startswith(("field_dgrad3_kernel", "field_dgrad3r_kernel")):
-        return (1.0 if "<mixed>" in name else 3.0), (MAC_DGRAD - MAC_FOLD) / MAC_DGRAD, PEAK_BF16_MFMA_TFLOPS
+        return 3.0, (MAC_DGRAD - MAC_FOLD) / MAC_DGRAD, PEAK_BF16_MFMA_TFLOPS
     if name.startswith("wgrad1_kernel"):
         return 1.0, (MAC_WGRAD - MAC_FOLD) / MAC_WGRAD, PEAK_BF16_MFMA_TFLOPS
     if name.startswith("wgrad3_256_kernel"):
@@ -379,7 +378,7 @@ def _profile_row_matches(timer_name, prof_name):
         want = "2" if ("<save bf16>" in timer_name or (f16 and "save" in timer_name)) else ("1" if "<save" in timer_name else "0")
         return first == want
     if key in ("field_dgrad3_kernel", "field_dgrad3r_kernel"):
-        want = "1" if "<mixed>" in timer_name else ("2" if ("<bf16 out>" in timer_name or f16) else "0")
+        want = "2" if ("<bf16 out>" in timer_name or f16) else "0"
         return first == want
     return True
 
@@ -388,7 +387,7 @@ def pmc_traffic(kernel_name, precision):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary of this same command (separate --pmc
     passes; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the
     process, so this is the profile of the same command committed under profiles/ (None if absent)."""
-    tag = {"bf16x3": "bf16x3_", "mixed": "mixed_", "fp16x3": "fp16x3_"}.get(precision, "")
+    tag = {"bf16x3": "bf16x3_", "fp16x3": "fp16x3_"}.get(precision, "")
     for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}pmc_summary.csv")
         if os.path.exists(path):
@@ -500,7 +499,7 @@ def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024, which=None):
         m.load_state_dict(P)
         return m
     rk = dict(N_samples=64, N_importance=128, white_bkgd=True, raw_noise_std=0.)
-    prev_prec, prev_ops = npa.get_precision(), hb.WGRAD_OPERANDS
+    prev_prec = npa.get_precision()
     results = {}
     try:
         for seed in seeds:
@@ -528,12 +527,9 @@ def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024, which=None):
                                        f"nan {int(torch.isnan(out).sum())}, target [{float(tgt_held.min())}, {float(tgt_held.max())}], "
                                        f"same storage {out.data_ptr() == tgt_held.data_ptr()}")
                 return -10 * math.log10(mse)
-            for name, prec, operands in (("fp32", "fp32", None), ("fp32_twin", "fp32", None), ("fp16x3", "fp16x3", None), ("bf16x3", "bf16x3", "bf16"),
-                                         ("bf16x3_fp32_operands", "bf16x3", "fp32"), ("mixed", "mixed", None)):
+            for name, prec in (("fp32", "fp32"), ("fp32_twin", "fp32"), ("fp16x3", "fp16x3"), ("bf16x3", "bf16x3")):
                 if which is not None and name not in which:
                     continue
-                if operands is not None:
-                    hb.WGRAD_OPERANDS = operands
                 torch.manual_seed(seed)
                 nc, nf = net(Sc), net(Sf)
                 if name == "fp32_twin":
@@ -553,10 +549,8 @@ def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024, which=None):
                     (npa.img2mse(out["rgb_map"], tgt_pool[idx]) + npa.img2mse(out["rgb0"], tgt_pool[idx])).backward()
                     opt.step()
                 results.setdefault(name, []).append(psnr(nc, nf))
-                hb.WGRAD_OPERANDS = prev_ops
     finally:
         npa.set_precision(prev_prec)
-        hb.WGRAD_OPERANDS = prev_ops
     table = {}
     for name, vals in results.items():
         table[name] = {"psnr_db_per_seed": [round(v, 3) for v in vals], "mean_db": sum(vals) / len(vals), "spread_db": max(vals) - min(vals),
@@ -683,15 +677,15 @@ class Session:
             with torch.no_grad():
                 rgb_g = npa.render(self.H, self.W, self.K, chunk=self.args.chunk, rays=gbatch, **kwargs)[0]
             gate = wl.precision_gate(rgb_g, torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"]))
-            if with_operands and ((precision == "bf16x3" and hb.WGRAD_OPERANDS == "bf16") or precision == "fp16x3"):
-                # the one place this datapath stores less than fp32: the operands of the weight-gradient GEMM (bf16, RNE).
-                # Gradient of the training loss against the fixture's target, this storage vs fp32 storage (same kernels
-                # otherwise; tests/test_gpu_parity.py test_bf16_operand_storage_* hold the 4096-ray batch to <= 3e-4)
+            if with_operands and precision in ("bf16x3", "fp16x3"):
+                # the one place these datapaths store less than fp32: the operands of the weight-gradient GEMM (the stored hi words:
+                # 11 / 8 significant bits).  Gradient of the training loss against the fixture's target, this datapath vs the EXACT-fp32
+                # datapath (the distance also contains the hierarchical sampling's sensitivity to forward rounding; the isolated
+                # operand-rounding measurement is tests/test_gpu_fp16x3.py::test_split_backward_under_a_training_losss_upstream_gradient:
+                # 1.9e-5 fp16 / 1.6e-4 bf16 of the gradient vs fp64)
                 tgt = torch.tensor(gold["target"]).to(dev)
 
-                def grads_with(operands, prec=precision):
-                    before = hb.WGRAD_OPERANDS
-                    hb.WGRAD_OPERANDS = operands
+                def grads_with(prec):
                     npa.set_precision(prec)
                     try:
                         for m in gate_nets:
@@ -700,16 +694,12 @@ class Session:
                         (npa.img2mse(rgb, tgt) + npa.img2mse(ex["rgb0"], tgt)).backward()
                         return torch.cat([gate_nets[0].last_flat_grad, gate_nets[1].last_flat_grad]).double()
                     finally:
-                        hb.WGRAD_OPERANDS = before
                         npa.set_precision(precision)
-                # reference point: the split-bf16 chain with fp32 operand storage (round 3's fp32-class gradient)
-                g16, g32 = grads_with("bf16"), grads_with("fp32", "bf16x3")
-                gate["wgrad_operands"] = {
-                    "stored_as": ("fp16 hi words of the fp16 split (11 significant bits); compared with the split-bf16 chain storing fp32 operands, so the "
-                                  "difference also contains the two chains' own product errors (2^-22 vs 2^-17)") if precision == "fp16x3" else
-                                 "bf16 (forward and delta chain: 3-term split-bf16 arithmetic, unchanged)",
-                    "gradient_rel_l2_vs_fp32_operand_storage": float((g16 - g32).norm() / g32.norm()),
-                    "gradient_cosine_deficit": 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm())), "rays": 1024}
+                g16, g32 = grads_with(precision), grads_with("fp32")
+                gate["gradient"] = {
+                    "rel_l2_vs_fp32_datapath": float((g16 - g32).norm() / g32.norm()),
+                    "cosine_deficit": 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm())), "rays": 1024,
+                    "what": "training-loss gradient of both networks on the gate fixture, this datapath vs the exact-fp32 datapath"}
         finally:
             npa.set_precision(prev)
         gate.update(datapath=precision, rays=1024, bar_psnr_delta_db=0.01,
@@ -827,7 +817,7 @@ def main():
         multi = {"rccl_ranks_seen": parallel.ranks_seen()}
 
     # ---- secondary numbers of the same run (never the headline)
-    other_infer = infer_chain = second = second_mixed = fp32_operands = None
+    other_infer = infer_chain = second = None
     if args.mode == "train":
         k_inf = max(5, args.steps // 2)
         el_i, _ = measure(args.precision, k_inf, 2, ses.infer_step, with_kernels=False)
@@ -854,24 +844,6 @@ def main():
         tab2 = kernel_table(kern2)
         second = {"dtype": DTYPE_NAME[p2].split(" ")[0], "value": n * world * k2 / el2, "unit": "rays/s",
                   "steps": k2, "ms_per_step": 1e3 * el2 / k2, "roofline": roofline_of(tab2), "kernels": _brief(tab2)}
-        if args.mode == "train" and args.precision != "mixed":
-            k3 = max(4, args.steps // 2)
-            el3, kern3 = measure("mixed", k3, 2, step, with_kernels=True)
-            second_mixed = {"dtype": "bf16x3 forward (outputs identical to the bf16x3 datapath) + bf16 backward (saved activations / "
-                                     "deltas rounded to bf16, one bf16 MFMA per product, f32 accumulate); gradients are NOT fp32-class",
-                            "value": n * world * k3 / el3, "unit": "rays/s", "steps": k3, "ms_per_step": 1e3 * el3 / k3,
-                            "kernels": _brief(kernel_table(kern3))}
-        if args.mode == "train" and args.precision == "bf16x3" and hb.WGRAD_OPERANDS == "bf16":
-            # the same datapath with the operands of the weight-gradient GEMM stored as fp32 (every gradient fp32-class)
-            hb.WGRAD_OPERANDS = "fp32"
-            try:
-                k4 = max(4, args.steps // 2)
-                el4, kern4 = measure("bf16x3", k4, 2, step, with_kernels=True)
-            finally:
-                hb.WGRAD_OPERANDS = "bf16"
-            fp32_operands = {"dtype": "bf16x3 with NERF_WGRAD_OPERANDS=fp32 (saved activations and deltas fp32, split by the weight-gradient GEMM)",
-                             "value": n * world * k4 / el4, "unit": "rays/s", "steps": k4, "ms_per_step": 1e3 * el4 / k4,
-                             "kernels": _brief(kernel_table(kern4))}
     npa.set_precision(args.precision)
     default_run = (world == 1 and args.mode == "train" and args.config == "lego" and not args.strong and not args.no_configs
                    and args.rays == N_RAND)
@@ -951,13 +923,6 @@ def main():
             if not args.no_gate and rank == 0:
                 g = ses.gate("bf16x3", with_operands=False)
                 out["precision_gate"] = None if g is None else {k: g[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed")}
-            # ... and with fp32 operand storage (round 3's fp32-class-gradient leg)
-            hb.WGRAD_OPERANDS = "fp32"
-            try:
-                el4, _ = measure("bf16x3", kb, 2, step, with_kernels=False)
-            finally:
-                hb.WGRAD_OPERANDS = "bf16"
-            out["fp32_operand_storage"] = {"value": n * world * kb / el4, "ms_per_step": 1e3 * el4 / kb}
             return out
         bf16x3_leg = _guarded(errors, "bf16x3_datapath", _b3)
         npa.set_precision(args.precision)
@@ -1071,10 +1036,6 @@ def main():
                                              "vs sample_coarse -> field forward -> composite -> sample_fine -> field forward -> composite"}
         if second is not None:
             line["other_datapath"] = second
-        if second_mixed is not None:
-            line["mixed_precision_training"] = second_mixed
-        if fp32_operands is not None:
-            line["fp32_operand_storage"] = fp32_operands
         if bf16x3_leg is not None:
             line["bf16x3_datapath"] = bf16x3_leg
         if reduced_infer is not None:
@@ -1092,11 +1053,8 @@ def main():
             line["speedup_vs_rocm_eager"] = {"headline": value / ref}
             if second is not None:
                 line["speedup_vs_rocm_eager"][second["dtype"]] = second["value"] / ref
-            if fp32_operands is not None:
-                line["speedup_vs_rocm_eager"]["fp32_operands"] = fp32_operands["value"] / ref
             if bf16x3_leg is not None:
                 line["speedup_vs_rocm_eager"]["bf16x3"] = bf16x3_leg["value"] / ref
-                line["speedup_vs_rocm_eager"]["bf16x3_fp32_operands"] = bf16x3_leg["fp32_operand_storage"]["value"] / ref
             if sustained is not None:
                 line["speedup_vs_rocm_eager"]["sustained"] = sustained["train"]["rays_per_s"] / ref
             if reduced_infer is not None:

@@ -131,59 +131,40 @@ int nerf_field_dgrad(const float* packed, const float* act, const float* d_raw, 
 int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                      float* partial, float* grad, int accumulate, void* stream);
 
-/* ---- split-bf16 ("bf16x3") datapath of the same functions: every product W*x is evaluated as
- * W_hi*x_hi + W_hi*x_lo + W_lo*x_hi on bf16 MFMA with fp32 accumulation (~1e-5 relative error per product,
- * judged by the PSNR-delta criterion instead of the fp32 tolerances).  Parameters are repacked into (hi, lo)
- * bf16 fragment streams of nerf_packed3_floats() 32-bit words.  The save buffers (act, delta) of this datapath hold
- * 32-point feature-major tiles instead of point-major rows (element (p, f) of an F-wide region at
- * (p/32)*F*32 + f*32 + p%32, sized for n_rays*n_samples rounded up to 32; nerf_act_floats / nerf_delta_floats
- * cover both datapaths), and the ReLU bitmask words are in this datapath's lane order: forward and backward of one
- * evaluation must use the same datapath. */
+/* ---- the three-term SPLIT datapaths of the same functions (ABI v7; csrc/split_types.h): every product W x of the MLP is evaluated
+ * as  W_hi x_hi + W_hi x_lo + W_lo x_hi  on 16-bit MFMAs with fp32 accumulation, hi = T(v), lo = T(v - hi):
+ *   split = 1, T = IEEE half ("fp16x3", the host code's default): v_mfma_f32_16x16x32_f16 / 32x32x16_f16, ~2^-22 per product --
+ *              fp32-class; the rows / deltas saved for the weight-gradient GEMM are the hi words (11 significant bits);
+ *   split = 0, T = bfloat16 ("bf16x3"): ~2^-17 per product, 8-bit saved operands; fp32's exponent range (no overflow possible).
+ * Judged by the north-star PSNR criterion (measured: 4e-6 / 2.4e-4 dB) and by fp64 comparisons of the gradients (tests/).
+ * Parameters are repacked into (hi, lo) fragment streams of nerf_packed3_floats() 32-bit words by nerf_pack_params_split
+ * (streams = mask of 1: 16-point forward stream, 4: transposed streams of the delta chain -- 5 = everything these entry points read;
+ * bits 2 / 8 write the streams of the superseded 32-point kernels, kept for the test-only reference library).  feature_linear is
+ * FOLDED into the view branch: W' = Wv[:, :256] Wf, b' = Wv[:, :256] bf + bv are derived at pack time (helpers:111-115: no activation
+ * between the two layers); `feature` and its delta are neither computed nor saved, and the weight-gradient entry point takes the
+ * canonical parameter vector `params` (the one that was packed) to produce the gradients of Wf, bf and Wv[:, :256] from
+ * G = delta_hv^T h7:  dWv[:, :256] = G Wf^T + dbv bf^T,  dWf = Wv[:, :256]^T G,  dbf = Wv[:, :256]^T dbv.
+ *   Kernels: 16 points per wavefront at 2 waves / SIMD, weights through a 17-slot LDS ring of 8 KiB fragment units (csrc/field_ring.h);
+ * the delta chain 32 points per wavefront on the same ring.  The save buffers hold 16-bit elements in tiles (rows of the 256- /
+ * 128-wide regions in 16-point tiles, row16h order; deltas and encodings in 32-point feature-major tiles; csrc/nerf_common.h), the
+ * ReLU bitmask words are in these kernels' lane order: forward, dgrad and weight gradients of one evaluation must use the same
+ * split (nerf_field_wgrad_phase(datapath = -1) picks the GEMM from the buffer records: 4 = bf16 operands, 5 = fp16 operands).
+ *   Range (split = 1): weights, encodings and activations must stay below 65520 in magnitude (a NeRF's are O(1..100)); an overflow
+ * turns into inf / NaN in `raw` (the ReLU propagates NaN).  Deltas are tiny (upstream gradients ~1e-6): nerf_field_dgrad_split(split
+ * = 1) first reduces max|d_raw| on the device and runs the chain on s * d_raw with s the power of two that puts that maximum in
+ * [16, 32) (the chain is linear; s and 1/s live in the delta buffer), every stored delta and partial weight gradient carries s, and
+ * the reduction phase of nerf_field_wgrad_phase multiplies by 1/s -- exact.  A non-finite d_raw propagates to the gradient.
+ * Replace run_nerf.py:37-51 + run_nerf_helpers.py:15-45, :96-119 and their autograd like nerf_field_fwd / nerf_field_bwd. */
 int nerf_packed3_floats(void);
-int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream);
-/* the same, writing only the fragment streams the caller will read (one launch behind the derivation of the folded layer):
- * streams = mask of 1: 16-point forward (nerf_field_fwd16*_bf16x3), 2: 32-point forward (nerf_field_fwd_bf16x3 / _mixed),
- * 4: transposed streams of the delta chain (nerf_field_dgrad*_bf16x3), 8: their hi-only copy (nerf_field_dgrad_mixed).
- * 15 = nerf_pack_params_bf16x3.  A kernel that reads a stream that was not written computes garbage: the caller chooses. */
-int nerf_pack_params_bf16x3_sel(const float* params, float* packed3, int streams, void* stream);
-int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                          int n_samples, float* raw, float* act, void* stream);
-/* the same forward on 16 points per wavefront at 2 waves / SIMD instead of 32 at 1 (same arithmetic class: 3 bf16
- * MFMAs per product, fp32 accumulate): a second resident wave hides the LDS latency and the save work the 32-point
- * kernel leaves exposed.  act NULL = inference; otherwise it writes EXACTLY the save buffer of nerf_field_fwd_bf16x3
- * (bf16_save = 0; rows of the 256- / 128-wide regions in 16-point tiles, datapath 3 of nerf_field_wgrad_phase) or the
- * same regions with bf16 elements (bf16_save != 0; rows in 16-point tiles of 2-byte elements, datapath 4).  Sums the
- * products in a different order than the 32-point kernel: the two agree to rounding (~1e-5 of |raw|), not bit for bit.
- * nerf_debug_pack16_table: host gather table of its fragment stream (tests). */
-int nerf_field_fwd16_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                            int n_samples, float* raw, float* act, int bf16_save, void* stream);
-/* nerf_field_fwd16_bf16x3 on the weight RING (csrc/field_ring.h): a 17-slot LDS ring of 8 KiB fragment units instead of
- * two 64 KiB buffers, one barrier per 64 KiB placed inside the chunk, fragments requested one unit ahead, the L2 -> LDS
- * DMA issued in 2 KiB parts behind the MFMAs.  Same fragment stream, same summation order: raw and everything saved are
- * BIT-IDENTICAL to nerf_field_fwd16_bf16x3(bf16_save = 1) (act != NULL: bf16 rows, datapath 4 of nerf_field_wgrad_phase)
- * or to its inference form (act NULL).  Replaces run_nerf.py:37-51 + run_nerf_helpers.py:15-45, :96-119 like the other
- * forwards. */
-int nerf_field_fwd16r_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                             int n_samples, float* raw, float* act, void* stream);
-int nerf_debug_pack16_table(int* out_host);
-/* ---- the three-term split with a selectable 16-bit type (ABI v7; csrc/split_types.h).  split = 0: bfloat16 -- exactly the
- * entry points above (nerf_pack_params_bf16x3_sel, nerf_field_fwd16r_bf16x3, nerf_field_dgrad3r_bf16x3(delta_bf16 = 1)), bit for
- * bit.  split = 1: IEEE half ("fp16x3"): W x = W_hi x_hi + W_hi x_lo + W_lo x_hi with hi = fp16(v), lo = fp16(v - hi) on
- * v_mfma_f32_16x16x32_f16 / 32x32x16_f16 -- the same MFMA count, ~2^-22 per product instead of 2^-17 (fp32-class), and the rows /
- * deltas saved for the weight-gradient GEMM carry 11 significant bits instead of 8.  The three calls of one network evaluation
- * must use the same split (the packed buffer, the save buffer and the delta buffer hold 16-bit elements of that type;
- * nerf_field_wgrad_phase(datapath = -1) picks the matching GEMM from the buffer records, datapath 5 = fp16 operands).
- *   Range (split = 1): weights, encodings and activations must stay below 65520 in magnitude (a NeRF's are O(1..100)); an
- *   overflow turns into inf / NaN in `raw`.  Deltas are tiny (upstream gradients ~1e-6): nerf_field_dgrad_split(split = 1) first
- *   reduces max|d_raw| on the device and runs the chain on s * d_raw with s the power of two that puts that maximum in [16, 32)
- *   (the chain is linear; s and 1/s live in the delta buffer), every stored delta and partial weight gradient carries s, and
- *   the reduction phase of nerf_field_wgrad_phase multiplies by 1/s -- exact.  A non-finite d_raw propagates to the gradient.
- * Replace run_nerf.py:37-51 + run_nerf_helpers.py:15-45, :96-119 and their autograd like the entry points they generalise. */
 int nerf_pack_params_split(const float* params, float* packed3, int streams, int split, void* stream);
 int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                          int n_samples, float* raw, float* act /* nullable: inference */, int split, void* stream);
 int nerf_field_dgrad_split(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
                            float* delta, int split, void* stream);
+/* test hooks (host only): gather tables of the fragment streams -- out_host[e] for every 16-bit element e: 2 * canonical_index +
+ * is_low_part, or -1 for zero padding (nerf_debug_pack3_table: the (hi, lo) streams incl. the transposed ones, declared below;
+ * nerf_debug_pack16_table: the 16-point forward stream). */
+int nerf_debug_pack16_table(int* out_host);
 /* ---- reduced product class for INFERENCE: split = 2 of nerf_pack_params_split / nerf_field_fwd_split (act must be NULL).
  * Every product of the 256-wide contractions (layers 1..7, the trunk part of the view branch) is  W_hi16 x_hi16  on the fp16 MFMA
  * plus the two correction terms  W_hi8 x_lo8 + W_lo8 x_hi8  as block-scaled fp8 e4m3 MFMAs of K = 128 (v_mfma_scale_f32_16x16x128_
@@ -195,68 +176,26 @@ int nerf_field_dgrad_split(const float* packed3, const float* act, const float* 
  * place where a 2^-15 error can move a ray's opacity by O(1); call it after the reduced pass, before raw2outputs. */
 int nerf_field_fwd_last_sample(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                                int n_samples, float* raw, void* stream);
-/* backward halves in the split-bf16 datapath (act must come from nerf_field_fwd_bf16x3).  dgrad also leaves a tiled
- * copy of d_raw inside delta, which is what wgrad contracts with: nerf_field_wgrad_bf16x3 must be given the delta
- * buffer of nerf_field_dgrad_bf16x3 for the same d_raw (its own d_raw argument is not read).  All weight-gradient
- * jobs, full-width and narrow, run on one tile kernel (12 after the folded feature layer and the alpha rider; 13 on bf16
- * operands).
- * delta_bf16 != 0: the chain is computed exactly as with 0 (3-term products, fp32 deltas in registers), but the deltas
- * are WRITTEN rounded to bf16 (same tiles, 2-byte elements) for the bf16-operand weight-gradient GEMM: pair it with an
- * act buffer saved with bf16_save != 0 and with nerf_field_wgrad_phase(datapath = 2 / 4).  Only the operands of the
- * weight-gradient contraction are rounded (zero-mean, averaged over all points), never the delta chain. */
-int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
-                            float* delta, int delta_bf16, void* stream);
-int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                            float* partial, float* grad, int accumulate, const float* params, void* stream);
-/* nerf_field_dgrad_bf16x3 on the weight RING (csrc/field_ring.h, field_bwd_ring.hip): every MFMA carries one fragment
- * request / a piece of the operand split / a row store in its shadow and the L2 -> LDS DMA leaves in 4 KiB parts, instead of
- * barrier + DMA burst + LDS latency + store burst after every 64 KiB chunk.  Same transposed stream, same summation order:
- * the deltas written are BIT-IDENTICAL to nerf_field_dgrad_bf16x3 with the same delta_bf16. */
-int nerf_field_dgrad3r_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
-                              float* delta, int delta_bf16, void* stream);
-/* The split-bf16 and mixed datapaths evaluate feature_linear and the feature columns of views_linears.0 as ONE layer
- * (helpers:111-115: no activation between them): W' = Wv[:, :256] Wf, b' = Wv[:, :256] bf + bv are derived by
- * nerf_pack_params_bf16x3.  `feature` and its delta are therefore neither computed nor saved; the weight-gradient entry
- * points take the canonical parameter vector `params` (the one that was packed) and produce the gradients of Wf, bf and
- * Wv[:, :256] from G = delta_hv^T h7:  dWv[:, :256] = G Wf^T + dbv bf^T,  dWf = Wv[:, :256]^T G,  dbf = Wv[:, :256]^T dbv. */
-/* ---- bf16 operand storage and the mixed-precision training variant.  nerf_field_fwd_mixed is the 32-point split-bf16
- * forward (same raw as nerf_field_fwd_bf16x3, bit for bit) saving its rows rounded to bf16 (32-point tiles, 2-byte
- * elements); nerf_field_wgrad_mixed contracts bf16 operands (delta_bf16^T * x_bf16, exact products, fp32 accumulation)
- * streamed from HBM into the MFMA without conversion.  Together with nerf_field_dgrad_bf16x3(delta_bf16 = 1) — the
- * unchanged 3-term delta chain writing bf16 deltas — that is the default split-bf16 training path of the host code.
- * nerf_field_dgrad_mixed instead runs the delta chain itself on single bf16 products (W_hi^T * delta_hi): the
- * mixed-precision option, whose gradients carry bf16 rounding noise (cosine to the fp64 gradient >= 0.999). */
-int nerf_field_fwd_mixed(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                         int n_samples, float* raw, float* act, void* stream);
-int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
-                           float* delta, void* stream);
-int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                           float* partial, float* grad, int accumulate, const float* params, void* stream);
-/* ---- which layout a scratch buffer holds.  The save buffer of a forward exists in five layouts and the delta buffer of a
- * dgrad in three (csrc/nerf_common.h); the entry point that writes a buffer decides, and the entry points that read it must
- * agree.  The library remembers per buffer ADDRESS what its own entry points last wrote there (host-side table only;
- * nothing is stored on the device and no pointer is dereferenced later) and
+/* ---- which layout a scratch buffer holds.  The save buffer of a forward and the delta buffer of a dgrad exist in three layouts each
+ * (fp32 point-major rows; bf16 tiles; fp16 tiles: csrc/nerf_common.h); the entry point that writes a buffer decides, and the entry
+ * points that read it must agree.  The library remembers per buffer ADDRESS what its own entry points last wrote there (host-side
+ * table only; nothing is stored on the device and no pointer is dereferenced later) and
  *   - every dgrad / weight-gradient entry point returns NERF_E_BADARG when given a buffer of the wrong family, of another
  *     ray / sample count, or an (act, delta) pair that no datapath contracts -- instead of computing garbage;
  *   - nerf_field_wgrad_phase(datapath = -1) takes the datapath from the record.
  * Buffers the library has not written (copies, foreign producers) are not checked.
- * nerf_buffer_layout: the recorded kind, or -1 for an unknown buffer.  act: 0 fp32 point-major rows (nerf_field_fwd),
- * 1 / 2 = 32-point tiles fp32 / bf16 (nerf_field_fwd_bf16x3 / _mixed), 3 / 4 = rows in 16-point tiles fp32 / bf16
- * (nerf_field_fwd16_bf16x3, nerf_field_fwd16r_bf16x3), 5 = rows in 16-point tiles of fp16 (nerf_field_fwd_split(split = 1));
- * delta (*is_delta = 1): 0 fp32 rows, 1 / 2 / 3 = 32-point tiles fp32 / bf16 / fp16. */
+ * nerf_buffer_layout: the recorded kind, or -1 for an unknown buffer.  act: 0 fp32 point-major rows (nerf_field_fwd), 4 / 5 = rows
+ * in 16-point tiles of bf16 / fp16 (nerf_field_fwd_split(split = 0 / 1)); delta (*is_delta = 1): 0 fp32 rows, 2 / 3 = 32-point
+ * tiles of bf16 / fp16. */
 int nerf_buffer_layout(const float* buf, int* is_delta, int* n_rays, int* n_samples);
-/* nerf_field_wgrad / nerf_field_wgrad_bf16x3 split into their three launches so that a profiler can bracket each:
- * phases bit 0 = the eight full-width (256x256) jobs (datapaths 1-4: all jobs), bit 1 = the six narrow jobs (fp32 datapath
- * only), bit 2 = reduction of the per-chunk partial gradients into grad.  Calling it with phases 1, 2, 4 in that order
- * equals one call with 7. */
+/* The weight gradients dW = delta^T x, db = sum delta of one evaluation (the second half of nerf_field_bwd; the only form on the
+ * split datapaths), split into launches a profiler can bracket: phases bit 0 = the GEMM jobs (fp32: the eight full-width 256x256
+ * jobs; split datapaths: all 13 jobs on the streaming 16-bit GEMM), bit 1 = the six narrow jobs (fp32 datapath only), bit 2 =
+ * reduction of the per-chunk partial gradients into grad (deterministic, no atomics; + the folded feature layer's gradients).
+ * Calling it with phases 1, 2, 4 in that order equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate,
-                           int datapath /* -1 as recorded for act / delta (above); 0 fp32; 1 fp32 operands split by the GEMM, act saved by nerf_field_fwd_bf16x3
-                                           (32-point tiles); 3 the same, act saved by nerf_field_fwd16_bf16x3 (rows in
-                                           16-point tiles); 2 bf16 operands (act from nerf_field_fwd_mixed, delta from
-                                           nerf_field_dgrad_mixed or nerf_field_dgrad_bf16x3(delta_bf16 = 1)); 4 the
-                                           same, act saved by nerf_field_fwd16_bf16x3(bf16_save = 1) (16-point tiles); 5 fp16
-                                           operands (nerf_field_fwd_split / nerf_field_dgrad_split with split = 1) */,
+                           int datapath /* -1 as recorded for act / delta (above); 0 fp32; 4 bf16 operands; 5 fp16 operands */,
                            int phases, const float* params /* canonical parameters; may be NULL for datapath 0 */,
                            void* stream);
 /* ---- render_rays in one call (run_nerf.py:308-418 and its autograd): the whole of a ray batch's forward, and the whole of
@@ -267,8 +206,8 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
  * outputs, and ONE scratch buffer of nerf_render_workspace_floats() floats that lives from the forward to its backward
  * (depths, coarse raw, compositing weights; when training also the saved activations, deltas and partial gradients: ~23 KB
  * per sample point on the default datapath -- split larger ray batches, the reference's `chunk` argument does exactly that).
- *   precision 0: exact fp32 datapath; 1: split-bf16 (wgrad_operands_bf16 selects the storage of the weight-gradient GEMM's
- *   operands, 1 = the default of the binding); 2: mixed-precision training option; 3: split-fp16 (fp16 operand storage).
+ *   precision 0: exact fp32 datapath; 1: split-bf16; 3: split-fp16 (packed buffers from nerf_pack_params_split with the
+ *   matching split; 16-bit operand storage of the weight-gradient GEMM either way).
  *   Backward with accumulate = 0: every gradient vector handed in is written -- a network whose pass received no upstream
  *   gradient gets zeros; d_disp / d_acc may be given without d_rgb.
  *   packed_f / params_f / grad_f NULL (or packed_f == packed_c): the fine pass uses the coarse network (network_fine None).
@@ -280,8 +219,8 @@ typedef struct NerfRenderCfg {
     int n_coarse, n_fine;          /* N_samples, N_importance */
     int lindisp, white_bkgd;
     float raw_noise_std;
-    int precision;                 /* 0 fp32, 1 split-bf16, 2 mixed, 3 split-fp16 (packed buffers from nerf_pack_params_split(split = 1)) */
-    int wgrad_operands_bf16;       /* precision 1: operands of the weight-gradient GEMM stored as bf16 (1) or fp32 (0) */
+    int precision;                 /* 0 fp32, 1 split-bf16, 3 split-fp16 */
+    int reserved;                  /* (round 3: operand storage switch; ignored) */
 } NerfRenderCfg;
 size_t nerf_render_workspace_floats(const NerfRenderCfg* cfg, int n_rays, int training);
 int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const float* packed_f, const float* rays, int ray_stride,
@@ -291,7 +230,7 @@ int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const 
 /* nerf_render_rays_fwd(training = 0) as ONE kernel launch (csrc/render_fused.hip): a workgroup owns 16 rays from the coarse
  * depths (run_nerf.py:357-379) through both networks, raw2outputs (:262-305) and sample_pdf + sort (:392-396) to the final
  * colours.  Same device code as the separate launches: every output is bit-identical to nerf_render_rays_fwd.  Same arguments
- * and workspace (nerf_render_workspace_floats(cfg, n_rays, 0)).  Split-bf16 / mixed datapath only, and only sample counts
+ * and workspace (nerf_render_workspace_floats(cfg, n_rays, 0)).  Split datapaths only (precision 1 / 3), and only sample counts
  * for which 16 rays fill whole 128-point tiles in both passes (n_coarse and n_coarse + n_fine multiples of 8, at most 1024
  * samples per ray): nerf_render_infer_supported(cfg) tells; otherwise NERF_E_BADARG. */
 int nerf_render_infer_supported(const NerfRenderCfg* cfg);

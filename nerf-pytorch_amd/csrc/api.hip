@@ -40,9 +40,6 @@ bool tag_lookup(const void* buf, BufTag* out) {
 }
 int datapath_of(int act_kind, int delta_kind) {
     if (act_kind == ACT_ROWS_F32 && delta_kind == DELTA_ROWS_F32) return 0;
-    if (act_kind == ACT_TILE32_F32 && delta_kind == DELTA_TILE32_F32) return 1;
-    if (act_kind == ACT_TILE32_BF16 && delta_kind == DELTA_TILE32_BF16) return 2;
-    if (act_kind == ACT_TILE16_F32 && delta_kind == DELTA_TILE32_F32) return 3;
     if (act_kind == ACT_TILE16_BF16 && delta_kind == DELTA_TILE32_BF16) return 4;
     if (act_kind == ACT_TILE16_F16 && delta_kind == DELTA_TILE32_F16) return 5;
     return -1;
@@ -55,8 +52,8 @@ static int check_act_for_dgrad(const char* fn, const void* act, bool split_bf16,
     if (!tag_lookup(act, &t)) return 0;
     if (t.is_delta) return fail_arg(fn, "`act` is a buffer this library last wrote DELTAS into");
     if ((t.kind != ACT_ROWS_F32) != split_bf16)
-        return fail_arg(fn, split_bf16 ? "`act` was saved by the exact-fp32 forward (point-major rows, fp32 bitmask order): not readable by the split-bf16 dgrad"
-                                       : "`act` was saved by a split-bf16 forward (tiles, bf16x3 bitmask order): not readable by the fp32 dgrad");
+        return fail_arg(fn, split_bf16 ? "`act` was saved by the exact-fp32 forward (point-major rows, fp32 bitmask order): not readable by a split datapath's dgrad"
+                                       : "`act` was saved by a split datapath's forward (tiles, its bitmask order): not readable by the fp32 dgrad");
     if (t.n_rays != n_rays || t.n_samples != n_samples) {
         snprintf(g_err, sizeof(g_err), "%s: `act` was saved for %d rays x %d samples, this call says %d x %d", fn, t.n_rays, t.n_samples, n_rays, n_samples);
         return NERF_E_BADARG;
@@ -275,8 +272,8 @@ static int datapath_from_tags(const char* fn, const void* act, const void* delta
     if (!(ka && kd)) return -1;
     const int dp = datapath_of(ta.kind, td.kind);
     if (dp < 0) {
-        snprintf(g_err, sizeof(g_err), "%s: act layout %d (0 fp32 rows, 1/2 32-point tiles fp32/bf16, 3/4/5 16-point tiles fp32/bf16/fp16) cannot be "
-                 "contracted with delta kind %d (0 fp32 rows, 1/2/3 tiles fp32/bf16/fp16): the forward and the dgrad that wrote them belong to different datapaths",
+        snprintf(g_err, sizeof(g_err), "%s: act layout %d (0 fp32 rows, 4 / 5 = 16-point tiles of bf16 / fp16) cannot be "
+                 "contracted with delta kind %d (0 fp32 rows, 2 / 3 = tiles of bf16 / fp16): the forward and the dgrad that wrote them belong to different datapaths",
                  fn, ta.kind, td.kind);
         *rc = NERF_E_BADARG;
     }
@@ -287,7 +284,7 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
                            float* partial, float* grad, int accumulate, int datapath, int phases, const float* params,
                            void* stream) {
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && datapath >= -1 && datapath <= 5, "bad size");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && (datapath == -1 || datapath == 0 || datapath == 4 || datapath == 5), "bad size / datapath (-1, 0, 4, 5)");
     int rc;
     const int recorded = datapath_from_tags(__func__, act, delta, n_rays, n_samples, &rc);
     if (rc) return rc;
@@ -299,33 +296,9 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
                  "the saved rows and deltas follow from the forward and dgrad entry points that produced them)", __func__, datapath, recorded);
         return NERF_E_BADARG;
     }
-    REQUIRE(datapath == 0 || params, "the split-bf16 / mixed datapaths need the canonical parameters (folded feature layer)");
+    REQUIRE(datapath == 0 || params, "the split datapaths need the canonical parameters (folded feature layer)");
     return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate,
                                                    datapath, phases, (hipStream_t)stream, params));
-}
-
-int nerf_field_dgrad_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
-                            float* delta, int delta_bf16, void* stream) {
-    REQUIRE(packed3 && act && d_raw && delta, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
-            (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
-            "packed/act/d_raw/delta must be 16-byte aligned");
-    if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
-    tag_record(delta, 1, delta_bf16 ? DELTA_TILE32_BF16 : DELTA_TILE32_F32, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, delta_bf16 ? 2 : 0, (hipStream_t)stream));
-}
-
-int nerf_field_dgrad3r_bf16x3(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
-                              float* delta, int delta_bf16, void* stream) {
-    REQUIRE(packed3 && act && d_raw && delta, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
-            (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
-            "packed/act/d_raw/delta must be 16-byte aligned");
-    if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
-    tag_record(delta, 1, delta_bf16 ? DELTA_TILE32_BF16 : DELTA_TILE32_F32, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_dgrad3r(packed3, act, d_raw, n_rays, n_samples, delta, delta_bf16, 0, (hipStream_t)stream));
 }
 
 int nerf_field_dgrad_split(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
@@ -340,35 +313,7 @@ int nerf_field_dgrad_split(const float* packed3, const float* act, const float* 
     return done(__func__, nerf::launch_field_dgrad3r(packed3, act, d_raw, n_rays, n_samples, delta, 1, split, (hipStream_t)stream));
 }
 
-int nerf_field_dgrad_mixed(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
-                           float* delta, void* stream) {
-    REQUIRE(packed3 && act && d_raw && delta, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
-            (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
-            "packed/act/d_raw/delta must be 16-byte aligned");
-    if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
-    tag_record(delta, 1, DELTA_TILE32_BF16, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_dgrad3(packed3, act, d_raw, n_rays, n_samples, delta, 1, (hipStream_t)stream));
-}
-
-int nerf_field_wgrad_mixed(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                           float* partial, float* grad, int accumulate, const float* params, void* stream) {
-    REQUIRE(act && delta && d_raw && partial && grad && params, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 2, 7,
-                                                   (hipStream_t)stream, params));
-}
-
-int nerf_field_wgrad_bf16x3(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
-                            float* partial, float* grad, int accumulate, const float* params, void* stream) {
-    REQUIRE(act && delta && d_raw && partial && grad && params, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    return done(__func__, nerf::launch_field_wgrad(act, delta, d_raw, n_rays, n_samples, partial, grad, accumulate, 1, 7,
-                                                   (hipStream_t)stream, params));
-}
-
-/* ---- split-bf16 ("bf16x3") datapath: same boundary, precision_mode = 1 */
+/* ---- three-term split datapaths (bf16 / fp16 parts) */
 int nerf_packed3_floats(void) { return nerf::PACKED3_WORDS; }
 
 int nerf_debug_pack3_table(int* out_host) {
@@ -381,30 +326,6 @@ int nerf_debug_pack16_table(int* out_host) {
     REQUIRE(out_host, "null pointer");
     nerf::pack16_table_host(out_host);
     return 0;
-}
-
-int nerf_field_fwd16_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                            int n_samples, float* raw, float* act, int bf16_save, void* stream) {
-    REQUIRE(packed3 && rays && z_vals && raw, "null pointer");
-    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
-    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
-            (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
-    if (act) tag_record(act, 0, bf16_save ? ACT_TILE16_BF16 : ACT_TILE16_F32, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_fwd16(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act,
-                                                   bf16_save, (hipStream_t)stream));
-}
-
-int nerf_field_fwd16r_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                             int n_samples, float* raw, float* act, void* stream) {
-    REQUIRE(packed3 && rays && z_vals && raw, "null pointer");
-    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
-    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
-            (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
-    if (act) tag_record(act, 0, ACT_TILE16_BF16, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_fwd16r(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, 0,
-                                                    (hipStream_t)stream));
 }
 
 int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
@@ -434,41 +355,6 @@ int nerf_pack_params_split(const float* params, float* packed3, int streams, int
     REQUIRE(streams >= 0 && streams <= 15 && split >= 0 && split <= 2, "streams is a mask of bits 0..3, split 0 (bf16), 1 (fp16) or 2 (reduced inference stream)");
     REQUIRE(split != 2 || (streams & 1), "split = 2 refills the 16-point forward stream: streams must include bit 0");
     return done(__func__, nerf::launch_pack3_sel(params, packed3, streams, (hipStream_t)stream, split));
-}
-
-int nerf_pack_params_bf16x3(const float* params, float* packed3, void* stream) {
-    REQUIRE(params && packed3, "null pointer");
-    return done(__func__, nerf::launch_pack3(params, packed3, (hipStream_t)stream));
-}
-
-int nerf_pack_params_bf16x3_sel(const float* params, float* packed3, int streams, void* stream) {
-    REQUIRE(params && packed3, "null pointer");
-    REQUIRE(streams >= 0 && streams <= 15, "streams is a mask of bits 0..3");
-    return done(__func__, nerf::launch_pack3_sel(params, packed3, streams, (hipStream_t)stream));
-}
-
-int nerf_field_fwd_bf16x3(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                          int n_samples, float* raw, float* act, void* stream) {
-    REQUIRE(packed3 && rays && z_vals && raw, "null pointer");
-    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
-    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
-            (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
-    if (act) tag_record(act, 0, ACT_TILE32_F32, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_fwd3(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, 0,
-                                                  (hipStream_t)stream));
-}
-
-int nerf_field_fwd_mixed(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                         int n_samples, float* raw, float* act, void* stream) {
-    REQUIRE(packed3 && rays && z_vals && raw && act, "null pointer");
-    REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
-    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
-            (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
-    tag_record(act, 0, ACT_TILE32_BF16, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_fwd3(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, 1,
-                                                  (hipStream_t)stream));
 }
 
 int nerf_mse_scratch_floats(void) { return nerf::MSE_SCRATCH_FLOATS; }

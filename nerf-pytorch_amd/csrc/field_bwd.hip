@@ -164,12 +164,6 @@ struct WgradJob {
     int b_tile16;                   // bf16x3: B is stored in 16-point tiles with the row16 row order (field_fwd16_kernel<1>)
     int b_ray_tiles;                // wgrad1_kernel: > 0 = B is constant along a ray (the direction encoding) and stored ONCE per
                                     // ray as [ray][feature][8 copies] bf16 (512 B per ray); value = 32-point tiles per ray
-    // bf16x3 only: a rank-1 rider on this job's B operand.  aux != nullptr: dW_aux[f] = sum_p aux[p] * B[p][f] and
-    // db_aux = sum_p aux[p] are accumulated in fp32 by the B-staging threads from the values they convert anyway
-    // (4 FMAs per round) -- the alpha_linear weight gradient rides on the job that stages the trunk output h7, which
-    // saves its own job re-reading all of h7 (1 KB per point).  aux = row of a 4-wide 32-point tile region (d_sigma).
-    const float* aux;
-    int aux_w_off, aux_b_off;
 };
 struct WgradArgs {
     WgradJob job[WG_MAX_JOBS];
@@ -390,209 +384,8 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(WgradArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ bf16x3 weight gradients
-// dW[n][k] = sum_p delta[p][n] * x[p][k] for all 14 (delta, input) jobs, 3 bf16 MFMAs per product on
-// v_mfma_f32_32x32x16_bf16 (contraction over points).  Operands are stored in 32-point feature-major tiles
-// (nerf_common.h, ActLayout3): a tile is the k-extent of one stage, and the MFMA wants 8 consecutive POINTS of one
-// feature per lane -- exactly how a tile lays them out.  Staging: the 256 threads of an operand read a tile as one
-// contiguous block, 16 B per lane and lane-linear (round r = features 32r..32r+31; thread t holds points
-// 4*(t&7)..+3 of feature 32r + t/8), split the values into (hi, lo) bf16 and write 8 + 8 bytes into a feature-major
-// LDS image padded to 144 B per feature (conflict-free ds_read_b128 for the fragments).  Narrow operands
-// (63 / 27 / 3 / 1 features) run through the same tile: rounds beyond their width re-read the last feature (cache
-// hits) and stage zeros, so padding costs no HBM bytes (the kernel is HBM-bound, idle MFMA blocks are free).  Bias gradients fall out of the staging threads
-// exactly (fp32 sums of the values they loaded).  64 KiB of operands per 48 MFMAs per wave.
-constexpr int WG3_FEAT_BYTES = 144;                              // 32 pts x 2 B x (hi, lo) + 16 B pad
-constexpr int WG3_OPERAND_BYTES = 256 * WG3_FEAT_BYTES;          // 36,864
-constexpr int WG3_LDS_BYTES = 2 * 2 * WG3_OPERAND_BYTES;         // 2 buffers x (A, B) = 147,456
-constexpr int WG3_ROUNDS = 8;                                    // 256 features / 32 per round
-
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const unsigned h = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-        hi[i] = h;
-        lo[i] = pack_bf16x2(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
-    }
-}
-
-__global__ __launch_bounds__(512) void wgrad3_256_kernel(WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm3[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_n = wave >> 2, wave_k = wave & 3;
-    const int ji = blockIdx.x % a.n_jobs;
-    const int chunk = blockIdx.x / a.n_jobs;
-    const WgradJob& jb = a.job[ji];
-    const long p_begin = (long)chunk * a.chunk_pts;              // multiple of 32: chunks start on a tile
-    const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
-    const int nrows = (int)(p_end - p_begin);
-    const int n_stages = (nrows + WG_STAGE - 1) / WG_STAGE;
-    // staging role: waves 0-3 stage delta (A), waves 4-7 the input (B)
-    const int sop = __builtin_amdgcn_readfirstlane(tid >> 8);
-    const int st_t = tid & 255;
-    // lane -> (feature of the round, 4-point group): a wave stages 8 features x 8 groups.  The LDS image has a pitch of
-    // 36 dwords per feature (conflict-free ds_read_b128 of the fragments); a ds_write_b64 is serviced in groups of 16
-    // contiguous lanes over 32 banks, so a group must hold 8 consecutive features (bank offsets 4k) x 2 adjacent point
-    // groups (the two dword pairs of one 16-byte piece): lane = 16*g + 2*k + b -> feature k, point group 2*g + b.
-    // (feature = lane >> 3, group = lane & 7 put two features with 12 overlapping banks in every group: 2-way conflicts
-    // on a third of all LDS cycles, profiles/r01_bf16x3_pmc_summary.csv.)  The global loads stay one contiguous KiB per wave.
-    const int sk = (st_t >> 1) & 7;
-    const int sg = ((st_t >> 4) & 3) * 2 + (st_t & 1);            // 4-point group inside the tile
-    const int sfeat = (st_t >> 6) * 8 + sk;                        // the thread's feature in round 0 (0..31)
-    const int swidth = sop == 0 ? jb.nA : jb.nB;
-    const int sld = sop == 0 ? jb.lda : jb.ldb;                    // features per tile of the operand's region
-    // scalar base of this workgroup's first tile + 32-bit per-lane byte offsets (a chunk spans < 4 GiB)
-    const char* cbase = reinterpret_cast<const char*>((sop == 0 ? jb.A : jb.B) + (p_begin >> 5) * (long)sld * 32);
-    const unsigned tile_bytes = 128u * (unsigned)sld;
-    const int sf0 = sfeat;
-    const int sflast = swidth - 1;
-    float colsum[WG3_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < WG3_ROUNDS; ++r) colsum[r] = 0.0f;
-    // 8 independent, unconditional 16-byte loads per stage (rounds beyond a narrow operand's width re-read its last
-    // feature: cache hits, no HBM bytes); zeros (features beyond the width; points >= P in the last stage of the last
-    // chunk) are selected when the values are consumed, so the loads stay in flight across a whole compute phase
-    // 16-point tiles (B operands written by field_fwd16_kernel<1>): the stage's 32 points are two consecutive tiles of
-    // sld rows x 64 B, rows in row16 order; the staged LDS row index is then a ROW of the tile, not a feature -- the
-    // contraction does not care, the output columns are mapped back through row16_feature() when they are written
-    const bool t16 = sop == 1 && jb.b_tile16 != 0;
-    const unsigned row_bytes = t16 ? 64u : 128u;
-    const unsigned sg_off = t16 ? (unsigned)(sg >> 2) * 64u * (unsigned)sld + 16u * (unsigned)(sg & 3) : 16u * (unsigned)sg;
-    auto gload_into = [&](f32x4 (&dst)[WG3_ROUNDS], int st) {
-        const unsigned off0 = (unsigned)st * tile_bytes + sg_off;
-#pragma unroll
-        for (int r = 0; r < WG3_ROUNDS; ++r)        // row clamped into the operand: always inside the tile
-            dst[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(cbase + (off0 + row_bytes * (unsigned)min(32 * r + sf0, sflast))));
-    };
-    // rank-1 rider (see WgradJob::aux): the B-staging waves weight their column sums with aux[p]
-    const bool rider = sop == 1 && jb.aux != nullptr;              // wave-uniform
-    const float* aux_base = jb.aux + (p_begin >> 5) * (long)(4 * 32) + 4 * sg;
-    float aux_sum = 0.0f;
-    auto swrite_from = [&](const f32x4 (&src)[WG3_ROUNDS], int buf, int st) {
-        unsigned char* dst = sm3 + (buf * 2 + sop) * WG3_OPERAND_BYTES + sfeat * WG3_FEAT_BYTES + 8 * sg;
-        const int left = nrows - st * WG_STAGE - 4 * sg;           // points of this thread's group that exist
-        f32x4 wgt = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (rider) {    // 16 bytes of a 128-byte row every thread of the stage shares (L1 hits after the first)
-            const f32x4 ds = *reinterpret_cast<const f32x4*>(aux_base + (size_t)st * (4 * 32));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wgt[e] = e < left ? ds[e] : 0.0f;
-            if (sfeat == 0) aux_sum += (wgt[0] + wgt[1]) + (wgt[2] + wgt[3]);
-        }
-#pragma unroll
-        for (int r = 0; r < WG3_ROUNDS; ++r) {
-            const bool fv = 32 * r + sf0 <= sflast;
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (fv && e < left) ? src[r][e] : 0.0f;
-            u32x2 hi, lo;
-            split4(v, hi, lo);
-            *reinterpret_cast<u32x2*>(dst + r * 32 * WG3_FEAT_BYTES) = hi;
-            *reinterpret_cast<u32x2*>(dst + r * 32 * WG3_FEAT_BYTES + 64) = lo;
-            // A operand: bias gradient (plain column sum); B operand with a rider: aux-weighted column sum
-            colsum[r] += rider ? (v[0] * wgt[0] + v[1] * wgt[1]) + (v[2] * wgt[2] + v[3] * wgt[3]) : (v[0] + v[1]) + (v[2] + v[3]);
-        }
-    };
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const int row = lane & 31, hf = lane >> 5;
-    const int ni = min(4, (jb.nA - wave_n * 128 + 31) / 32);     // 32-row output blocks of this wave that hold real rows
-    const int nj = min(2, (jb.nB - wave_k * 64 + 31) / 32);
-    const bool wave_has_work = ni > 0 && nj > 0;
-    auto compute = [&](int buf) {
-        const unsigned char* sa = sm3 + (buf * 2) * WG3_OPERAND_BYTES + (wave_n * 128 + row) * WG3_FEAT_BYTES + 16 * hf;
-        const unsigned char* sb = sm3 + (buf * 2 + 1) * WG3_OPERAND_BYTES + (wave_k * 64 + row) * WG3_FEAT_BYTES + 16 * hf;
-        if (wave_has_work)
-#pragma unroll
-        for (int t = 0; t < WG_STAGE / 16; ++t) {
-            u32x4 bhi[2], blo[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bhi[j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * WG3_FEAT_BYTES + 32 * t);
-                blo[j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * WG3_FEAT_BYTES + 64 + 32 * t);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i >= ni) break;
-                const u32x4 ahi = *reinterpret_cast<const u32x4*>(sa + i * 32 * WG3_FEAT_BYTES + 32 * t);
-                const u32x4 alo = *reinterpret_cast<const u32x4*>(sa + i * 32 * WG3_FEAT_BYTES + 64 + 32 * t);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(ahi, bhi[j], acc[i][j]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(ahi, blo[j], acc[i][j]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(alo, bhi[j], acc[i][j]);
-            }
-        }
-    };
-    // Two register sets (rv, rw): the loads issued in one half-iteration are consumed by the write-back of the next
-    // one, i.e. they have a full compute phase plus a barrier to land.  Known limit: because the loads below are
-    // guarded, hipcc's waitcnt insertion drains vmcnt(0) before each new batch, so effectively one batch is in flight.
-    // A branch-free variant with two batches really in flight (16-point stages, counted vmcnt, no spills) was built and
-    // measured: same speed -- the kernel is paced by its MFMA issue + conversion VALU + barriers, not by load latency
-    //  -- so the simpler form with clamped, always-in-bounds addresses stays.
-    f32x4 rv[WG3_ROUNDS], rw[WG3_ROUNDS];
-    gload_into(rv, 0);
-    swrite_from(rv, 0, 0);
-    if (n_stages > 1) gload_into(rv, 1);
-    __syncthreads();
-    // invariant at the top of iteration st (even): LDS buf 0 holds stage st, rv holds stage st+1
-    for (int st = 0; st < n_stages; st += 2) {
-        if (st + 2 < n_stages) gload_into(rw, st + 2);
-        compute(0);
-        if (st + 1 < n_stages) swrite_from(rv, 1, st + 1);
-        __syncthreads();
-        if (st + 1 >= n_stages) break;
-        if (st + 3 < n_stages) gload_into(rv, st + 3);
-        compute(1);
-        if (st + 2 < n_stages) swrite_from(rw, 0, st + 2);
-        __syncthreads();
-    }
-    // acc[i][j][r] at lane (col = lane&31, hf) = dW[wave_n*128 + 32*i + d32row(r, hf)][wave_k*64 + 32*j + col]
-    float* out = a.partial + (size_t)chunk * N_PARAMS;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = wave_n * 128 + 32 * i + d32row(r, hf);
-            if (n < jb.nA) {
-                float* orow = out + jb.c_off + (size_t)n * jb.ldc;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int k = wave_k * 64 + 32 * j + row;
-                    if (k < jb.nB) orow[jb.b_tile16 ? row16_feature(k) : k] = acc[i][j][r];
-                }
-            }
-        }
-    if ((jb.bias_off >= 0 && sop == 0) || rider) {
-#pragma unroll
-        for (int r = 0; r < WG3_ROUNDS; ++r) {
-                float s = colsum[r];                // sum over the 8 point groups: lane bits 0, 4, 5
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
-                const int f = 32 * r + sfeat;
-                if (sg == 0 && f < swidth) {
-                    if (rider) out[jb.aux_w_off + (jb.b_tile16 ? row16_feature(f) : f)] = s;
-                    else out[jb.bias_off + f] = s;
-                }
-            }
-    }
-    if (rider) {                                    // db_aux = sum_p aux[p]: the threads of staged row 0, over the point groups
-        float s = aux_sum;
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (sfeat == 0 && sg == 0) out[jb.aux_b_off] = s;
-    }
-}
-
-// ------------------------------------------------------------------ mixed-precision weight gradients (bf16 operands)
-// Same 14 jobs, operands saved as bf16 in the same 32-point feature-major tiles (64-byte rows): a lane's MFMA
+// ------------------------------------------------------------------ streaming weight gradients of the split datapaths (16-bit operands)
+// 13 jobs, operands saved as 16-bit elements (bf16 or fp16: SP) in 32-point feature-major tiles (64-byte rows): a lane's MFMA
 // fragment (8 consecutive points of one feature = 16 B) is in memory as is, so the kernel is pure streaming:
 // HBM -> LDS by DMA into a ring of 4 stages (one stage = one 32-point tile of both operands = 32 KiB = 32
 // wave-instructions of global_load_lds_dwordx4, three stages = 96 KiB per CU in flight), ds_read_b128, one bf16 MFMA
@@ -784,7 +577,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
 }
 
 // fold == 0: every entry of the canonical gradient is the sum of its per-chunk partials.
-// fold == 1 (split-bf16 / mixed, feature layer folded into the view branch, nerf_common.h): the job (delta_hv, h7) left
+// fold == 1 (split datapaths, feature layer folded into the view branch, nerf_common.h): the job (delta_hv, h7) left
 //   G = delta_hv^T h7 in the slot of views_linears.0.weight[:, :256]; G and this call's dbv = sum delta_hv go to
 //   `scratch` ([128][256] | [128]) for wgrad_fold_kernel, and feature_linear.{weight,bias} / Wv[:, :256] are left to it.
 // inv_scale (nullable): device word holding 1 / s of the launch's delta scale (fp16 split, DeltaLayout3::scale): every partial
@@ -846,14 +639,11 @@ __global__ void wgrad_fold_kernel(const float* __restrict__ params, const float*
 // ------------------------------------------------------------------ host side
 static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
     // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU).  fp32: 14 jobs x
-    // 128 = 7 x 256 (the 8 full-width jobs x 128 = 4 x 256).  Split-bf16 (12 jobs: folded feature layer, alpha rides on
-    // the h7 job): 12 x 64 = 3 x 256; bf16 operands (13 jobs): 13 x 39 = 507 = 2 x 256 - 5 (59 chunks = 3 rounds: GEMM +1 %,
-    // reduction 0.055 instead of 0.043 ms).  (Measured for the 12 jobs: 64 and 128 chunks run
-    // the GEMM in the same time, 96 — a partial last round — is 10 % slower, and the partial-sum traffic of the
-    // deterministic reduction halves with 64: 0.113 -> 0.057 ms per launch.)  Small inputs get >= 256-point chunks.
-    // (13 jobs, launches below 400 k points -- the coarse pass: 19 chunks = 247 workgroups = ONE round; the GEMM takes the same
-    // time (0.65 ms at 262 k points) and the deterministic reduction reads half the partial sums: 0.044 -> 0.032 ms)
-    long n = n_jobs == 14 ? 128 : (n_jobs == 13 ? (P < 400000 ? 19 : 39) : 64);
+    // 128 = 7 x 256 (the 8 full-width jobs x 128 = 4 x 256).  Split datapaths (13 jobs, 16-bit operands): 13 x 39 = 507 =
+    // 2 x 256 - 5 (59 chunks = 3 rounds: GEMM +1 %, reduction 0.055 instead of 0.043 ms); launches below 400 k points -- the coarse
+    // pass: 19 chunks = 247 workgroups = ONE round (the GEMM takes the same time, the deterministic reduction reads half the
+    // partial sums: 0.044 -> 0.032 ms).  Small inputs get >= 256-point chunks.
+    long n = n_jobs == 14 ? 128 : (P < 400000 ? 19 : 39);
     const long cap = (P + 255) / 256;
     if (n > cap) n = cap;
     if (n < 1) n = 1;
@@ -866,7 +656,7 @@ static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
 size_t wgrad_partial_floats(long P) {
     // sized for either job count, plus the scratch of the folded feature layer (G | dbv) behind the partial sums
     int pts;
-    const int n14 = wgrad_chunks(P, &pts, 14), n13 = wgrad_chunks(P, &pts, 13);     // (12 jobs: 64 chunks)
+    const int n14 = wgrad_chunks(P, &pts, 14), n13 = wgrad_chunks(P, &pts, 13);
     return (size_t)(n14 > n13 ? n14 : n13) * N_PARAMS + N_DERIVED;
 }
 
@@ -893,22 +683,7 @@ __global__ void expand_dir_kernel(const f32x4* __restrict__ dir_ray, f32x4* __re
     const long p = i >> 3;
     dir_pt[i] = dir_ray[(p / S) * 8 + (i & 7)];
 }
-// the same into 32-point feature-major tiles of 32 features (bf16x3 datapath): thread = (tile, feature, 4-point group)
-__global__ void expand_dir_tiles_kernel(const float* __restrict__ dir_ray, f32x4* __restrict__ dir_pt, long P, int S) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n_tiles = (P + 31) >> 5;
-    if (i >= n_tiles * 256) return;
-    const long tile = i >> 8;
-    const int f = (int)(i >> 3) & 31, g = (int)i & 7;
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const long p = min(tile * 32 + 4 * g + e, P - 1);
-        v[e] = dir_ray[(p / S) * 32 + f];
-    }
-    dir_pt[i] = v;
-}
-// ... and with bf16 elements (mixed-precision backward): thread = (tile, feature, 8-point group)
+// the same into 32-point feature-major tiles of 32 features with 16-bit elements (split datapaths): thread = (tile, feature, 8-point group)
 template <typename SP>
 __device__ inline u32x4 pack8_sp(const float* v) {
     return u32x4{SP::cvt_pk(v[0], v[1]), SP::cvt_pk(v[2], v[3]), SP::cvt_pk(v[4], v[5]), SP::cvt_pk(v[6], v[7])};
@@ -944,19 +719,16 @@ __global__ void replicate_dir_bf16_kernel(const float* __restrict__ dir_ray, u32
 
 // phases: bit 0 = full-width jobs, bit 1 = narrow jobs, bit 2 = chunk reduction (7 = everything)
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
-                              float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream,
+                              float* partial, float* grad, int accumulate, int datapath, int phases, hipStream_t stream,
                               const float* params) {
-    // bf16x3 (datapath): 0 = fp32, 1 = split-bf16 with act saved by the 32-point forward (32-point tiles), 2 = mixed-precision
-    // backward (bf16 operands, one MFMA per product), 3 = split-bf16 with act saved by the 16-point forward (rows in
-    // 16-point tiles, nerf_common.h row16)
-    // 4 = bf16 operands whose B rows were saved by the 16-point forward (16-point bf16 tiles, row16h order)
-    // 5 = the same with fp16 elements (fp16 split: deltas scaled by the launch's power of two, removed in the reduction)
-    const bool f16 = bf16x3 == 5;
-    if (f16) bf16x3 = 4;
-    const bool mixed = bf16x3 == 2 || bf16x3 == 4;
-    const bool x_tile16 = bf16x3 == 3 || bf16x3 == 4;
-    bf16x3 = bf16x3 == 0 ? 0 : (mixed ? 2 : 1);
-    const bool fold = bf16x3 != 0;           // split-bf16 / mixed: feature layer folded into the view branch (nerf_common.h)
+    // datapath: 0 = fp32 (point-major rows); 4 = bf16 operands, rows saved by the 16-point forward (16-point tiles, row16h order),
+    // deltas in 32-point tiles; 5 = the same with fp16 elements (deltas scaled by the launch's power of two, removed in the reduction)
+    if (datapath != 0 && datapath != 4 && datapath != 5) return hipErrorInvalidValue;
+    const bool f16 = datapath == 5;
+    const bool mixed = datapath != 0;        // 16-bit operands streamed by wgrad1_kernel
+    const bool x_tile16 = mixed;
+    const int bf16x3 = mixed ? 2 : 0;
+    const bool fold = mixed;                 // split datapaths: feature layer folded into the view branch (nerf_common.h)
     if (fold && !params) return hipErrorInvalidValue;
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
@@ -973,27 +745,22 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         if (f16) inv_scale = delta + dl.scale + 1;
         for (int l = 0; l < D; ++l) { d_h[l] = delta + dl.h[l]; x_h[l] = act + al.h[l]; }
         d_feat = delta + dl.feat; d_hv = delta + dl.hv; d_rgb = delta + dl.graw;
-        // feature 3 of the 4-wide tile: 3 rows of 32 fp32 (bf16x3) or 32 bf16 (mixed, same region, 2-byte elements)
-        d_sigma = mixed ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(delta + dl.graw) + 3 * 32)
-                        : delta + dl.graw + 3 * 32;
+        // feature 3 of the 4-wide tile: 3 rows of 32 two-byte elements
+        d_sigma = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(delta + dl.graw) + 3 * 32);
         x_feat = act + al.feat; x_hv = act + al.hv; x_enc = act + al.enc; x_dir = act + al.dir_pt;
         ld_graw = 4;
         if (phases & 1) {   // act is written by the forward; the expanded copy is scratch inside the same buffer
-            if (mixed && S % 32 == 0) {
+            if (S % 32 == 0) {
                 const dim3 grid((unsigned)(((long)n_rays * 32 + 255) / 256));
                 u32x4* dst = reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt);
                 if (f16) hipLaunchKernelGGL(replicate_dir_bf16_kernel<SplitF16>, grid, dim3(256), 0, stream, act + al.dir, dst, (long)n_rays * 32);
                 else hipLaunchKernelGGL(replicate_dir_bf16_kernel<SplitBF16>, grid, dim3(256), 0, stream, act + al.dir, dst, (long)n_rays * 32);
-            } else if (mixed) {
+            } else {
                 const long n_thr = ((P + 31) >> 5) * 128;
                 const dim3 grid((unsigned)((n_thr + 255) / 256));
                 u32x4* dst = reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt);
                 if (f16) hipLaunchKernelGGL(expand_dir_tiles_bf16_kernel<SplitF16>, grid, dim3(256), 0, stream, act + al.dir, dst, P, S);
                 else hipLaunchKernelGGL(expand_dir_tiles_bf16_kernel<SplitBF16>, grid, dim3(256), 0, stream, act + al.dir, dst, P, S);
-            } else {
-                const long n_thr = ((P + 31) >> 5) * 256;
-                hipLaunchKernelGGL(expand_dir_tiles_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,
-                                   act + al.dir, reinterpret_cast<f32x4*>(const_cast<float*>(act) + al.dir_pt), P, S);
             }
             e = hipGetLastError();
             if (e != hipSuccess) return e;
@@ -1039,19 +806,15 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         }
     }
     if (!fold) add(d_feat, W, W, x_h[D - 1], W, W, 1, cn.wf, W, cn.bf);
-    // the alpha_linear gradient (A = d_sigma, one row) is its own job except on the split-bf16 datapath, where it rides
-    // on the job that stages the trunk output h7 anyway (WgradJob::aux)
-    const bool ride_sigma = fold && !mixed;
-    if (!ride_sigma) add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);
+    add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);           // alpha_linear (A = d_sigma, one row)
     // fold: G = delta_hv^T h7 lands in the slot of Wv[:, :256]; wgrad_fold_kernel turns it into dWv[:, :256], dWf, dbf
     if (fold) {
         add(d_hv, WV, WV, x_h[D - 1], W, W, 1, cn.wv, W + IN_DIR, cn.bv);
-        if (ride_sigma) { wa.job[nj - 1].aux = d_sigma; wa.job[nj - 1].aux_w_off = cn.wa; wa.job[nj - 1].aux_b_off = cn.ba; }
     } else add(d_hv, WV, WV, x_feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
     add(d_hv, WV, WV, x_dir, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
     if (mixed && S % 32 == 0 && nj <= WG_MAX_JOBS) wa.job[nj - 1].b_ray_tiles = S / 32;       // direction encoding: one record per ray
     add(d_rgb, ld_graw, 3, x_hv, WV, WV, 1, cn.wr, WV, cn.br);
-    if (nj != WG_MAX_JOBS - (fold ? 1 : 0) - (ride_sigma ? 1 : 0)) return hipErrorInvalidValue;
+    if (nj != WG_MAX_JOBS - (fold ? 1 : 0)) return hipErrorInvalidValue;
     // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
     WgradArgs big{}, small{};
     int small_tiles = 0;
@@ -1079,7 +842,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    static bool attr1_set = false, attr3_set = false;
+    static bool attr1_set = false;
     if (mixed && !attr1_set) {
         e = hipFuncSetAttribute((const void*)wgrad1_kernel<SplitBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, WG1_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1087,18 +850,9 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         if (e != hipSuccess) return e;
         attr1_set = true;
     }
-    if (bf16x3 == 1 && !attr3_set) {
-        e = hipFuncSetAttribute((const void*)wgrad3_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr3_set = true;
-    }
     if (big.n_jobs > 0 && mixed && (phases & 1)) {
         if (f16) hipLaunchKernelGGL(wgrad1_kernel<SplitF16>, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
         else hipLaunchKernelGGL(wgrad1_kernel<SplitBF16>, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    } else if (big.n_jobs > 0 && bf16x3 && (phases & 1)) {
-        hipLaunchKernelGGL(wgrad3_256_kernel, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG3_LDS_BYTES, stream, big);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     } else if (big.n_jobs > 0 && (phases & 1)) {

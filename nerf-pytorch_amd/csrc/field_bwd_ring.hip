@@ -244,7 +244,7 @@ hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const fl
                                 float* delta, int out16, int split, hipStream_t stream) {
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
-    if (split && !out16) return hipErrorInvalidValue;
+    if (!out16) return hipErrorInvalidValue;        // (fp32 deltas were the operand storage of round 3's fp32-operand GEMM: removed)
     FieldBwdRingArgs ba{packed3, act, d_raw, delta, n_rays, S};
     const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
     if (split) {
@@ -255,7 +255,7 @@ hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const fl
         hipLaunchKernelGGL(delta_scale_kernel, dim3(sb), dim3(256), 0, stream, reinterpret_cast<const f32x4*>(d_raw), P, slot);
         return launch_dgrad_one<2, SplitF16>(ba, blocks, stream);
     }
-    return out16 ? launch_dgrad_one<2, SplitBF16>(ba, blocks, stream) : launch_dgrad_one<0, SplitBF16>(ba, blocks, stream);
+    return launch_dgrad_one<2, SplitBF16>(ba, blocks, stream);
 }
 
 }  // namespace nerf

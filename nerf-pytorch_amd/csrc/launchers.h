@@ -76,22 +76,15 @@ hipError_t launch_field_bwd(const float* packed, const float* act, const float* 
 hipError_t launch_field_dgrad(const float* packed, const float* act, const float* d_raw, int n_rays, int S,
                               float* delta, hipStream_t stream);
 hipError_t launch_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int S,
-                              float* partial, float* grad, int accumulate, int bf16x3, int phases, hipStream_t stream,
-                              const float* params);     // canonical parameters: required by the split-bf16 / mixed datapaths
-hipError_t launch_field_dgrad3(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
-                               float* delta, int mode /* 0 x3 chain + fp32 deltas, 1 mixed, 2 x3 chain + bf16 deltas */, hipStream_t stream);
+                              float* partial, float* grad, int accumulate, int datapath /* 0 fp32, 4 bf16 operands, 5 fp16 operands */,
+                              int phases, hipStream_t stream, const float* params);     // canonical parameters: required by the split datapaths
 size_t wgrad_partial_floats(long P);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2, float eps, int step,
                        hipStream_t stream);
 void pack_table_host(int* out);
 void pack3_table_host(int* out);
 void pack16_table_host(int* out);
-hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream);
 hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream, int split = 0);
-hipError_t launch_field_fwd3(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
-                             int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
-hipError_t launch_field_fwd16(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
-                              int n_rays, int S, float* raw, float* act, int bf16_save, hipStream_t stream);
 // split (ring kernels, repack, streaming weight-gradient GEMM): 0 = bf16 three-term split, 1 = fp16 (csrc/split_types.h)
 hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                                int n_rays, int S, float* raw, float* act, int split, hipStream_t stream);

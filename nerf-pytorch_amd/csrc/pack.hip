@@ -376,10 +376,6 @@ hipError_t launch_pack3_sel(const float* canon_params, float* packed, int stream
     return hipGetLastError();
 }
 
-hipError_t launch_pack3(const float* canon_params, float* packed, hipStream_t stream) {
-    return launch_pack3_sel(canon_params, packed, 15, stream);
-}
-
 // host copy of the gather table (CPU tests emulate the MFMA data flow with it)
 void pack_table_host(int* out) {
     for (int i = 0; i < PACKED_FLOATS; ++i) out[i] = pack_source(i);

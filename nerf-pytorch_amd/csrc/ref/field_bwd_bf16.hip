@@ -5,6 +5,7 @@
 #include <type_traits>
 #include "field_device_bf16.h"
 #include "launchers.h"
+#include "ref_launchers.h"
 
 namespace nerf {
 

@@ -60,7 +60,7 @@ __global__ void add_inplace_kernel(float* dst, const float* src, size_t n) {
 }
 
 bool cfg_ok(const NerfRenderCfg* c) {
-    return c && c->n_coarse >= 3 && c->n_fine >= 0 && c->n_coarse + c->n_fine <= 4096 && c->precision >= 0 && c->precision <= 3 &&
+    return c && c->n_coarse >= 3 && c->n_fine >= 0 && c->n_coarse + c->n_fine <= 4096 && (c->precision == 0 || c->precision == 1 || c->precision == 3) &&
            c->raw_noise_std >= 0.0f;
 }
 
@@ -75,13 +75,8 @@ hipError_t field_forward(const NerfRenderCfg* c, const float* packed, const floa
         if (act) tag_record(act, 0, ACT_TILE16_F16, n, S);
         return nerf::launch_field_fwd16r(packed, rays, stride, z, n, S, raw, act, 1, st);
     }
-    const bool bf16_rows = c->precision == 2 || c->wgrad_operands_bf16;
-    if (!act || bf16_rows) {
-        if (act) tag_record(act, 0, ACT_TILE16_BF16, n, S);
-        return nerf::launch_field_fwd16r(packed, rays, stride, z, n, S, raw, act, 0, st);
-    }
-    tag_record(act, 0, ACT_TILE16_F32, n, S);
-    return nerf::launch_field_fwd16(packed, rays, stride, z, n, S, raw, act, 0, st);
+    if (act) tag_record(act, 0, ACT_TILE16_BF16, n, S);
+    return nerf::launch_field_fwd16r(packed, rays, stride, z, n, S, raw, act, 0, st);
 }
 
 // parameter gradient of one pass: dgrad + weight gradients into `grad`
@@ -95,12 +90,10 @@ hipError_t field_backward(const NerfRenderCfg* c, const float* packed, const flo
         tag_record(delta, 1, DELTA_TILE32_F16, n, S);
         return nerf::launch_field_wgrad(act, delta, d_raw, n, S, partial, grad, accumulate, 5, 7, st, params);
     }
-    const bool bf16_rows = c->precision == 2 || c->wgrad_operands_bf16;
-    if (c->precision == 2) e = nerf::launch_field_dgrad3(packed, act, d_raw, n, S, delta, 1, st);
-    else e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, bf16_rows ? 1 : 0, 0, st);
+    e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, 1, 0, st);
     if (e != hipSuccess) return e;
-    tag_record(delta, 1, bf16_rows ? DELTA_TILE32_BF16 : DELTA_TILE32_F32, n, S);
-    return nerf::launch_field_wgrad(act, delta, d_raw, n, S, partial, grad, accumulate, bf16_rows ? 4 : 3, 7, st, params);
+    tag_record(delta, 1, DELTA_TILE32_BF16, n, S);
+    return nerf::launch_field_wgrad(act, delta, d_raw, n, S, partial, grad, accumulate, 4, 7, st, params);
 }
 
 }  // namespace
@@ -116,7 +109,7 @@ int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const 
                          int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
                          float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
                          float* workspace, int training, void* stream) {
-    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0..3, raw_noise_std >= 0)");
+    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0 / 1 / 3, raw_noise_std >= 0)");
     REQUIRE(packed_c && rays && rgb && disp && acc && raw && workspace, "null pointer");
     REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
     REQUIRE(n_rays >= 0, "bad size");
@@ -172,8 +165,8 @@ int nerf_render_rays_infer(const NerfRenderCfg* cfg, const float* packed_c, cons
                            int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
                            float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
                            float* workspace, void* stream) {
-    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0..3, raw_noise_std >= 0)");
-    REQUIRE(nerf_render_infer_supported(cfg), "one-launch inference: split-bf16 / mixed datapath, 16 * n_coarse and 16 * (n_coarse + n_fine) "
+    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0 / 1 / 3, raw_noise_std >= 0)");
+    REQUIRE(nerf_render_infer_supported(cfg), "one-launch inference: a three-term split datapath (precision 1 / 3), 16 * n_coarse and 16 * (n_coarse + n_fine) "
             "multiples of 128, n_coarse + n_fine <= 1024 (use nerf_render_rays_fwd(training = 0) otherwise)");
     REQUIRE(packed_c && rays && rgb && disp && acc && raw && workspace, "null pointer");
     REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
@@ -209,7 +202,7 @@ int nerf_render_rays_bwd(const NerfRenderCfg* cfg, const float* packed_c, const 
                          float* workspace, float* grad_c, float* grad_f, int accumulate, void* stream) {
     REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg");
     REQUIRE(packed_c && rays && raw && workspace && grad_c, "null pointer");
-    REQUIRE(cfg->precision == 0 || params_c, "the split-bf16 / mixed datapaths need the canonical parameters (folded feature layer)");
+    REQUIRE(cfg->precision == 0 || params_c, "the split datapaths need the canonical parameters (folded feature layer)");
     REQUIRE(ray_stride >= 11 && n_rays >= 0, "bad size");
     REQUIRE(!(cfg->raw_noise_std > 0.0f) || noise_c, "raw_noise_std > 0 needs the noise draws of the forward");
     if (n_rays == 0) return 0;

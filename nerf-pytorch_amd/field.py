@@ -144,8 +144,6 @@ class NeRF(nn.Module):
         if self._packed is None or key != self._packed_key:
             self._packed = {}
             self._packed_key = key
-        if precision == "mixed":        # the mixed-precision backward reads the same (hi, lo) fragment streams
-            precision = "bf16x3"
         if precision not in self._packed:
             # fresh tensor each time: a pending backward keeps a reference to the old one
             self._packed[precision] = hb.pack_params(flat, precision=precision)

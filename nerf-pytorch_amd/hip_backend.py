@@ -50,24 +50,13 @@ def _declare(lib):
         "nerf_field_dgrad": (i, [p, p, p, i, i, p, p]),
         "nerf_field_wgrad": (i, [p, p, p, i, i, p, p, i, p]),
         "nerf_packed3_floats": (i, []),
-        "nerf_pack_params_bf16x3": (i, [p, p, p]),
-        "nerf_pack_params_bf16x3_sel": (i, [p, p, i, p]),
-        "nerf_field_fwd_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_debug_pack3_table": (i, [p]),
-        "nerf_field_dgrad_bf16x3": (i, [p, p, p, i, i, p, i, p]),
-        "nerf_field_dgrad3r_bf16x3": (i, [p, p, p, i, i, p, i, p]),
-        "nerf_field_wgrad_bf16x3": (i, [p, p, p, i, i, p, p, i, p, p]),
         "nerf_field_wgrad_phase": (i, [p, p, p, i, i, p, p, i, i, i, p, p]),
-        "nerf_field_fwd_mixed": (i, [p, p, i, p, i, i, p, p, p]),
-        "nerf_field_fwd16_bf16x3": (i, [p, p, i, p, i, i, p, p, i, p]),
-        "nerf_field_fwd16r_bf16x3": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_pack_params_split": (i, [p, p, i, i, p]),
         "nerf_field_fwd_split": (i, [p, p, i, p, i, i, p, p, i, p]),
         "nerf_field_dgrad_split": (i, [p, p, p, i, i, p, i, p]),
         "nerf_field_fwd_last_sample": (i, [p, p, i, p, i, i, p, p]),
         "nerf_debug_pack16_table": (i, [p]),
-        "nerf_field_dgrad_mixed": (i, [p, p, p, i, i, p, p]),
-        "nerf_field_wgrad_mixed": (i, [p, p, p, i, i, p, p, i, p, p]),
         "nerf_adam_step": (i, [p, p, p, p, i, f, f, f, f, i, p]),
         "nerf_render_workspace_floats": (sz, [p, i, i]),
         "nerf_render_rays_fwd": (i, [p, p, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p, i, p]),
@@ -94,10 +83,10 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_buffer_layout", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
-           "nerf_packed3_floats", "nerf_pack_params_bf16x3", "nerf_pack_params_bf16x3_sel", "nerf_field_fwd_bf16x3", "nerf_debug_pack3_table",
-           "nerf_field_dgrad_bf16x3", "nerf_field_dgrad3r_bf16x3", "nerf_field_wgrad_bf16x3", "nerf_field_wgrad_phase", "nerf_field_fwd_mixed", "nerf_field_fwd16_bf16x3", "nerf_field_fwd16r_bf16x3", "nerf_debug_pack16_table",
+           "nerf_packed3_floats", "nerf_debug_pack3_table",
+           "nerf_field_wgrad_phase", "nerf_debug_pack16_table",
            "nerf_pack_params_split", "nerf_field_fwd_split", "nerf_field_dgrad_split", "nerf_field_fwd_last_sample",
-           "nerf_field_dgrad_mixed", "nerf_field_wgrad_mixed", "nerf_adam_step",
+           "nerf_adam_step",
            "nerf_render_workspace_floats", "nerf_render_rays_fwd", "nerf_render_rays_bwd", "nerf_render_infer_supported",
            "nerf_render_rays_infer", "nerf_mse_scratch_floats", "nerf_mse_fwd", "nerf_mse_bwd", "nerf_build_inputs", "nerf_dense_fwd", "nerf_dense_dgrad", "nerf_dense_wgrad_scratch_floats",
            "nerf_dense_wgrad"]
@@ -186,7 +175,7 @@ BYTES_ACT_PER_POINT = 4 * (9 * 256 + 128 + 64 + 32) + 32 * 9 + 16  # saved activ
 BYTES_DELTA_PER_POINT = 4 * (9 * 256 + 128)             # deltas written by dgrad
 BYTES_WGRAD_BIG_PER_POINT = 4 * 8 * (256 + 256)         # each full-width job reads its delta and its input once
 BYTES_WGRAD_SMALL_PER_POINT = 4 * (2 * (256 + 64) + (4 + 256) + (128 + 256) + (128 + 32) + (4 + 128))
-# split-bf16 / mixed datapaths: feature_linear is folded into the view branch (csrc/nerf_common.h): one 256x256 layer
+# split datapaths: feature_linear is folded into the view branch (csrc/nerf_common.h): one 256x256 layer
 # less is EXECUTED in each of the three kernels, `feature` and its delta are neither written nor re-read
 FOLD_MAC = 256 * 256
 FLOP_FWD3_PER_POINT = 2 * (593408 - FOLD_MAC)
@@ -230,15 +219,15 @@ def pack_table():
     return tab
 
 
-# "mixed" = the bf16x3 forward (identical outputs) with a bf16 backward: saved activations / deltas rounded to bf16,
-# one bf16 MFMA per product in dgrad and wgrad (fp32 accumulation).  A training-speed option, not a parity datapath.
+# "fp16x3" / "bf16x3": the three-term split W x = W_hi x_hi + W_hi x_lo + W_lo x_hi with fp16 / bf16 parts (csrc/split_types.h) on the
+# weight-ring kernels; the operands of the weight-gradient GEMM are the stored hi words (11 / 8 significant bits).
 # "fp16x3" (round 4) = the same three-term split with IEEE-half parts (csrc/split_types.h): ~2^-22 per product instead of 2^-17
 # and 11-bit instead of 8-bit operands for the weight-gradient GEMM, at the bf16 MFMA count; needs |activations| < 65520.
 # "fp16_fp8c" (round 4, INFERENCE class): no_grad rendering with every product of the 256-wide layers as fp16 main term + two fp8
 # correction terms (csrc/field_ring8.h: ~2^-15 per product, 2 instead of 3 MFMA-equivalents; every ray's last sample re-evaluated
 # with the three-term fp16 products); anything that needs gradients runs the fp16x3 datapath unchanged.  Never the bench headline.
-PRECISIONS = ("fp32", "bf16x3", "mixed", "fp16x3", "fp16_fp8c")
-SPLIT = ("bf16x3", "mixed", "fp16x3", "fp16_fp8c")       # datapaths on the three-term-split kernels (folded feature layer, tiled saves)
+PRECISIONS = ("fp32", "fp16x3", "bf16x3", "fp16_fp8c")
+SPLIT = ("fp16x3", "bf16x3", "fp16_fp8c")       # datapaths on the three-term-split kernels (folded feature layer, tiled saves)
 
 
 def pack_table3():
@@ -266,37 +255,6 @@ def pack_table16():
     return tab
 
 
-# Storage of the operands of the weight-gradient GEMM (saved activations, deltas) on the bf16x3 datapath:
-#   "bf16" (default): written once, rounded to bf16 (RNE), contracted by the bf16 streaming GEMM (wgrad1_kernel, exact
-#           products, fp32 accumulation).  The forward and the delta chain are the 3-term split-bf16 arithmetic either
-#           way — only the GEMM's operands are rounded: zero-mean 2^-9 per element, averaged over the ~10^6 points of the
-#           contraction (1e-4 of |dW| at 131 k points, ~4e-5 at the 786 k points of a fine pass: below the datapath's
-#           own error against fp64; tests/test_gpu_parity.py test_bf16_operand_storage_*).  Half the HBM bytes of the
-#           training step.
-#   "fp32": fp32 tiles, split into (hi, lo) by the GEMM itself (wgrad3_256_kernel, 3 MFMAs per product).
-WGRAD_OPERANDS = __import__("os").environ.get("NERF_WGRAD_OPERANDS", "bf16")
-if WGRAD_OPERANDS not in ("bf16", "fp32"):
-    raise ValueError("NERF_WGRAD_OPERANDS must be 'bf16' or 'fp32'")
-
-
-def _bf16_operands(precision):
-    """the weight-gradient GEMM's operands are stored as 16-bit elements (bf16; fp16 on the fp16 split, always)"""
-    return precision in ("mixed", "fp16x3") or (precision == "bf16x3" and WGRAD_OPERANDS == "bf16")
-
-
-# the bf16x3 / mixed forward runs the 16-point-per-wave kernel (2 waves / SIMD); "0" selects the 32-point kernel
-# (1 wave / SIMD), which writes the same save buffer and agrees to rounding
-FWD_16PT = __import__("os").environ.get("NERF_FWD16", "ring") != "0"
-# ... and, unless NERF_FWD16=1, its weight-RING form (csrc/field_ring.h: 17-slot LDS ring, fragments requested one unit
-# ahead, DMA behind the MFMAs; bit-identical results) for inference and for bf16 rows; fp32 rows stay on the double-buffered kernel
-FWD_RING = __import__("os").environ.get("NERF_FWD16", "ring") == "ring"
-
-
-# the split-bf16 delta chain on the weight ring (csrc/field_bwd_ring.hip; bit-identical deltas); NERF_DGRAD=stream selects
-# the double-buffered kernel
-DGRAD_RING = __import__("os").environ.get("NERF_DGRAD", "ring") == "ring"
-
-
 def _small_offset():
     # SM_BIAS of csrc/nerf_common.h = first word after the fp32 forward + backward weight streams
     return 593408 + 557056
@@ -314,13 +272,10 @@ def pack_params(flat, out=None, precision="fp32"):
             out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
         _check(L.nerf_pack_params_split(_ptr(flat, "params"), _ptr(out, "packed"), 1 | 4, 1, _stream()), "nerf_pack_params_split")
         return out
-    if precision in ("bf16x3", "mixed"):
+    if precision == "bf16x3":       # bf16 (hi, lo) fragments of the same two streams
         if out is None:
             out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
-        # one launch for all four fragment streams (+ the derivation of the folded layer in front of it).  A host that knows
-        # which kernels it will run can pack less (nerf_pack_params_bf16x3_sel streams mask); this binding switches kernels
-        # on one packed buffer (tests, NERF_FWD16 / NERF_DGRAD), so it packs them all
-        _check(L.nerf_pack_params_bf16x3_sel(_ptr(flat, "params"), _ptr(out, "packed"), 15, _stream()), "nerf_pack_params_bf16x3_sel")
+        _check(L.nerf_pack_params_split(_ptr(flat, "params"), _ptr(out, "packed"), 1 | 4, 0, _stream()), "nerf_pack_params_split")
         return out
     if out is None:
         out = torch.empty(L.nerf_packed_floats(), dtype=torch.float32, device=flat.device)
@@ -442,7 +397,7 @@ def saved_bytes(n_rays, n_coarse, n_fine):
 class NerfRenderCfg(ctypes.Structure):
     """include/nerf_hip.h NerfRenderCfg (render_rays in one call)"""
     _fields_ = [("n_coarse", ctypes.c_int), ("n_fine", ctypes.c_int), ("lindisp", ctypes.c_int), ("white_bkgd", ctypes.c_int),
-                ("raw_noise_std", ctypes.c_float), ("precision", ctypes.c_int), ("wgrad_operands_bf16", ctypes.c_int)]
+                ("raw_noise_std", ctypes.c_float), ("precision", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
 ACT_LAYOUTS = {0: "fp32 rows", 1: "tile32 fp32", 2: "tile32 bf16", 3: "tile16 fp32", 4: "tile16 bf16", 5: "tile16 fp16"}
@@ -468,20 +423,18 @@ def _row16h(f):
 
 def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
     """Debug/test view of one saved region (activations or deltas) as a point-major [P, F] tensor.
-    region: "h0".."h7", "feat" (fp32 datapath only: the split-bf16 / mixed datapaths fold feature_linear into the view
-    branch and never write it), "hv", "enc".  The fp32 datapath stores point-major rows (act_layout); the bf16x3
-    datapath stores 32-point feature-major tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32 -- except
-    the 256- / 128-wide activation rows saved by the 16-point forward (precision "bf16x3" with FWD_16PT), which are in
-    16-point tiles with the row16 row order (tile16=True; default: what field_fwd recorded on the buffer).  bf16=True:
-    2-byte elements (mixed; bf16x3 with WGRAD_OPERANDS == "bf16"; default: what field_fwd recorded) in 32-point tiles,
-    or — rows saved by the 16-point forward, tile16=True — in 16-point tiles with the row16h row order."""
+    region: "h0".."h7", "feat" (fp32 datapath only: the split datapaths fold feature_linear into the view branch and never write
+    it), "hv", "enc".  The fp32 datapath stores point-major fp32 rows (act_layout); the split datapaths store 16-bit elements
+    (bf16 / fp16 by `precision`) in tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32: the 256- / 128-wide
+    activation rows saved by the forward in 16-point tiles with the row16h row order (tile16=True; default: what the library
+    recorded for the buffer), deltas and encodings in 32-point feature-major tiles."""
     tiled = precision in SPLIT
     kind, is_delta = buffer_layout(buf)[:2] if buf.is_cuda else (-1, False)
     f16 = precision == "fp16x3"         # 16-bit elements are IEEE halves
     if tile16 is None:
         tile16 = kind in (3, 4, 5) and not is_delta
     if bf16 is None:
-        bf16 = precision in ("mixed", "fp16x3") or kind in (2, 4)
+        bf16 = precision in SPLIT or kind in (2, 4, 5)
     Pa = (P + 31) // 32 * 32 if tiled else P
     widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
     off = 0
@@ -502,7 +455,7 @@ def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
     raise KeyError(region)
 
 
-# render_rays without gradients as ONE launch on the split-bf16 / mixed datapaths (csrc/render_fused.hip; bit-identical to the
+# render_rays without gradients as ONE launch on the split datapaths (csrc/render_fused.hip; bit-identical to the
 # chain of launches and as fast or faster for every ray count measured).  NERF_INFER_ONE_LAUNCH=0 keeps the chain:
 # sample_coarse -> field forward -> composite -> sample_fine -> field forward -> composite
 INFER_ONE_LAUNCH = os.environ.get("NERF_INFER_ONE_LAUNCH", "1") != "0"
@@ -510,7 +463,7 @@ INFER_ONE_LAUNCH = os.environ.get("NERF_INFER_ONE_LAUNCH", "1") != "0"
 
 def render_cfg(n_coarse, n_fine, lindisp, white_bkgd, raw_noise_std, precision):
     return NerfRenderCfg(int(n_coarse), int(n_fine), int(bool(lindisp)), int(bool(white_bkgd)), float(raw_noise_std),
-                         {"fp32": 0, "bf16x3": 1, "mixed": 2, "fp16x3": 3, "fp16_fp8c": 3}[precision], int(WGRAD_OPERANDS == "bf16"))
+                         {"fp32": 0, "bf16x3": 1, "fp16x3": 3, "fp16_fp8c": 3}[precision], 1)
 
 
 def render_infer_supported(n_coarse, n_fine, precision):
@@ -555,7 +508,6 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32", guard_pack
     S = z_vals.shape[1]
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
     act = WORKSPACE.take(act_floats(n, S), rays.device) if save_act else None
-    b16 = _bf16_operands(precision)
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in SPLIT:
         nbytes = BYTES_ACT3_PER_POINT * n * S if save_act else 16.0 * n * S
@@ -577,28 +529,11 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32", guard_pack
             _check(lib().nerf_field_fwd_split(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
                                               n, S, _ptr(raw), _ptr(act, "act", True), 1, _stream()), "nerf_field_fwd_split")
         return raw, act
-    if precision in ("bf16x3", "mixed") and FWD_16PT:
-        bf16_save = int(b16)
-        ring = FWD_RING and (bf16_save or not save_act)
-        label = ("field_fwd16r_kernel" if ring else "field_fwd16_kernel") + (("<save bf16>" if bf16_save else "<save>") if save_act else "")
-        with _timed(label, FLOP_FWD3_PER_POINT * n * S, BYTES_ACT3_BF16_PER_POINT * n * S if bf16_save and save_act else nbytes):
-            if ring:
-                _check(lib().nerf_field_fwd16r_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
-                                                      n, S, _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd16r_bf16x3")
-            else:
-                _check(lib().nerf_field_fwd16_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
-                                                     n, S, _ptr(raw), _ptr(act, "act", True), bf16_save, _stream()),
-                       "nerf_field_fwd16_bf16x3")
-        return raw, act
-    if b16 and save_act:
-        with _timed("field_fwd3_kernel<save bf16>", FLOP_FWD3_PER_POINT * n * S, BYTES_ACT3_BF16_PER_POINT * n * S):
-            _check(lib().nerf_field_fwd_mixed(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
-                                              n, S, _ptr(raw), _ptr(act, "act"), _stream()), "nerf_field_fwd_mixed")
-        return raw, act
-    if precision in ("bf16x3", "mixed"):
-        with _timed("field_fwd3_kernel<save>" if save_act else "field_fwd3_kernel", FLOP_FWD3_PER_POINT * n * S, nbytes):
-            _check(lib().nerf_field_fwd_bf16x3(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
-                                               n, S, _ptr(raw), _ptr(act, "act", True), _stream()), "nerf_field_fwd_bf16x3")
+    if precision == "bf16x3":
+        with _timed("field_fwd16r_kernel" + ("<save bf16>" if save_act else ""), FLOP_FWD3_PER_POINT * n * S,
+                    BYTES_ACT3_BF16_PER_POINT * n * S if save_act else nbytes):
+            _check(lib().nerf_field_fwd_split(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                              n, S, _ptr(raw), _ptr(act, "act", True), 0, _stream()), "nerf_field_fwd_split")
         return raw, act
     with _timed("field_fwd_kernel<save>" if save_act else "field_fwd_kernel", FLOP_FWD_PER_POINT * n * S, nbytes):
         _check(lib().nerf_field_fwd(_ptr(packed, "packed"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"), n, S,
@@ -660,10 +595,10 @@ def sample_pdf(bins, weights, n_samples, u, u_lin):
 
 def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32", params=None):
     """Parameter gradients of one field evaluation into the flat vector `grad`.  `params`: the canonical (flat) parameter
-    vector `packed` was made from -- required by the split-bf16 / mixed datapaths, whose folded feature layer needs Wf, bf
+    vector `packed` was made from -- required by the split datapaths, whose folded feature layer needs Wf, bf
     and Wv[:, :256] to turn G = delta_hv^T h7 into their gradients (csrc/nerf_common.h)."""
     if precision != "fp32" and params is None:
-        raise NerfHipError("field_bwd: the split-bf16 / mixed datapaths need params= (the flat parameter vector)")
+        raise NerfHipError("field_bwd: the split datapaths need params= (the flat parameter vector)")
     n, S, _ = d_raw.shape
     L = lib()
     dev = d_raw.device
@@ -677,38 +612,23 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32", params=Non
 
 
 def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S, params):
-    b3 = precision == "bf16x3"
-    mx = precision == "mixed"
-    h3 = precision == "fp16x3"
-    # what the forward wrote into `act` (the library's own record, nerf_buffer_layout): bf16 rows => bf16 deltas + the bf16
-    # streaming GEMM; the weight-gradient call below passes datapath = -1 ("as recorded"), and a mismatched pairing is
-    # refused by the library (NERF_E_BADARG)
+    split = {"bf16x3": 0, "fp16x3": 1}.get(precision)
+    # what the forward wrote into `act` (the library's own record, nerf_buffer_layout); the weight-gradient call below passes
+    # datapath = -1 ("as recorded"), and a mismatched pairing is refused by the library (NERF_E_BADARG)
     kind = buffer_layout(act)[0]
-    if precision in SPLIT and kind == -1:
+    if split is not None and kind == -1:
         raise NerfHipError("field_bwd: `act` is not a save buffer this library's forward wrote (no layout record): the split "
                            "datapaths cannot guess its tiling and element type")
-    b16 = b3 and kind in (2, 4)        # bf16x3 chain, bf16-stored GEMM operands (WGRAD_OPERANDS)
     P = n * S
-    if h3:
-        with _timed("field_dgrad3r_kernel<fp16>", FLOP_DGRAD3_PER_POINT * P, BYTES_DELTA3_BF16_PER_POINT * P):
-            _check(L.nerf_field_dgrad_split(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta), 1, _stream()),
+    if split is not None:
+        with _timed("field_dgrad3r_kernel<fp16>" if split else "field_dgrad3r_kernel<bf16 out>", FLOP_DGRAD3_PER_POINT * P, BYTES_DELTA3_BF16_PER_POINT * P):
+            _check(L.nerf_field_dgrad_split(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta), split, _stream()),
                    "nerf_field_dgrad_split")
-    elif mx:
-        with _timed("field_dgrad3_kernel<mixed>", FLOP_DGRAD3_PER_POINT * P, BYTES_DELTA3_BF16_PER_POINT * P):
-            _check(L.nerf_field_dgrad_mixed(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S,
-                                            _ptr(delta), _stream()), "nerf_field_dgrad_mixed")
-    elif b3:
-        base = "field_dgrad3r_kernel" if DGRAD_RING else "field_dgrad3_kernel"
-        with _timed(base + ("<bf16 out>" if b16 else ""), FLOP_DGRAD3_PER_POINT * P,
-                    (BYTES_DELTA3_BF16_PER_POINT if b16 else BYTES_DELTA3_PER_POINT) * P):
-            fn = L.nerf_field_dgrad3r_bf16x3 if DGRAD_RING else L.nerf_field_dgrad_bf16x3
-            _check(fn(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta), int(b16), _stream()),
-                   "nerf_field_dgrad3r_bf16x3" if DGRAD_RING else "nerf_field_dgrad_bf16x3")
     else:
         with _timed("field_dgrad_kernel", FLOP_DGRAD_PER_POINT * P, BYTES_DELTA_PER_POINT * P):
             _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
                                       _stream()), "nerf_field_dgrad")
-    bf16_gemm = mx or b16 or h3
+    gemm16 = split is not None          # 16-bit operands streamed straight into the MFMA (wgrad1_kernel)
     datapath = -1
     args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),
             int(bool(accumulate)), datapath)
@@ -716,11 +636,8 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
     if TIMER is None:
         _check(L.nerf_field_wgrad_phase(*args, 7, *tail), "nerf_field_wgrad_phase")
         return grad
-    if bf16_gemm:   # all 13 jobs stream bf16 operands straight into the MFMA
-        with _timed("wgrad1_kernel<fp16>" if h3 else "wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD_MIXED_PER_POINT * P):
-            _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
-    elif b3:    # all 12 jobs (full-width and narrow) run through the masked bf16x3 tile kernel
-        with _timed("wgrad3_256_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD3_PER_POINT * P):
+    if gemm16:      # all 13 jobs stream 16-bit operands straight into the MFMA
+        with _timed("wgrad1_kernel<fp16>" if split else "wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD_MIXED_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
     else:
         with _timed("wgrad256_kernel", FLOP_WGRAD_BIG_PER_POINT * P, BYTES_WGRAD_BIG_PER_POINT * P):
@@ -728,7 +645,7 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
         with _timed("wgrad_kernel(narrow jobs)", (FLOP_WGRAD_PER_POINT - FLOP_WGRAD_BIG_PER_POINT) * P, BYTES_WGRAD_SMALL_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 2, *tail), "nerf_field_wgrad_phase")
     # chunks of partial sums the reduction reads (csrc/field_bwd.hip, wgrad_chunks)
-    n_chunks = min((19 if P < 400000 else 39) if bf16_gemm else (64 if b3 else 128), max(1, (P + 255) // 256))
+    n_chunks = min((19 if P < 400000 else 39) if gemm16 else 128, max(1, (P + 255) // 256))
     with _timed("wgrad_reduce_kernel", 0.0, 4.0 * N_PARAMS * (n_chunks + 1)):
         _check(L.nerf_field_wgrad_phase(*args, 4, *tail), "nerf_field_wgrad_phase")
     return grad

@@ -18,12 +18,13 @@ _PRECISION = __import__("os").environ.get("NERF_PRECISION", "fp32")
 
 
 def set_precision(mode):
-    """Select the field datapath ("fp16x3": the three-term split with fp16 parts, fp32-class, the bench headline; "fp16_fp8c":
-    fp16x3 for everything that needs gradients and the reduced fp16 + fp8-correction products for no_grad rendering; see
-    hip_backend.PRECISIONS): "fp32" (exact fp32 MFMA, the parity anchor), "bf16x3" (split-bf16 MFMA,
-    fp32 accumulate, ~1e-5 relative error; judged by the PSNR-delta criterion) or "mixed" (the bf16x3 forward,
-    bit-identical outputs, with a bf16 backward: saved activations / deltas rounded to bf16, single bf16 MFMA
-    products in dgrad / wgrad -- a mixed-precision training option)."""
+    """Select the field datapath (hip_backend.PRECISIONS):
+      "fp32"      exact fp32 MFMA (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain): the parity anchor;
+      "fp16x3"    every product as three fp16 MFMAs, W_hi x_hi + W_hi x_lo + W_lo x_hi with hi = fp16(v), lo = fp16(v - hi): ~2^-22 per
+                  product (fp32-class), fp32 accumulation / activations / gradients; the bench headline;
+      "bf16x3"    the same with bf16 parts (~2^-17 per product, 8-bit operands for the weight-gradient GEMM; fp32's exponent range:
+                  the datapath for activations beyond fp16's 65504);
+      "fp16_fp8c" fp16x3 for everything that needs gradients; no_grad rendering on fp16 main term + fp8 correction terms (~2^-15)."""
     global _PRECISION
     if mode not in hb.PRECISIONS:
         raise ValueError(f"precision must be one of {hb.PRECISIONS}")
@@ -218,7 +219,7 @@ class _RenderRays(torch.autograd.Function):
             ctx.save_for_backward(r["raw_f"] if n_f > 0 else r["raw_c"])
         elif not need:
             _release(r)
-        # the folded feature layer of the split-bf16 / mixed backward reads the LIVE parameters (Wf, bf, Wv) next to
+        # the folded feature layer of the split datapaths' backward reads the LIVE parameters (Wf, bf, Wv) next to
         # fragments packed at forward time: remember which parameter state this forward saw
         ctx.param_state = tuple(_param_state(m) for m in (model_c, model_f) if m is not None)
         ctx.consumed = False

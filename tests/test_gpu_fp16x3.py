@@ -140,7 +140,7 @@ def test_field_backward_fp16x3_arithmetic_and_flips(npa, dev, nets, n_rays, S):
 
 
 @pytest.mark.parametrize("precision", ["fp16x3", "bf16x3"])
-def test_split_backward_under_a_training_losss_upstream_gradient(npa, dev, nets, precision, monkeypatch):
+def test_split_backward_under_a_training_losss_upstream_gradient(npa, dev, nets, precision):
     """The same fp64 comparison (the kernel's own ReLU pattern forced) with the upstream gradient a training step produces:
     d_raw = the adjoint of raw2outputs for an MSE loss on 512 rays x 192 samples (98 k points).  Its sums over points are
     COHERENT, so the zero-mean rounding of the stored weight-gradient operands averages down relative to the result: whole-gradient
@@ -149,7 +149,6 @@ def test_split_backward_under_a_training_losss_upstream_gradient(npa, dev, nets,
     sampling's sensitivity to forward rounding instead, see test_fp16x3_training_gradient_full_batch_vs_the_fp32_datapath)."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
-    monkeypatch.setattr(hb, "WGRAD_OPERANDS", "bf16")
     n_rays, S = 512, 192
     P = n_rays * S
     g = torch.Generator().manual_seed(11)
@@ -218,30 +217,29 @@ def _compare_with_the_fp32_datapath(g, g32, label):
     return rel, cosdef
 
 
-def test_fp16x3_training_gradient_full_batch_vs_the_fp32_datapath(npa, dev, monkeypatch):
+def test_fp16x3_training_gradient_full_batch_vs_the_fp32_datapath(npa, dev):
     """BASELINE configs[1] batch (4096 rays x (64+128)): the gradient of the training loss on the fp16 split (fp16 operand storage)
-    against the EXACT-fp32 datapath's, next to round 3's two split-bf16 variants (bf16 / fp32 operand storage) against the same
-    reference.  (Not against another split datapath: the hierarchical samples depend on the coarse pass's rounding, so two
-    different forwards differ by sample positions, not by gradient arithmetic -- measured 6.6e-4 between fp16x3 and bf16x3.)
-    What the distance contains: the fp16 operand rounding (2^-12, zero-mean, averaged over 262 k / 786 k points), the chain's
-    2^-22 products and the sampling's sensitivity to forward rounding at the 2^-22 level."""
-    g32 = _flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch, precision="fp32")
-    rel, cosdef = _compare_with_the_fp32_datapath(_flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch, precision="fp16x3"), g32, "4096 rays, fp16x3 vs fp32 datapath")
-    rel_b, _ = _compare_with_the_fp32_datapath(_flat_grads_through_render(npa, dev, 4096, "bf16", monkeypatch), g32, "4096 rays, bf16x3 (bf16 operands) vs fp32 datapath")
-    rel_b32, _ = _compare_with_the_fp32_datapath(_flat_grads_through_render(npa, dev, 4096, "fp32", monkeypatch), g32, "4096 rays, bf16x3 (fp32 operands) vs fp32 datapath")
-    assert rel <= 6e-4 and cosdef <= 2e-7, (rel, cosdef)          # measured 3.5e-4 (bf16x3: 8.4e-4 / 8.3e-4 with bf16 / fp32 operand storage)
-    assert rel < rel_b and rel < rel_b32, (rel, rel_b, rel_b32)
+    against the EXACT-fp32 datapath's, next to the split-bf16 datapath against the same reference.  (Not one split datapath against
+    another: the hierarchical samples depend on the coarse pass's rounding, so two different forwards differ by sample positions,
+    not by gradient arithmetic -- measured 6.6e-4 between fp16x3 and bf16x3.)  What the distance contains: the fp16 operand
+    rounding (2^-12, zero-mean, averaged over 262 k / 786 k points; isolated: test_split_backward_under_a_training_losss_upstream_
+    gradient), the chain's 2^-22 products and the sampling's sensitivity to forward rounding at the 2^-22 level."""
+    g32 = _flat_grads_through_render(npa, dev, 4096, precision="fp32")
+    rel, cosdef = _compare_with_the_fp32_datapath(_flat_grads_through_render(npa, dev, 4096, precision="fp16x3"), g32, "4096 rays, fp16x3 vs fp32 datapath")
+    rel_b, _ = _compare_with_the_fp32_datapath(_flat_grads_through_render(npa, dev, 4096), g32, "4096 rays, bf16x3 vs fp32 datapath")
+    assert rel <= 6e-4 and cosdef <= 2e-7, (rel, cosdef)          # measured 3.5e-4 (bf16x3: 8.4e-4)
+    assert rel < rel_b, (rel, rel_b)
 
 
 @pytest.mark.parametrize("case", range(6))
-def test_fp16x3_gradient_on_every_golden_configuration_vs_the_fp32_datapath(npa, dev, nets, case, monkeypatch):
+def test_fp16x3_gradient_on_every_golden_configuration_vs_the_fp32_datapath(npa, dev, nets, case):
     """The same comparison on the six golden configurations (256 rays: 16 k / 49 k points per contraction): fp16x3 vs the exact-fp32
-    datapath, whole-gradient relative L2, next to bf16x3 with fp32 operand storage."""
+    datapath, whole-gradient relative L2, next to bf16x3."""
     name, kw, seed, through = GOLDEN_CASES[case]
     render = {None: None, "fern": (orc.FERN, orc.fern_batch(256, seed=3)), "lego": (orc.LEGO, orc.lego_batch(256, seed=7))}[through]
-    g32 = _golden_grads(npa, dev, nets, kw, seed, "bf16", monkeypatch, render, precision="fp32")
-    rel, cosdef = _compare_with_the_fp32_datapath(_golden_grads(npa, dev, nets, kw, seed, "bf16", monkeypatch, render, precision="fp16x3"), g32, f"{name}: fp16x3 vs fp32 datapath")
-    rel_b, _ = _compare_with_the_fp32_datapath(_golden_grads(npa, dev, nets, kw, seed, "fp32", monkeypatch, render), g32, f"{name}: bf16x3 (fp32 operands) vs fp32 datapath")
+    g32 = _golden_grads(npa, dev, nets, kw, seed, render, precision="fp32")
+    rel, cosdef = _compare_with_the_fp32_datapath(_golden_grads(npa, dev, nets, kw, seed, render, precision="fp16x3"), g32, f"{name}: fp16x3 vs fp32 datapath")
+    rel_b, _ = _compare_with_the_fp32_datapath(_golden_grads(npa, dev, nets, kw, seed, render), g32, f"{name}: bf16x3 vs fp32 datapath")
     # measured 3.9e-5 .. 2.8e-4, and 2.0e-3 on the two lego_train configurations (bf16x3 there: 3.0e-3): one ray with fine samples in bins
     # the coarse pass found empty (helpers:234-236) moves under any forward rounding -- the reference's own fp32 and fp64 runs differ likewise
     assert rel <= 3e-3 and cosdef <= 3e-6 and rel <= 1.2 * rel_b, (name, rel, cosdef, rel_b)

@@ -15,7 +15,24 @@ from test_gpu_parity import GOLD, _golden_randoms, dev, maxdiff, nets, npa  # no
 pytestmark = pytest.mark.gpu
 
 
-# ---------------------------------------------------------------- weight-ring forward
+# ---------------------------------------------------------------- weight-ring kernels vs the kernels they replaced
+_REF = None
+
+
+def _ref_lib(npa):
+    """libnerf_hip_ref.so: the superseded double-buffered split-bf16 kernels (csrc/ref/), built for these tests only -- they are not
+    part of the product library or of include/nerf_hip.h (round 4)."""
+    global _REF
+    if _REF is None:
+        import ctypes
+        lib = ctypes.CDLL(npa.build.build_ref())
+        i, p = ctypes.c_int, ctypes.c_void_p
+        lib.nerf_ref_field_fwd16.argtypes = [p, p, i, p, i, i, p, p, i, p]
+        lib.nerf_ref_field_dgrad3.argtypes = [p, p, p, i, i, p, i, p]
+        _REF = lib
+    return _REF
+
+
 @pytest.mark.parametrize("n_rays,S", [(37, 5), (129, 64), (512, 192), (333, 77), (1, 1)])
 def test_ring_forward_bit_identical(npa, dev, nets, n_rays, S):
     """field_fwd16r_kernel (weight ring, csrc/field_ring.h) against field_fwd16_kernel (double-buffered stream): the same
@@ -35,9 +52,9 @@ def test_ring_forward_bit_identical(npa, dev, nets, n_rays, S):
             act = torch.zeros(hb.act_floats(n_rays, S), device=dev) if save else None
             a = act.data_ptr() if save else None
             if kind == "stream":
-                rc = L.nerf_field_fwd16_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n_rays, S, raw.data_ptr(), a, 1, s)
+                rc = _ref_lib(npa).nerf_ref_field_fwd16(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n_rays, S, raw.data_ptr(), a, 1, s)
             else:
-                rc = L.nerf_field_fwd16r_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n_rays, S, raw.data_ptr(), a, s)
+                rc = L.nerf_field_fwd_split(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n_rays, S, raw.data_ptr(), a, 0, s)
             assert rc == 0, L.nerf_last_error()
             outs[(kind, save)] = (raw, act)
     torch.cuda.synchronize()
@@ -51,31 +68,30 @@ def test_ring_forward_bit_identical(npa, dev, nets, n_rays, S):
     assert torch.equal(outs[("ring", False)][0], outs[("ring", True)][0])      # inference == saving forward
 
 
-def test_ring_is_the_default_forward(npa, dev, nets):
-    """hip_backend routes the split-bf16 forward (inference and bf16 rows) through the ring kernel; fp32 rows stay on the
-    double-buffered kernel.  Checked through the per-kernel timer labels bench.py reports."""
+def test_the_split_forward_is_the_ring_kernel(npa, dev, nets):
+    """hip_backend routes the split forwards (inference and saving, either 16-bit type) through the weight-ring kernel.  Checked
+    through the per-kernel timer labels bench.py reports."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
-    assert hb.FWD_16PT and hb.FWD_RING
     rays = orc.synthetic_rays(16, seed=1).to(dev)
     z = torch.sort(torch.rand(16, 8, device=dev) * 4 + 2, -1)[0]
     hb.TIMER = hb.KernelTimer()
     try:
-        hb.field_fwd(nf.packed_params("bf16x3"), rays, z, save_act=False, precision="bf16x3")
-        _, act = hb.field_fwd(nf.packed_params("bf16x3"), rays, z, save_act=True, precision="bf16x3")
-        hb.WORKSPACE.give(act)
+        for prec in ("bf16x3", "fp16x3"):
+            hb.field_fwd(nf.packed_params(prec), rays, z, save_act=False, precision=prec)
+            _, act = hb.field_fwd(nf.packed_params(prec), rays, z, save_act=True, precision=prec)
+            hb.WORKSPACE.give(act)
         names = set(hb.TIMER.summary())
     finally:
         hb.TIMER = None
-    assert names == {"field_fwd16r_kernel", "field_fwd16r_kernel<save bf16>"} or hb.WGRAD_OPERANDS == "fp32", names
+    assert names == {"field_fwd16r_kernel", "field_fwd16r_kernel<save bf16>", "field_fwd16r_kernel<fp16>", "field_fwd16r_kernel<fp16, save>"}, names
 
 
-@pytest.mark.parametrize("bf16_out", [1, 0])
 @pytest.mark.parametrize("n_rays,S", [(37, 5), (129, 64), (256, 192), (333, 77), (1, 1)])
-def test_ring_dgrad_bit_identical(npa, dev, nets, n_rays, S, bf16_out):
+def test_ring_dgrad_bit_identical(npa, dev, nets, n_rays, S):
     """field_dgrad3r_kernel (weight ring, every MFMA with its share of the other work in its shadow) against
     field_dgrad3_kernel (double-buffered stream, work in bursts between the chunks): same transposed stream, same order
-    per accumulator, so every word of the delta buffer (bf16 or fp32 deltas, the tiled copy of d_raw) is bit-identical."""
+    per accumulator, so every word of the delta buffer (bf16 deltas, the tiled copy of d_raw) is bit-identical."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
     L = hb.lib()
@@ -87,11 +103,14 @@ def test_ring_dgrad_bit_identical(npa, dev, nets, n_rays, S, bf16_out):
     s = torch.cuda.current_stream().cuda_stream
     raw = torch.empty(n_rays, S, 4, device=dev)
     act = torch.zeros(hb.act_floats(n_rays, S), device=dev)
-    assert L.nerf_field_fwd16r_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n_rays, S, raw.data_ptr(), act.data_ptr(), s) == 0
+    assert L.nerf_field_fwd_split(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n_rays, S, raw.data_ptr(), act.data_ptr(), 0, s) == 0
     out = []
-    for fn in (L.nerf_field_dgrad_bf16x3, L.nerf_field_dgrad3r_bf16x3):
+    for ring in (False, True):
         delta = torch.zeros(L.nerf_delta_floats(n_rays, S), device=dev)
-        assert fn(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n_rays, S, delta.data_ptr(), bf16_out, s) == 0, L.nerf_last_error()
+        if ring:
+            assert L.nerf_field_dgrad_split(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n_rays, S, delta.data_ptr(), 0, s) == 0, L.nerf_last_error()
+        else:
+            assert _ref_lib(npa).nerf_ref_field_dgrad3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n_rays, S, delta.data_ptr(), 2, s) == 0
         out.append(delta)
     torch.cuda.synchronize()
     assert int((out[1] != 0).sum()) > 0
@@ -141,23 +160,22 @@ def _field_with_forced_relu(P64, feats, masks):
     return torch.cat([rgb, sigma], -1), pres
 
 
-@pytest.mark.parametrize("operands", ["bf16", "fp32"])
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192), (70, 20)])
-def test_field_backward_bf16x3_arithmetic_and_flips(npa, dev, nets, n_rays, S, operands, monkeypatch):
+def test_field_backward_bf16x3_arithmetic_and_flips(npa, dev, nets, n_rays, S):
     """The split-bf16 backward held to fp32-class ARITHMETIC bounds.  A ReLU unit whose pre-activation lies within the
     forward's error of zero legitimately takes either side of its kink (test_field_backward separates these points with a
     mask for the fp32 datapath; here a few units per point are affected, so masking points would leave nothing).  The
     two effects are separated exactly instead: the kernel SAVES the ReLU pattern it used (the bitmasks dgrad reads), so
       (1) the gradient is compared with fp64 autograd of the reference network evaluated with THAT pattern: what remains
-          is arithmetic error, held to 1e-3 of max|g| per tensor with fp32 operand storage.  With bf16 operand storage
-          the bound is 8e-3 (measured 5.4e-3 on rgb_linear.weight, 384 entries): the upstream gradient here is RANDOM, the worst case for the zero-mean 2^-9 operand rounding
-          (incoherent sums: it does not average down relative to the result; on the coherent gradient of a
-          training loss the same rounding is 1e-4, test_bf16_operand_storage_*);
+          is arithmetic error: the three-term products and the bf16 rounding (2^-9, zero-mean) of the stored weight-gradient
+          operands, held to 8e-3 of max|g| per tensor (measured 5.4e-3 on rgb_linear.weight, 384 entries): the upstream gradient
+          here is RANDOM, the worst case for that rounding (incoherent sums: it does not average down relative to the result; under
+          a training loss's upstream gradient it is 1.6e-4 of the gradient, test_gpu_fp16x3.py, and the fp16 split's 11-bit
+          operands bring both numbers down 8x);
       (2) the pattern itself is compared with fp64's: every unit that differs must have |fp64 pre-activation| within the
           forward's error bound of zero, and such units must be rare."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
-    monkeypatch.setattr(hb, "WGRAD_OPERANDS", operands)
     g = torch.Generator().manual_seed(7 * n_rays + S)
     rays = orc.synthetic_rays(n_rays, seed=S + 1)
     z = torch.sort(torch.rand(n_rays, S, generator=g) * 4.0 + 2.0, -1)[0]
@@ -183,7 +201,7 @@ def test_field_backward_bf16x3_arithmetic_and_flips(npa, dev, nets, n_rays, S, o
         gg = grad[off:off + int(np.prod(shape))].view(shape)
         r = P64[nm].grad
         worst[nm] = maxdiff(gg, r) / max(float(r.abs().max()), 1e-30)
-    bound = 1e-3 if operands == "fp32" else 8e-3
+    bound = 8e-3
     # (2) flips
     n_units = flips = 0
     worst_pre = 0.0
@@ -195,7 +213,7 @@ def test_field_backward_bf16x3_arithmetic_and_flips(npa, dev, nets, n_rays, S, o
         if diff.any():
             scale = max(1.0, float(pre.detach().abs().max()))
             worst_pre = max(worst_pre, float(pre.detach().abs()[diff].max()) / scale)
-    print(f"bf16x3 backward [{operands} operands] vs fp64 with the kernel's own ReLU pattern: max|err|/max|g| "
+    print(f"bf16x3 backward vs fp64 with the kernel's own ReLU pattern: max|err|/max|g| "
           f"{max(worst.values()):.1e} ({max(worst, key=worst.get)}); ReLU units on the other side of their kink: {flips} of {n_units} "
           f"({flips / P:.2f} per point), largest |pre-activation| among them {worst_pre:.1e} of the layer's max")
     assert max(worst.values()) <= bound, worst
@@ -215,9 +233,8 @@ GOLDEN_CASES = [
 ]
 
 
-def _golden_grads(npa, dev, nets, kw, seed, operands, monkeypatch, render=None, precision="bf16x3"):
+def _golden_grads(npa, dev, nets, kw, seed, render=None, precision="bf16x3"):
     nc, nf, Pc, Pf = nets
-    monkeypatch.setattr(npa.hip_backend, "WGRAD_OPERANDS", operands)
     target = torch.tensor(np.random.RandomState(99).rand(256, 3), dtype=torch.float32).to(dev)
     args = dict(N_samples=64, retraw=True, N_importance=128, network_fine=nf, perturb=0., white_bkgd=True, raw_noise_std=0., lindisp=False)
     args.update(kw)
@@ -244,23 +261,6 @@ def _golden_grads(npa, dev, nets, kw, seed, operands, monkeypatch, render=None, 
     if args["N_importance"] > 0:
         gs.append(nf.last_flat_grad.double().cpu())
     return torch.cat(gs)
-
-
-@pytest.mark.parametrize("case", range(6))
-def test_bf16_operand_storage_on_every_golden_configuration(npa, dev, nets, case, monkeypatch):
-    """bf16 vs fp32 storage of the weight-gradient GEMM's operands (everything else identical) on the six golden
-    configurations (4 x render_rays, 2 x through render() incl. fern / NDC): 256 rays x (64 [+ 192]) points each.  The
-    rounding is zero-mean and averages with the number of points of the contraction (16 k coarse / 49 k fine here, against
-    262 k / 786 k of a training batch, where test_bf16_operand_storage_full_batch holds 3e-4 / 1e-7): bounds 1.5e-3 relative
-    L2 of the whole gradient, cosine deficit 2e-6."""
-    name, kw, seed, through = GOLDEN_CASES[case]
-    render = {None: None, "fern": (orc.FERN, orc.fern_batch(256, seed=3)), "lego": (orc.LEGO, orc.lego_batch(256, seed=7))}[through]
-    g16 = _golden_grads(npa, dev, nets, kw, seed, "bf16", monkeypatch, render)
-    g32 = _golden_grads(npa, dev, nets, kw, seed, "fp32", monkeypatch, render)
-    rel = float((g16 - g32).norm() / g32.norm())
-    cosdef = 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm()))
-    print(f"{name}: bf16 vs fp32 operand storage: relative L2 {rel:.2e}, cosine deficit {cosdef:.1e}")
-    assert rel <= 1.5e-3 and cosdef <= 2e-6, (name, rel, cosdef)
 
 
 # ---------------------------------------------------------------- chunked rendering with injected draws
@@ -404,15 +404,15 @@ def _one_call_step(npa, dev, flat_c, flat_f, rays, rnd, target, precision, lr_st
     n = rays.shape[0]
     s = torch.cuda.current_stream().cuda_stream
     ptr = lambda t: None if t is None else t.data_ptr()
-    prec = {"fp32": 0, "bf16x3": 1, "mixed": 2, "fp16x3": 3}[precision]
-    cfg = hb.NerfRenderCfg(64, 128, 0, 1, 1.0 if "noise_c" in rnd else 0.0, prec, int(hb.WGRAD_OPERANDS == "bf16"))
+    prec = {"fp32": 0, "bf16x3": 1, "fp16x3": 3}[precision]
+    cfg = hb.NerfRenderCfg(64, 128, 0, 1, 1.0 if "noise_c" in rnd else 0.0, prec, 0)
     packed = []
     for flat in (flat_c, flat_f):
         p = torch.empty(L.nerf_packed3_floats() if prec else L.nerf_packed_floats(), device=dev)
-        if prec == 3:
-            assert L.nerf_pack_params_split(flat.data_ptr(), p.data_ptr(), 15, 1, s) == 0
+        if prec:
+            assert L.nerf_pack_params_split(flat.data_ptr(), p.data_ptr(), 5, int(prec == 3), s) == 0
         else:
-            assert (L.nerf_pack_params_bf16x3 if prec else L.nerf_pack_params)(flat.data_ptr(), p.data_ptr(), s) == 0
+            assert L.nerf_pack_params(flat.data_ptr(), p.data_ptr(), s) == 0
         packed.append(p)
     ws = torch.empty(L.nerf_render_workspace_floats(ctypes.byref(cfg), n, 1), device=dev)
     o = dict(rgb=torch.empty(n, 3, device=dev), disp=torch.empty(n, device=dev), acc=torch.empty(n, device=dev),
@@ -436,7 +436,7 @@ def _one_call_step(npa, dev, flat_c, flat_f, rays, rnd, target, precision, lr_st
     return o, gc, gf
 
 
-@pytest.mark.parametrize("precision,noise", [("fp32", False), ("bf16x3", True), ("mixed", False), ("fp16x3", True)])
+@pytest.mark.parametrize("precision,noise", [("fp32", False), ("bf16x3", True), ("fp16x3", True)])
 def test_one_call_abi_matches_the_binding(npa, dev, nets, precision, noise):
     """nerf_render_rays_fwd / _bwd (one C call per direction, caller-owned workspace) against the in-repo binding's
     render_rays + autograd on the same rays, draws and weights: the same launches in the same order, so outputs and both
@@ -545,7 +545,7 @@ def test_one_call_abi_trains_two_steps(npa, dev, nets):
 
 
 def test_weight_gradient_refuses_mismatched_buffers_on_the_gpu(npa, dev, nets):
-    """The pairing checks of the C ABI with real buffers: bf16 rows + fp32 deltas, a save buffer of another sample count."""
+    """The pairing checks of the C ABI with real buffers: bf16 rows + fp16 deltas, a save buffer of another sample count."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
     L = hb.lib()
@@ -560,13 +560,13 @@ def test_weight_gradient_refuses_mismatched_buffers_on_the_gpu(npa, dev, nets):
     delta = torch.empty(L.nerf_delta_floats(n, S), device=dev)
     partial = torch.empty(L.nerf_wgrad_partial_floats(n, S), device=dev)
     grad = torch.empty(hb.N_PARAMS, device=dev)
-    assert L.nerf_field_fwd16r_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n, S, raw.data_ptr(), act.data_ptr(), s) == 0
+    assert L.nerf_field_fwd_split(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n, S, raw.data_ptr(), act.data_ptr(), 0, s) == 0
     assert hb.buffer_layout(act) == (4, False, n, S)
-    assert L.nerf_field_dgrad3r_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n, S, delta.data_ptr(), 0, s) == 0      # fp32 deltas
+    assert L.nerf_field_dgrad_split(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n, S, delta.data_ptr(), 1, s) == 0      # fp16 deltas
     args = (act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), n, S, partial.data_ptr(), grad.data_ptr(), 0)
     assert L.nerf_field_wgrad_phase(*args, -1, 7, nf.flat_params().data_ptr(), s) == -1 and b"different datapaths" in L.nerf_last_error()
-    assert L.nerf_field_dgrad3r_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n, S // 2, delta.data_ptr(), 1, s) == -1
-    assert L.nerf_field_dgrad3r_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n, S, delta.data_ptr(), 1, s) == 0
+    assert L.nerf_field_dgrad_split(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n, S // 2, delta.data_ptr(), 0, s) == -1
+    assert L.nerf_field_dgrad_split(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n, S, delta.data_ptr(), 0, s) == 0
     assert L.nerf_field_wgrad_phase(*args, -1, 7, nf.flat_params().data_ptr(), s) == 0
     torch.cuda.synchronize()
     assert bool(torch.isfinite(grad).all())
@@ -574,7 +574,7 @@ def test_weight_gradient_refuses_mismatched_buffers_on_the_gpu(npa, dev, nets):
 
 # ---------------------------------------------------------------- render_rays without gradients in one launch
 @pytest.mark.parametrize("n_rays", [1, 17, 129, 1000])
-@pytest.mark.parametrize("case", ["det", "random_white_noise", "lindisp", "coarse_only", "small", "mixed_same_net", "fp16x3_det", "fp16x3_random_white_noise"])
+@pytest.mark.parametrize("case", ["det", "random_white_noise", "lindisp", "coarse_only", "small", "same_net", "fp16x3_det", "fp16x3_random_white_noise"])
 def test_one_launch_inference_is_bit_identical_to_the_chain_of_launches(npa, dev, nets, n_rays, case, monkeypatch):
     """render_infer_kernel (csrc/render_fused.hip): a workgroup takes 16 rays from the coarse depths through both networks,
     raw2outputs and sample_pdf + sort to the colours, calling the SAME device code as the separate launches -- so every
@@ -586,14 +586,14 @@ def test_one_launch_inference_is_bit_identical_to_the_chain_of_launches(npa, dev
     n_c, n_f = {"coarse_only": (64, 0), "small": (8, 16)}.get(case, (64, 128))
     kw = dict(N_samples=n_c, N_importance=n_f, network_fine=nf, retraw=True)
     rnd = None
-    prec = "mixed" if case == "mixed_same_net" else ("fp16x3" if case.startswith("fp16x3") else "bf16x3")
+    prec = "fp16x3" if case.startswith("fp16x3") else "bf16x3"
     case = case.replace("fp16x3_", "")
     if case == "random_white_noise":
         kw.update(white_bkgd=True, perturb=1.0, raw_noise_std=0.7)
         rnd = {k: v.to(dev) for k, v in orc.synthetic_randoms(n_rays, n_c, n_f, seed=11).items()}
     elif case == "lindisp":
         kw.update(lindisp=True, white_bkgd=True)
-    elif case == "mixed_same_net":
+    elif case == "same_net":
         kw.update(network_fine=None, white_bkgd=True)
     rays = orc.synthetic_rays(n_rays, seed=91).to(dev)
     npa.set_precision(prec)
@@ -619,14 +619,14 @@ def test_one_launch_inference_is_bit_identical_to_the_chain_of_launches(npa, dev
 
 
 def test_one_launch_inference_refuses_what_it_cannot_tile(npa, dev, nets):
-    """16 rays must fill whole 128-point tiles in both passes and the datapath must be split-bf16 / mixed: anything else is
+    """16 rays must fill whole 128-point tiles in both passes and the datapath must be a three-term split: anything else is
     NERF_E_BADARG from the C entry point (and the host code keeps the chain of launches)."""
     import ctypes
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
     L = hb.lib()
     assert not hb.render_infer_supported(63, 128, "bf16x3") and not hb.render_infer_supported(64, 127, "bf16x3")
-    assert not hb.render_infer_supported(64, 128, "fp32") and hb.render_infer_supported(64, 128, "mixed")
+    assert not hb.render_infer_supported(64, 128, "fp32") and hb.render_infer_supported(64, 128, "fp16x3")
     assert not hb.render_infer_supported(512, 1024, "bf16x3")      # per-ray scratch beyond one wavefront's share of the LDS
     cfg = hb.render_cfg(63, 128, False, True, 0.0, "bf16x3")
     n = 16

@@ -243,65 +243,43 @@ def test_frame_sink_orders_frames_and_writes_the_same_pngs(tmp_path):
 
 
 def test_precision_selection_and_saved_row_views():
-    """set_precision accepts the five datapaths and rejects anything else; saved_rows inverts the tile layout of
-    csrc/nerf_common.h (element (p, f) of an F-wide region at (p/32)*F*32 + f*32 + p%32, fp32 or bf16)."""
-    assert npa.hip_backend.PRECISIONS == ("fp32", "bf16x3", "mixed", "fp16x3", "fp16_fp8c")
+    """set_precision accepts the four datapaths and rejects anything else; saved_rows inverts the tile layouts of
+    csrc/nerf_common.h: 16-bit elements (bf16 / fp16 by precision), element (p, f) of an F-wide region at (p/32)*F*32 + f*32 + p%32
+    (deltas, encodings) or, for the rows the forward saves, in 16-point tiles with the row16h row order."""
+    assert npa.hip_backend.PRECISIONS == ("fp32", "fp16x3", "bf16x3", "fp16_fp8c")
     prev = npa.get_precision()
     try:
         for mode in npa.hip_backend.PRECISIONS:
             npa.set_precision(mode)
             assert npa.get_precision() == mode
-        with pytest.raises(ValueError):
-            npa.set_precision("fp16")
+        for bad in ("fp16", "mixed"):
+            with pytest.raises(ValueError):
+                npa.set_precision(bad)
     finally:
         npa.set_precision(prev)
     P, Pp = 70, 96
     widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
     total = sum(Pp * F for _, F in widths)
-    want = {name: torch.randn(P, F).bfloat16().float() for name, F in widths}        # bf16-exact values for both element types
-    buf32 = torch.zeros(total)
-    buf16 = torch.zeros(total).view(torch.bfloat16)                                  # 2-byte elements, same float offsets
-    off = 0
-    for name, F in widths:
-        p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
-        idx = (p // 32) * F * 32 + f * 32 + p % 32
-        buf32[off + idx] = want[name]
-        buf16[2 * off + idx] = want[name].bfloat16()
-        off += Pp * F
-    for name, F in widths:
-        assert torch.equal(npa.hip_backend.saved_rows(buf32, P, name, "bf16x3"), want[name])
-        assert torch.equal(npa.hip_backend.saved_rows(buf16.view(torch.float32), P, name, "mixed"), want[name])
     flat = torch.arange(P * 2688, dtype=torch.float32)
     assert torch.equal(npa.hip_backend.saved_rows(flat, P, "h1", "fp32"), flat[P * 256:2 * P * 256].view(P, 256))
-    # rows saved by the 16-point forward: 16-point tiles, feature 4*q + j of a 16-block at row 8*(q>>1) + 2*j + (q&1)
-    buf16t = torch.zeros(total)
-    off = 0
-    for name, F in widths:
-        p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
-        if F in (256, 128):
-            q, j = (f % 16) // 4, f % 4
-            row = (f // 16) * 16 + 8 * (q >> 1) + 2 * j + (q & 1)
-            idx = (p // 16) * F * 16 + row * 16 + p % 16
-        else:
-            idx = (p // 32) * F * 32 + f * 32 + p % 32
-        buf16t[off + idx] = want[name]
-        off += Pp * F
-    for name, F in widths:
-        assert torch.equal(npa.hip_backend.saved_rows(buf16t, P, name, "bf16x3", tile16=True), want[name]), name
-    # bf16 rows saved by the 16-point forward (operands of the bf16 weight-gradient GEMM): 16-point tiles of 2-byte
-    # elements, row16h row order (one paired store instruction = 8 consecutive rows = two full lines); the 64-wide
-    # encoding stays in 32-point tiles
-    bufh = torch.zeros(total).view(torch.bfloat16)
-    off = 0
-    for name, F in widths:
-        p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
-        rowh = (f // 16) * 16 + 8 * ((f >> 1) & 1) + 2 * ((f >> 2) & 3) + (f & 1)     # feature 4q + r at row 8*(r>>1) + 2q + (r&1)
-        idx = (p // 16) * F * 16 + rowh * 16 + p % 16 if F in (256, 128) else (p // 32) * F * 32 + f * 32 + p % 32
-        bufh[2 * off + idx] = want[name].bfloat16()
-        off += Pp * F
-    for name, F in widths:
-        assert torch.equal(npa.hip_backend.saved_rows(bufh.view(torch.float32), P, name, "bf16x3", tile16=True, bf16=True), want[name]), name
-    assert npa.hip_backend.WGRAD_OPERANDS in ("bf16", "fp32")
+    for precision, dt in (("bf16x3", torch.bfloat16), ("fp16x3", torch.float16)):
+        want = {name: torch.randn(P, F).to(dt).float() for name, F in widths}
+        # 32-point feature-major tiles of 2-byte elements (deltas, encodings), same float offsets as fp32 regions
+        buf16 = torch.zeros(total).view(dt)
+        # rows saved by the forward: 16-point tiles, row16h row order (one paired store instruction = 8 consecutive rows = two full
+        # lines); the 64-wide encoding stays in 32-point tiles
+        bufh = torch.zeros(total).view(dt)
+        off = 0
+        for name, F in widths:
+            p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
+            buf16[2 * off + (p // 32) * F * 32 + f * 32 + p % 32] = want[name].to(dt)
+            rowh = (f // 16) * 16 + 8 * ((f >> 1) & 1) + 2 * ((f >> 2) & 3) + (f & 1)     # feature 4q + r at row 8*(r>>1) + 2q + (r&1)
+            idx = (p // 16) * F * 16 + rowh * 16 + p % 16 if F in (256, 128) else (p // 32) * F * 32 + f * 32 + p % 32
+            bufh[2 * off + idx] = want[name].to(dt)
+            off += Pp * F
+        for name, F in widths:
+            assert torch.equal(npa.hip_backend.saved_rows(buf16.view(torch.float32), P, name, precision, tile16=False), want[name]), name
+            assert torch.equal(npa.hip_backend.saved_rows(bufh.view(torch.float32), P, name, precision, tile16=True), want[name]), name
     # one store instruction of that kernel (j fixed, q = 0..3) covers rows {2j, 2j+1} and {8+2j, 8+2j+1}: two full lines
     r16 = npa.hip_backend._row16
     for j in range(4):
@@ -431,30 +409,31 @@ def test_buffer_tags_refuse_mismatched_pairings():
     packed, rays, z, raw, act, act2, delta, d_raw, partial, grad, params = (0x10000 * (k + 1) for k in range(11))
     kind = lambda buf: L.nerf_buffer_layout(buf, None, None, None)
     assert kind(act) == -1                                                   # unknown buffer
-    assert L.nerf_field_fwd16r_bf16x3(packed, rays, 11, z, 0, 64, raw, act, None) == 0
+    assert L.nerf_field_fwd_split(packed, rays, 11, z, 0, 64, raw, act, 0, None) == 0
     assert kind(act) == 4                                                    # rows in 16-point bf16 tiles
     assert L.nerf_field_fwd(packed, rays, 11, z, 0, 64, raw, act2, None) == 0
     assert kind(act2) == 0                                                   # fp32 point-major rows
     # a split-bf16 dgrad on the fp32 forward's save buffer (other bitmask order, other layout): refused
-    assert L.nerf_field_dgrad3r_bf16x3(packed, act2, d_raw, 0, 64, delta, 1, None) == -1
+    assert L.nerf_field_dgrad_split(packed, act2, d_raw, 0, 64, delta, 0, None) == -1
     assert b"exact-fp32 forward" in L.nerf_last_error()
     assert L.nerf_field_dgrad(packed, act, d_raw, 0, 64, delta, None) == -1
     # other sample count than the forward's: refused
-    assert L.nerf_field_dgrad3r_bf16x3(packed, act, d_raw, 0, 32, delta, 1, None) == -1
-    # bf16 rows + fp32 deltas: no weight-gradient datapath contracts that pair
-    assert L.nerf_field_dgrad3r_bf16x3(packed, act, d_raw, 0, 64, delta, 0, None) == 0
+    assert L.nerf_field_dgrad_split(packed, act, d_raw, 0, 32, delta, 0, None) == -1
+    # bf16 rows + fp16 deltas: no weight-gradient datapath contracts that pair
+    assert L.nerf_field_dgrad_split(packed, act, d_raw, 0, 64, delta, 1, None) == 0
     is_delta = ctypes.c_int(0)
-    assert L.nerf_buffer_layout(delta, ctypes.byref(is_delta), None, None) == 1 and is_delta.value == 1
+    assert L.nerf_buffer_layout(delta, ctypes.byref(is_delta), None, None) == 3 and is_delta.value == 1
     assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, -1, 7, params, None) == -1
     assert b"different datapaths" in L.nerf_last_error()
     # the matching pair: datapath -1 resolves to 4; an explicit other datapath is refused
-    assert L.nerf_field_dgrad3r_bf16x3(packed, act, d_raw, 0, 64, delta, 1, None) == 0
+    assert L.nerf_field_dgrad_split(packed, act, d_raw, 0, 64, delta, 0, None) == 0
     assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, -1, 7, params, None) == 0
     assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, 4, 7, params, None) == 0
-    assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, 2, 7, params, None) == -1
-    assert b"datapath 2 requested" in L.nerf_last_error()
+    assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, 5, 7, params, None) == -1
+    assert b"datapath 5 requested" in L.nerf_last_error()
+    assert L.nerf_field_wgrad_phase(act, delta, d_raw, 0, 64, partial, grad, 0, 2, 7, params, None) == -1          # no such datapath any more
     # act and delta swapped
     assert L.nerf_field_wgrad_phase(delta, act, d_raw, 0, 64, partial, grad, 0, -1, 7, params, None) == -1
     # buffers the library never wrote are not checked (datapath must then be given)
-    assert L.nerf_field_wgrad_phase(0x900000, 0xA00000, d_raw, 0, 64, partial, grad, 0, 2, 7, params, None) == 0
+    assert L.nerf_field_wgrad_phase(0x900000, 0xA00000, d_raw, 0, 64, partial, grad, 0, 5, 7, params, None) == 0
     assert L.nerf_field_wgrad_phase(0x900000, 0xA00000, d_raw, 0, 64, partial, grad, 0, -1, 7, params, None) == -1

@@ -14,7 +14,7 @@ kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, us
 nc, nf = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
 nc.load_state_dict(Pc)
 nf.load_state_dict(Pf)
-npa.set_precision("bf16x3")
+npa.set_precision("fp16x3")
 for n in (1024, 4096, 5000, 32768):
     rays = wl.synthetic_rays(n, seed=1).to(dev)
     res = {}

@@ -14,7 +14,7 @@ L = hb.lib()
 Pc, Pf = wl.scene_params()
 nf = npa.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True).to(dev)
 nf.load_state_dict(Pf)
-p3 = nf.packed_params("bf16x3")
+p3 = nf.packed_params("fp16x3")
 s = torch.cuda.current_stream().cuda_stream
 N = 4096
 rays = wl.synthetic_rays(N, seed=1).to(dev)
@@ -23,7 +23,7 @@ for S in (64, 192):
     bufs[S] = (torch.sort(torch.rand(N, S, device=dev) * 4 + 2, -1)[0], torch.empty(N, S, 4, device=dev), torch.empty(hb.act_floats(N, S), device=dev))
 def fwd(S, save=True):
     z, raw, act = bufs[S]
-    assert L.nerf_field_fwd16r_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, S, raw.data_ptr(), act.data_ptr() if save else None, s) == 0
+    assert L.nerf_field_fwd_split(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, S, raw.data_ptr(), act.data_ptr() if save else None, 1, s) == 0
 def timed(seq):
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)]
     evs[0].record()

@@ -1,5 +1,5 @@
-"""Board power and clocks while one kernel runs back to back (rocm-smi sampled from a second thread): is the MFMA roof the
-power cap?  Usage: python tools/exp_power.py"""
+"""Board power and clocks while one kernel of the fp16x3 datapath runs back to back (rocm-smi sampled from a second thread): what clock
+does the chip grant under each heavy kernel, and at what package power?  Usage: python tools/exp_power.py"""
 import os, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,8 +14,9 @@ Pc, Pf = wl.scene_params()
 kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
 net = npa.NeRF(**kw).to(dev)
 net.load_state_dict(Pf)
-p3 = net.packed_params("bf16x3")
+p3 = net.packed_params("fp16x3")
 flat = net.flat_params()
+p8 = net.packed_params("fp16_fp8c")
 N, S = 4096, 192
 rays = wl.synthetic_rays(N, seed=1).to(dev)
 z = torch.sort(torch.rand(N, S, device=dev) * 4 + 2, -1)[0]
@@ -28,9 +29,10 @@ grad = torch.empty(hb.N_PARAMS, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 K = {
     "idle": None,
-    "forward (inference)": lambda: L.nerf_field_fwd16r_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, S, raw.data_ptr(), None, st),
-    "forward (saving)": lambda: L.nerf_field_fwd16r_bf16x3(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, S, raw.data_ptr(), act.data_ptr(), st),
-    "dgrad": lambda: L.nerf_field_dgrad3r_bf16x3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, S, delta.data_ptr(), 1, st),
+    "forward (inference)": lambda: L.nerf_field_fwd_split(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, S, raw.data_ptr(), None, 1, st),
+    "forward (inference, fp16 + fp8c)": lambda: L.nerf_field_fwd_split(p8.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, S, raw.data_ptr(), None, 2, st),
+    "forward (saving)": lambda: L.nerf_field_fwd_split(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), N, S, raw.data_ptr(), act.data_ptr(), 1, st),
+    "dgrad": lambda: L.nerf_field_dgrad_split(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), N, S, delta.data_ptr(), 1, st),
     "wgrad": lambda: L.nerf_field_wgrad_phase(act.data_ptr(), delta.data_ptr(), d_raw.data_ptr(), N, S, partial.data_ptr(), grad.data_ptr(), 0, -1, 3,
                                               flat.data_ptr(), st),
 }

@@ -18,7 +18,7 @@ def pose(theta):        # camera on a circle of radius 4 looking at the origin
 poses = torch.stack([pose(0.15 * i) for i in range(int(os.environ.get("FRAMES", 6)))]).to(dev)
 rk = dict(network_fn=nc, network_query_fn=None, N_samples=64, N_importance=128, network_fine=nf, perturb=0., white_bkgd=True,
           raw_noise_std=0., ndc=False, near=2., far=6., use_viewdirs=True)
-npa.set_precision(os.environ.get("PREC", "bf16x3"))
+npa.set_precision(os.environ.get("PREC", "fp16x3"))
 with torch.no_grad(), tempfile.TemporaryDirectory() as d:
     npa.render_path(poses[:1], (H, W, focal), K, 32768, rk)          # warm-up
     for savedir in (None, d):

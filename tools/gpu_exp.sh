@@ -1,4 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out/r04
-timeout 900 python -m pytest tests/test_gpu_fp16x3.py tests/test_gpu_parity.py -m gpu -q -s -k "reduced or (gate_psnr and fp16_fp8c)" 2>&1 | grep -E "^E  |reduced class|fp16_fp8c|passed|failed" | cut -c1-400 | tee gpurun_out/r04/t_red.log
-timeout 300 python tools/exp_reduced.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04/reduced_timing.txt
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -60 > gpurun_out/check_tests.log; tail -25 gpurun_out/check_tests.log
+timeout 200 python __graft_entry__.py smoke 2>&1 | tail -4
+timeout 900 python bench.py > gpurun_out/check_bench.json 2> gpurun_out/check_bench.err; tail -c 300 gpurun_out/check_bench.err; python -c "
+import json
+d=json.loads([l for l in open('gpurun_out/check_bench.json') if l.startswith('{')][-1])
+print(d['value'], d['ms_per_step'], d.get('sustained_rays_per_s'), d.get('errors'), d['speedup_vs_rocm_eager'])
+print(d['precision_gate'].get('gradient'), d['roofline'].get('traffic'))
+"
