@@ -152,7 +152,7 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
  *   Range (split = 1): weights, encodings and activations must stay below 65520 in magnitude (a NeRF's are O(1..100)); an overflow
  * turns into inf / NaN in `raw` (the ReLU propagates NaN).  Deltas are tiny (upstream gradients ~1e-6): nerf_field_dgrad_split(split
  * = 1) first reduces max|d_raw| on the device and runs the chain on s * d_raw with s the power of two that puts that maximum in
- * [16, 32) (the chain is linear; s and 1/s live in the delta buffer), every stored delta and partial weight gradient carries s, and
+ * [16, 32) (the chain is linear; the maximum lives in the delta buffer), every stored delta and partial weight gradient carries s, and
  * the reduction phase of nerf_field_wgrad_phase multiplies by 1/s -- exact.  A non-finite d_raw propagates to the gradient.
  * Replace run_nerf.py:37-51 + run_nerf_helpers.py:15-45, :96-119 and their autograd like nerf_field_fwd / nerf_field_bwd. */
 int nerf_packed3_floats(void);

@@ -580,17 +580,17 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
 // fold == 1 (split datapaths, feature layer folded into the view branch, nerf_common.h): the job (delta_hv, h7) left
 //   G = delta_hv^T h7 in the slot of views_linears.0.weight[:, :256]; G and this call's dbv = sum delta_hv go to
 //   `scratch` ([128][256] | [128]) for wgrad_fold_kernel, and feature_linear.{weight,bias} / Wv[:, :256] are left to it.
-// inv_scale (nullable): device word holding 1 / s of the launch's delta scale (fp16 split, DeltaLayout3::scale): every partial
-// sum carries the factor s = 2^k, removed here exactly.
+// amax (nullable): device word holding the bit pattern of the launch's max|d_raw| (fp16 split, DeltaLayout3::scale): every partial
+// sum carries the factor s = delta_scale_bits(amax) = 2^k, removed here exactly.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chunks, float* __restrict__ grad, int accumulate,
-                                    int fold, float* __restrict__ scratch, const float* __restrict__ inv_scale) {
+                                    int fold, float* __restrict__ scratch, const unsigned* __restrict__ amax) {
     constexpr Canon cn = canon();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N_PARAMS) return;
     if (fold && i >= cn.wf && i < cn.bf + W) return;                    // produced by wgrad_fold_kernel (no partials exist)
     float s = 0.0f;
     for (int cix = 0; cix < n_chunks; ++cix) s += partial[(size_t)cix * N_PARAMS + i];
-    if (inv_scale) s *= inv_scale[0];
+    if (amax) s *= __uint_as_float(delta_scale_bits(amax[0], true));
     if (fold) {
         if (i >= cn.wv && i < cn.bv) {
             const int k = (i - cn.wv) / (W + IN_DIR), col = (i - cn.wv) % (W + IN_DIR);
@@ -737,12 +737,12 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     // operand bases.  fp32 datapath: point-major rows (lda = row pitch); bf16x3: 32-point feature-major tiles
     // (lda = features per tile, a feature offset f0 is folded into the base as f0 * 32)
     const float *d_h[D], *d_feat, *d_hv, *d_rgb, *d_sigma, *x_h[D], *x_feat, *x_hv, *x_enc, *x_dir;
-    const float* inv_scale = nullptr;
+    const unsigned* amax = nullptr;
     int ld_graw;
     if (bf16x3) {
         const ActLayout3 al = act_layout3((size_t)P, (size_t)n_rays);
         const DeltaLayout3 dl = delta_layout3((size_t)P);
-        if (f16) inv_scale = delta + dl.scale + 1;
+        if (f16) amax = reinterpret_cast<const unsigned*>(delta + dl.scale);
         for (int l = 0; l < D; ++l) { d_h[l] = delta + dl.h[l]; x_h[l] = act + al.h[l]; }
         d_feat = delta + dl.feat; d_hv = delta + dl.hv; d_rgb = delta + dl.graw;
         // feature 3 of the 4-wide tile: 3 rows of 32 two-byte elements
@@ -868,7 +868,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     if (phases & 4) {
         float* scratch = partial + wgrad_partial_floats(P) - N_DERIVED;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, stream,
-                           (const float*)partial, n_chunks, grad, accumulate, fold ? 1 : 0, scratch, inv_scale);
+                           (const float*)partial, n_chunks, grad, accumulate, fold ? 1 : 0, scratch, amax);
         if (fold)
             hipLaunchKernelGGL(wgrad_fold_kernel, dim3((WV * W + W * W + W + 255) / 256), dim3(256), 0, stream,
                                params, (const float*)scratch, grad, accumulate);

@@ -9,7 +9,7 @@
 // Same transposed fragment stream (P3B), same MFMA order per accumulator, same masks: every delta written is
 // BIT-IDENTICAL to field_dgrad3_kernel<MODE> (tests/test_gpu_round3.py::test_ring_dgrad_bit_identical).
 // MODE 0: fp32 deltas (operands of wgrad3_256_kernel); MODE 2: the same chain, deltas written as 16-bit elements of the split's
-// type SP (split_types.h; wgrad1_kernel).  SP = SplitF16: the chain runs on s * d_raw, s a power of two per launch (delta_scale_kernel).
+// type SP (split_types.h; wgrad1_kernel).  SP = SplitF16: the chain runs on s * d_raw, s a power of two per launch (delta_amax_kernel).
 // The mixed-precision chain (MODE 1) stays on field_dgrad3_kernel<1>.
 #include <type_traits>
 #include "field_ring.h"
@@ -44,38 +44,25 @@ __device__ inline void apply_mask3r(float (&d)[NV], const f32x16* acc, u32x4 m) 
     }
 }
 
-// max|d_raw| over the launch -> the power-of-two scale of the fp16 split's chain (nerf_common.h, DeltaLayout3::scale).  Blocks
-// reduce their slice and atomicMax the bit pattern (non-negative floats order like unsigned integers: the result does not depend
-// on the order of the atomics); the last block to arrive (ticket) derives s.  Non-finite or zero maxima give s = 1.
-__global__ __launch_bounds__(256) void delta_scale_kernel(const f32x4* __restrict__ d_raw, long n4, unsigned* __restrict__ slot) {
+// max|d_raw| over the launch (its bit pattern: non-negative floats order like unsigned integers, so the atomic maximum does not
+// depend on the order of the atomics) -> DeltaLayout3::scale word 0, zeroed by the launcher; the consumers derive the power-of-two
+// scale from it (nerf_common.h, delta_scale_bits).
+__global__ __launch_bounds__(1024) void delta_amax_kernel(const f32x4* __restrict__ d_raw, long n4, unsigned* __restrict__ slot) {
     float m = 0.0f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (long)gridDim.x * 1024) {
         const f32x4 v = d_raw[i];
         m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);     // (NaN: fmaxf keeps the other operand)
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    __shared__ float wm[4];
-    __shared__ bool last;
+    __shared__ float wm[16];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        atomicMax(slot + 2, __float_as_uint(m));
-        __threadfence();
-        last = atomicAdd(slot + 3, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
-        const unsigned bits = atomicMax(slot + 2, 0u);      // (read through the atomic path)
-        const int e = (int)((bits >> 23) & 0xffu);          // biased exponent of the maximum
-        // s = 2^(TARGET - (e - 127)); e == 0 (zero / subnormal maximum) or e == 255 (inf): no scaling
-        int k = DELTA_SCALE_TARGET_LOG2 - (e - 127);
-        if (e == 0 || e == 255) k = 0;
-        k = max(-100, min(100, k));
-        reinterpret_cast<float*>(slot)[0] = __uint_as_float((unsigned)(127 + k) << 23);
-        reinterpret_cast<float*>(slot)[1] = __uint_as_float((unsigned)(127 - k) << 23);
+    if (threadIdx.x < 16) {
+        m = wm[threadIdx.x];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (threadIdx.x == 0) atomicMax(slot, __float_as_uint(m));
     }
 }
 
@@ -103,7 +90,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     const int lslot = half * 128 + (lane & 31);
     f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);             // (d_rgb3, d_sigma)
     if (SP::F16) {      // the whole chain is linear in d_raw: run it on s * d_raw (s = 2^k, exact), see DeltaLayout3::scale
-        const float sc = a.delta[dl.scale];
+        const float sc = __uint_as_float(delta_scale_bits(reinterpret_cast<const unsigned*>(a.delta + dl.scale)[0], false));
         g = f32x4{g[0] * sc, g[1] * sc, g[2] * sc, g[3] * sc};
     }
     if (valid) {        // tile-major copy of d_raw: the A operand of the rgb_linear / alpha_linear weight gradients
@@ -251,8 +238,8 @@ hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const fl
         unsigned* slot = reinterpret_cast<unsigned*>(delta + delta_layout3((size_t)P).scale);
         hipError_t e = hipMemsetAsync(slot, 0, 16, stream);
         if (e != hipSuccess) return e;
-        const unsigned sb = (unsigned)min((long)512, (P + 255) / 256);
-        hipLaunchKernelGGL(delta_scale_kernel, dim3(sb), dim3(256), 0, stream, reinterpret_cast<const f32x4*>(d_raw), P, slot);
+        const unsigned sb = (unsigned)min((long)128, (P + 4095) / 4096);
+        hipLaunchKernelGGL(delta_amax_kernel, dim3(sb), dim3(1024), 0, stream, reinterpret_cast<const f32x4*>(d_raw), P, slot);
         return launch_dgrad_one<2, SplitF16>(ba, blocks, stream);
     }
     return launch_dgrad_one<2, SplitBF16>(ba, blocks, stream);

@@ -301,9 +301,10 @@ __host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N) {
     a.total = o;
     return a;
 }
-// graw: tiles of 4 = copy of d_raw (rgb3, sigma).  scale: 4 floats {s, 1/s, max|d_raw| bits, 0} -- the fp16 split's delta chain
-// runs on s * d_raw, s an exact power of two chosen per launch (delta_scale_kernel, field_bwd_ring.hip) so that the deltas sit in
-// fp16's range; every stored delta and every partial weight gradient carries the factor s, wgrad_reduce_kernel removes it.
+// graw: tiles of 4 = copy of d_raw (rgb3, sigma).  scale: 4 words, word 0 = the bit pattern of max|d_raw| over the launch
+// (delta_amax_kernel, field_bwd_ring.hip) -- the fp16 split's delta chain runs on s * d_raw, s = delta_scale_of(max) an exact
+// power of two, so that the deltas sit in fp16's range; every stored delta and every partial weight gradient carries the factor
+// s, wgrad_reduce_kernel removes it (both kernels derive s / 1/s from the same word).
 struct DeltaLayout3 { size_t h[D], feat, hv, graw, scale, total; };
 __host__ __device__ inline DeltaLayout3 delta_layout3(size_t P) {
     DeltaLayout3 a{};
@@ -322,5 +323,13 @@ __host__ __device__ inline DeltaLayout3 delta_layout3(size_t P) {
 // grow 2^11-fold along the chain before it does (measured growth on the test scenes: <= 8); hi + lo is exact to 2^-25 absolute,
 // i.e. 2^-29 of the largest upstream gradient.
 constexpr int DELTA_SCALE_TARGET_LOG2 = 4;
+// s = 2^k (inverse = false) or 2^-k (true) for a launch whose max|d_raw| has the bit pattern `amax_bits`; zero, subnormal or
+// non-finite maxima give 1
+__host__ __device__ inline unsigned delta_scale_bits(unsigned amax_bits, bool inverse) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);
+    int k = (e == 0 || e == 255) ? 0 : DELTA_SCALE_TARGET_LOG2 - (e - 127);
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    return (unsigned)(127 + (inverse ? -k : k)) << 23;
+}
 
 }  // namespace nerf

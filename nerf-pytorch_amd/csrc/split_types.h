@@ -10,7 +10,7 @@
 //       SUBNORMAL operands exactly (no flush), v_cvt_pk_f16_f32 rounds to nearest even incl. subnormal results, and
 //       v_fma_mix_f32 forms v - f32(hi) exactly, so hi + lo represents v to max(2^-23 |v|, 2^-25) absolute.  Range: |v| must
 //       stay below 65520 (activations and weights of a NeRF are O(1..100)); an overflow becomes inf -> NaN in `raw`, loudly.
-//       Deltas are scaled by an exact power of two per launch (delta_scale_kernel) because upstream gradients are ~1e-6.
+//       Deltas are scaled by an exact power of two per launch (delta_amax_kernel) because upstream gradients are ~1e-6.
 //       The split itself is 4 VALU operations per value pair (cvt_pk, 2 x fma_mix, cvt_pk) against 6 for bf16.
 #pragma once
 #include "field_device_bf16.h"
