@@ -971,7 +971,26 @@ def main():
             return {"workload": "the 32,768-ray global batch of BASELINE configs[3] on ONE GPU (lego 64+128, training step; rendered in 4 "
                                 "sub-chunks of 8192 rays that all keep their saved activations: ~90 of the 288 GB)",
                     "value": 32768 * 2 / el, "unit": "rays/s", "steps": 2, "ms_per_step": 1e3 * el / 2, "precision_gate": lego_gate}
-        for name, fn in (("fern_train", leg_fern), ("render_only", leg_render), ("batch_32768", leg_big)):
+        def leg_coarse():
+            # BASELINE configs[0] is the reference's CPU-plumbing configuration; its SHAPE on the GPU (no fine network: one pass, one
+            # compositing, no sample_pdf; the golden fixture lego_coarse_only.npz pins the same shape against the reference)
+            n0 = 1024
+            co = Session("lego", args, rank, world, dev, n0, False)
+            try:
+                kw0 = dict(co.kwargs_train, N_importance=0, network_fine=None)
+                opt0 = npa.FlatAdam(list(co.net_c.parameters()), lr=5e-4, betas=(0.9, 0.999))
+
+                def step0(i):
+                    rgb, _, _, _ = npa.render(co.H, co.W, co.K, chunk=args.chunk, rays=co.batches[i % co.pool], verbose=False, retraw=True, **kw0)
+                    opt0.zero_grad()
+                    npa.img2mse(rgb, co.targets[i % co.pool]).backward()
+                    opt0.step()
+                el, _ = measure(args.precision, 20, 5, step0, with_kernels=False)
+            finally:
+                co.close()
+            return {"workload": "the shape of BASELINE configs[0] on the GPU: lego 400x400, N_rand=1024 x 64 samples, no fine network, training step",
+                    "value": n0 * 20 / el, "unit": "rays/s", "steps": 20, "ms_per_step": 1e3 * el / 20}
+        for name, fn in (("fern_train", leg_fern), ("render_only", leg_render), ("batch_32768", leg_big), ("coarse_only_1024", leg_coarse)):
             res = _guarded(errors, "configs." + name, fn)
             if res is not None:
                 legs[name] = res

@@ -238,7 +238,7 @@ hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const fl
         unsigned* slot = reinterpret_cast<unsigned*>(delta + delta_layout3((size_t)P).scale);
         hipError_t e = hipMemsetAsync(slot, 0, 16, stream);
         if (e != hipSuccess) return e;
-        const unsigned sb = (unsigned)min((long)128, (P + 4095) / 4096);
+        const unsigned sb = (unsigned)min((long)1024, (P + 1023) / 1024);      // one 16-byte load per thread: the launch is latency, not bytes
         hipLaunchKernelGGL(delta_amax_kernel, dim3(sb), dim3(1024), 0, stream, reinterpret_cast<const f32x4*>(d_raw), P, slot);
         return launch_dgrad_one<2, SplitF16>(ba, blocks, stream);
     }

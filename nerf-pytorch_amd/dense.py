@@ -187,6 +187,12 @@ class DenseNeRF(nn.Module):
     def query(self, rays, z_vals):
         """raw [N, S, 4 | output_ch] of the sample points o + d z of `rays` [N, 8 | 11]: nerf_build_inputs + the layer stack"""
         n, S = z_vals.shape
+        # without gradients nothing has to outlive a layer: bound the transient activations (D + 2 arrays of P x W floats) by
+        # evaluating ~2^20 points at a time -- what the reference's netchunk does (run_nerf.py:27-34; results do not depend on it)
+        rays_per_slice = max(1, (1 << 20) // max(S, 1))
+        if n > rays_per_slice and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return torch.cat([self.query(rays[i:i + rays_per_slice].contiguous(), z_vals[i:i + rays_per_slice].contiguous())
+                              for i in range(0, n, rays_per_slice)], 0)
         C = self.input_ch + self.input_ch_views
         x = torch.zeros((n * S, C), dtype=torch.float32, device=rays.device)      # (columns the kernel does not write stay defined)
         hb._check(hb.lib().nerf_build_inputs(hb._ptr(rays, "rays"), rays.shape[1], hb._ptr(z_vals, "z_vals"), n, S, self.multires,
