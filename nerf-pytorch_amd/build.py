@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "render_abi.hip", "pack.hip", "ray_ops.hip", "field_fwd.hi
 # test-only library of the superseded split-bf16 kernels (bit-identity references of the ring kernels): build_ref()
 REF_LIB_PATH = os.path.join(PKG_DIR, "libnerf_hip_ref.so")
 REF_SOURCES = [os.path.join("ref", "ref_api.hip"), os.path.join("ref", "field_fwd_bf16.hip"), os.path.join("ref", "field_bwd_bf16.hip")]
-HEADERS = ["nerf_common.h", "field_device.h", "field_device_bf16.h", "split_types.h", "field_ring.h", "field_fwd_ring_body.h", "ray_device.h", "api_util.h", "launchers.h", os.path.join("..", "..", "include", "nerf_hip.h")]
+HEADERS = ["nerf_common.h", "field_device.h", "field_device_bf16.h", "split_types.h", "field_ring.h", "field_ring8.h", "field_fwd_ring_body.h", "ray_device.h", "api_util.h", "launchers.h", os.path.join("..", "..", "include", "nerf_hip.h")]
 # -ffp-contract=off: the per-ray arithmetic is written in the reference's operation
 # order (separate multiply / add) so z_vals, dists and sample points round identically.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]

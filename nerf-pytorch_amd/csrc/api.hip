@@ -310,7 +310,7 @@ int nerf_field_dgrad_split(const float* packed3, const float* act, const float* 
             "packed/act/d_raw/delta must be 16-byte aligned");
     if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
     tag_record(delta, 1, split ? DELTA_TILE32_F16 : DELTA_TILE32_BF16, n_rays, n_samples);
-    return done(__func__, nerf::launch_field_dgrad3r(packed3, act, d_raw, n_rays, n_samples, delta, 1, split, (hipStream_t)stream));
+    return done(__func__, nerf::launch_field_dgrad3r(packed3, act, d_raw, n_rays, n_samples, delta, split, (hipStream_t)stream));
 }
 
 /* ---- three-term split datapaths (bf16 / fp16 parts) */

@@ -161,7 +161,7 @@ struct WgradJob {
     int c_off, ldc, bias_off;       // offsets into the canonical gradient vector; bias_off < 0: none
     int tiles_k, tile_base;         // tiles of this job: [tile_base, tile_base + tiles_n*tiles_k)
     int vecA, vecB;                 // 16-byte aligned full-row loads allowed
-    int b_tile16;                   // bf16x3: B is stored in 16-point tiles with the row16 row order (field_fwd16_kernel<1>)
+    int b_tile16;                   // split datapaths: B is stored in 16-point tiles, row16h row order (the forward's saved rows)
     int b_ray_tiles;                // wgrad1_kernel: > 0 = B is constant along a ray (the direction encoding) and stored ONCE per
                                     // ray as [ray][feature][8 copies] bf16 (512 B per ray); value = 32-point tiles per ray
 };
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     const int sld = sop == 0 ? jb.lda : jb.ldb;
     const unsigned tile_bytes = 64u * (unsigned)sld;
     const char* cbase = reinterpret_cast<const char*>(sop == 0 ? jb.A : jb.B) + (size_t)(p_begin >> 5) * tile_bytes;
-    // B operands saved by field_fwd16_kernel<2>: the stage's 32 points are two consecutive 16-point tiles of sld rows x
+    // B operands saved by the 16-point forward: the stage's 32 points are two consecutive 16-point tiles of sld rows x
     // 32 B (row16h order, nerf_common.h); 8-point group g of feature f sits at tile (g >> 1), row16h(f), bytes 16 * (g & 1)
     const bool t16 = sop == 1 && jb.b_tile16 != 0;
     // B constant along a ray: every 8-point group of feature f of a tile is the ray's 16-byte record of f (8 copies of the
@@ -731,21 +731,19 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     // deltas in 32-point tiles; 5 = the same with fp16 elements (deltas scaled by the launch's power of two, removed in the reduction)
     if (datapath != 0 && datapath != 4 && datapath != 5) return hipErrorInvalidValue;
     const bool f16 = datapath == 5;
-    const bool mixed = datapath != 0;        // 16-bit operands streamed by wgrad1_kernel
-    const bool x_tile16 = mixed;
-    const int bf16x3 = mixed ? 2 : 0;
-    const bool fold = mixed;                 // split datapaths: feature layer folded into the view branch (nerf_common.h)
+    const bool split16 = datapath != 0;      // split datapaths: 16-bit operands streamed by wgrad1_kernel,
+    const bool fold = split16;               //   feature layer folded into the view branch (nerf_common.h)
     if (fold && !params) return hipErrorInvalidValue;
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     hipError_t e;
     constexpr Canon cn = canon();
-    // operand bases.  fp32 datapath: point-major rows (lda = row pitch); bf16x3: 32-point feature-major tiles
+    // operand bases.  fp32 datapath: point-major rows (lda = row pitch); split datapaths: 32-point feature-major tiles
     // (lda = features per tile, a feature offset f0 is folded into the base as f0 * 32)
     const float *d_h[D], *d_feat, *d_hv, *d_rgb, *d_sigma, *x_h[D], *x_feat, *x_hv, *x_enc, *x_dir;
     const unsigned* amax = nullptr;
     int ld_graw;
-    if (bf16x3) {
+    if (split16) {
         const ActLayout3 al = act_layout3((size_t)P, (size_t)n_rays);
         const DeltaLayout3 dl = delta_layout3((size_t)P);
         if (f16) amax = reinterpret_cast<const unsigned*>(delta + dl.scale);
@@ -792,7 +790,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         WgradJob& j = wa.job[nj++];
         j.A = A; j.B = B; j.lda = lda; j.nA = nA; j.ldb = ldb; j.nB = nB; j.b_rowdiv = rowdiv;
         // rows saved by the 16-point forward (256- / 128-wide regions) are in 16-point tiles; encodings are not
-        j.b_tile16 = (x_tile16 && (ldb == W || ldb == WV)) ? 1 : 0;
+        j.b_tile16 = (split16 && (ldb == W || ldb == WV)) ? 1 : 0;
         j.b_ray_tiles = 0;
         j.c_off = c_off; j.ldc = ldc; j.bias_off = bias_off;
         const int tn = (nA + WG_TILE - 1) / WG_TILE;
@@ -818,7 +816,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         add(d_hv, WV, WV, x_h[D - 1], W, W, 1, cn.wv, W + IN_DIR, cn.bv);
     } else add(d_hv, WV, WV, x_feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
     add(d_hv, WV, WV, x_dir, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
-    if (mixed && S % 32 == 0 && nj <= WG_MAX_JOBS) wa.job[nj - 1].b_ray_tiles = S / 32;       // direction encoding: one record per ray
+    if (split16 && S % 32 == 0 && nj <= WG_MAX_JOBS) wa.job[nj - 1].b_ray_tiles = S / 32;       // direction encoding: one record per ray
     add(d_rgb, ld_graw, 3, x_hv, WV, WV, 1, cn.wr, WV, cn.br);
     if (nj != WG_MAX_JOBS - (fold ? 1 : 0)) return hipErrorInvalidValue;
     // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
@@ -826,7 +824,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     int small_tiles = 0;
     for (int j = 0; j < nj; ++j) {
         const WgradJob& src = wa.job[j];
-        if (bf16x3 || (src.nA == 256 && src.nB == 256 && src.vecA && src.vecB && src.b_rowdiv == 1)) {
+        if (split16 || (src.nA == 256 && src.nB == 256 && src.vecA && src.vecB && src.b_rowdiv == 1)) {
             big.job[big.n_jobs++] = src;
         } else {
             WgradJob& dst = small.job[small.n_jobs++];
@@ -849,14 +847,14 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         attr_set = true;
     }
     static bool attr1_set = false;
-    if (mixed && !attr1_set) {
+    if (split16 && !attr1_set) {
         e = hipFuncSetAttribute((const void*)wgrad1_kernel<SplitBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, WG1_LDS_BYTES);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)wgrad1_kernel<SplitF16>, hipFuncAttributeMaxDynamicSharedMemorySize, WG1_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr1_set = true;
     }
-    if (big.n_jobs > 0 && mixed && (phases & 1)) {
+    if (big.n_jobs > 0 && split16 && (phases & 1)) {
         if (f16) hipLaunchKernelGGL(wgrad1_kernel<SplitF16>, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
         else hipLaunchKernelGGL(wgrad1_kernel<SplitBF16>, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
         e = hipGetLastError();

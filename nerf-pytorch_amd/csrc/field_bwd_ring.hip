@@ -1,16 +1,14 @@
-// field_dgrad3r_kernel: the split-bf16 delta chain (field_dgrad3_kernel of field_bwd_bf16.hip: d_raw -> dL/d(pre-activation)
-// of every layer; the autograd of run_nerf_helpers.py:96-119) on the weight RING of field_ring.h.  32 points per wave on
-// v_mfma_f32_32x32x16_bf16, 4 waves, one per SIMD -- the shape of the double-buffered kernel -- but a wave alone on its
-// SIMD has nobody to cover what it does between MFMAs, and the double-buffered kernel spends that time after every
-// 64 KiB chunk: barrier, 16 DMA pieces per wave issued back to back, LDS latency of the first fragments, 32 row stores in
-// a burst (MFMA-busy 0.53 in the round-2 profile).  Here every MFMA (32 cycles of pipe) carries its own share of that work
-// in its shadow: one fragment request 8 MFMAs ahead of its use, a piece of the next k-step's operand split, one row
+// field_dgrad3r_kernel: the delta chain of the split datapaths (d_raw -> dL/d(pre-activation) of every layer; the autograd of
+// run_nerf_helpers.py:96-119) on the weight RING of field_ring.h.  32 points per wave on v_mfma_f32_32x32x16_{bf16,f16}, 4 waves,
+// one per SIMD.  A wave alone on its SIMD has nobody to cover what it does between MFMAs (the double-buffered kernel of round 2,
+// csrc/ref/field_bwd_bf16.hip, spends that time after every 64 KiB chunk: barrier, 16 DMA pieces per wave back to back, LDS latency
+// of the first fragments, 32 row stores in a burst: MFMA-busy 0.53).  Here every MFMA (32 cycles of pipe) carries its own share of
+// that work in its shadow: one fragment request 8 MFMAs ahead of its use, a piece of the next k-step's operand split, one row
 // store, and behind each of four units per chunk a 4 KiB DMA part (field_ring.h: unit_pipelined, WeightRingT<4>).
-// Same transposed fragment stream (P3B), same MFMA order per accumulator, same masks: every delta written is
-// BIT-IDENTICAL to field_dgrad3_kernel<MODE> (tests/test_gpu_round3.py::test_ring_dgrad_bit_identical).
-// MODE 0: fp32 deltas (operands of wgrad3_256_kernel); MODE 2: the same chain, deltas written as 16-bit elements of the split's
-// type SP (split_types.h; wgrad1_kernel).  SP = SplitF16: the chain runs on s * d_raw, s a power of two per launch (delta_amax_kernel).
-// The mixed-precision chain (MODE 1) stays on field_dgrad3_kernel<1>.
+// Same transposed fragment stream (P3B), same MFMA order per accumulator, same masks as that kernel: with SP = SplitBF16 every
+// delta written is BIT-IDENTICAL to it (tests/test_gpu_round3.py::test_ring_dgrad_bit_identical).  Deltas leave as 16-bit elements
+// of the split's type SP (split_types.h; operands of wgrad1_kernel).  SP = SplitF16: the chain runs on s * d_raw, s a power of
+// two per launch (delta_amax_kernel).
 #include <type_traits>
 #include "field_ring.h"
 #include "launchers.h"
@@ -66,11 +64,8 @@ __global__ __launch_bounds__(1024) void delta_amax_kernel(const f32x4* __restric
     }
 }
 
-template <int MODE, typename SP>
+template <typename SP>
 __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldBwdRingArgs a) {
-    static_assert(MODE == 0 || MODE == 2, "3-term chain; fp32 or 16-bit deltas");
-    static_assert(!SP::F16 || MODE == 2, "the fp16 split stores fp16 deltas");
-    constexpr bool OUT16 = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -87,7 +82,6 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     const ActLayout3 al = act_layout3(P, (size_t)a.n_rays);
     const DeltaLayout3 dl = delta_layout3(P);
     const size_t tile = (size_t)blockIdx.x * FIELD3_WAVES + wave;          // this wave's tile of every delta region
-    const int lslot = half * 128 + (lane & 31);
     f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);             // (d_rgb3, d_sigma)
     if (SP::F16) {      // the whole chain is linear in d_raw: run it on s * d_raw (s = 2^k, exact), see DeltaLayout3::scale
         const float sc = __uint_as_float(delta_scale_bits(reinterpret_cast<const unsigned*>(a.delta + dl.scale)[0], false));
@@ -95,15 +89,9 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     }
     if (valid) {        // tile-major copy of d_raw: the A operand of the rgb_linear / alpha_linear weight gradients
         const size_t goff = tile * (4 * 32) + half * 64 + (lane & 31);
-        if (OUT16) {
-            unsigned short* gt = reinterpret_cast<unsigned short*>(a.delta + dl.graw) + goff;
-            nt_store(gt, SP::cvt1(half ? g[2] : g[0]));
-            nt_store(gt + 32, SP::cvt1(half ? g[3] : g[1]));
-        } else {
-            float* gt = a.delta + dl.graw + goff;
-            nt_store(gt, half ? g[2] : g[0]);
-            nt_store(gt + 32, half ? g[3] : g[1]);
-        }
+        unsigned short* gt = reinterpret_cast<unsigned short*>(a.delta + dl.graw) + goff;
+        nt_store(gt, SP::cvt1(half ? g[2] : g[0]));
+        nt_store(gt + 32, SP::cvt1(half ? g[3] : g[1]));
     }
     u32x4 msk[D + 1];
     {
@@ -136,27 +124,24 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
 
     f32x16 acc[8];
     float d[128];
-    // bf16 deltas: unconditional paired stores (field_device_bf16.h, store_tile3h_pair).  A wave whose tile lies beyond the
+    // 16-bit deltas: unconditional paired stores.  A wave whose tile lies beyond the
     // padded point range (last workgroup only) writes to a dump tile: the unused `feat` region.
     const bool tile_ok = __builtin_amdgcn_readfirstlane((int)(tile * 32 < pad32(P))) != 0;
     const unsigned odd = (unsigned)lane & 1u;
     const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;
     const int pair_off = ((lane >> 5) * 4 + (int)odd) * 16 + ((lane & 31) >> 1);      // dwords inside the tile
-    // one paired bf16 store: rows (r, r + 1) of 32-feature block ob of a F-wide region (the element order of
-    // store_tile3h_pair), values v0 / v1 of this lane's point
+    // one paired 16-bit store: rows (r, r + 1) of 32-feature block ob of a F-wide region (32-point feature-major tiles,
+    // nerf_common.h), `own` = the two values of this lane's point
     auto store_pair16 = [&](size_t region_off, int F, int ob, int r, unsigned own) __attribute__((always_inline)) {
         const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
         unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.delta + (tile_ok ? region_off : dl.feat))
                                                      + (tile_ok ? tile * (size_t)(F * 32) : (size_t)0)) + pair_off;
         nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, __builtin_amdgcn_perm(nbr, own, pair_sel));
     };
-    auto store_f32 = [&](size_t region_off, int F, int ob, int r, float v) __attribute__((always_inline)) {
-        if (valid) nt_store(a.delta + region_off + tile * (size_t)(F * 32) + lslot + (32 * ob + (r & 3) + 8 * (r >> 2)) * 32, v);
-    };
     // the deltas in `v` (value 16 ob + r) leave while the next contraction consumes them: unit i of NU writes its share
-    // (NV / NU values: bf16 pairs or single fp32 rows)
+    // (NV / NU values as 16-bit pairs)
     size_t store_region = 0;
-    constexpr int NP = OUT16 ? 8 : 0;       // row stores guaranteed behind the last fetch part (two per unit, positions 3..6)
+    constexpr int NP = 8;       // row stores guaranteed behind the last fetch part (two per unit, positions 3..6)
 
     // ---- view branch folded with feature_linear (nerf_common.h): delta of the trunk output =
     //      (alpha_linear^T d_sigma + W'^T d_hv) * relu'(h7); the feature_linear^T units of the stream are skipped
@@ -179,10 +164,9 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     ring_units<SP, 16, 2, 0, true, 0>(ring, fa, fb, fl, acc, dhv, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
         constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;            // unit 0..15: 64 values -> 4 per unit
 #pragma unroll
-        for (int t = 0; t < (OUT16 ? 2 : 4); ++t) {
-            const int q = (OUT16 ? 2 : 4) * i + t;
-            if (OUT16) store_pair16(store_region, WV, q / 8, 2 * (q % 8), bhi[2 * decltype(gg)::value + t]);
-            else store_f32(store_region, WV, q / 16, q % 16, dhv[q]);
+        for (int t = 0; t < 2; ++t) {
+            const int q = 2 * i + t;
+            store_pair16(store_region, WV, q / 8, 2 * (q % 8), bhi[2 * decltype(gg)::value + t]);
         }
     });
     apply_mask3r<128>(d, acc, msk[D - 1]);
@@ -198,10 +182,9 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
         ring_units<SP, 32, 2, 0, false, NP>(ring, fa, fb, fl, acc, d, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
             constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;        // unit 0..31: 128 values -> 4 per unit
 #pragma unroll
-            for (int t = 0; t < (OUT16 ? 2 : 4); ++t) {
-                const int q = (OUT16 ? 2 : 4) * i + t;
-                if (OUT16) store_pair16(store_region, W, q / 8, 2 * (q % 8), bhi[2 * decltype(gg)::value + t]);
-                else store_f32(store_region, W, q / 16, q % 16, d[q]);
+            for (int t = 0; t < 2; ++t) {
+                const int q = 2 * i + t;
+                store_pair16(store_region, W, q / 8, 2 * (q % 8), bhi[2 * decltype(gg)::value + t]);
             }
         });
         u32x4 m = msk[0];                   // ReLU bitmask of h_{l-1} (static indices only: msk stays in registers)
@@ -210,28 +193,26 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
         apply_mask3r<128>(d, acc, m);
     }
     // dl.h[0]
-    if (OUT16) store_tile16_pair<SP, 0, 8>(reinterpret_cast<unsigned short*>(a.delta + (tile_ok ? (size_t)0 : dl.feat)) + (tile_ok ? tile * (size_t)(W * 32) : (size_t)0), lane, d);
-    else if (valid) store_tile3<0, 8>(a.delta + tile * (W * 32) + lslot, d);
+    store_tile16_pair<SP, 0, 8>(reinterpret_cast<unsigned short*>(a.delta + (tile_ok ? (size_t)0 : dl.feat)) + (tile_ok ? tile * (size_t)(W * 32) : (size_t)0), lane, d);
 }
 
-template <int MODE, typename SP>
+template <typename SP>
 static hipError_t launch_dgrad_one(const FieldBwdRingArgs& ba, unsigned blocks, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3r_kernel<MODE, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3r_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((field_dgrad3r_kernel<MODE, SP>), dim3(blocks), dim3(FIELD3_WAVES * 64), RING_LDS_FLOATS * 4, stream, ba);
+    hipLaunchKernelGGL((field_dgrad3r_kernel<SP>), dim3(blocks), dim3(FIELD3_WAVES * 64), RING_LDS_FLOATS * 4, stream, ba);
     return hipGetLastError();
 }
 
-// out16: deltas stored as 16-bit elements of the split's type (operands of wgrad1_kernel); split: 0 bf16, 1 fp16 (out16 only)
+// split: 0 bf16, 1 fp16 parts (of the products and of the stored deltas)
 hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
-                                float* delta, int out16, int split, hipStream_t stream) {
+                                float* delta, int split, hipStream_t stream) {
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
-    if (!out16) return hipErrorInvalidValue;        // (fp32 deltas were the operand storage of round 3's fp32-operand GEMM: removed)
     FieldBwdRingArgs ba{packed3, act, d_raw, delta, n_rays, S};
     const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
     if (split) {
@@ -240,9 +221,9 @@ hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const fl
         if (e != hipSuccess) return e;
         const unsigned sb = (unsigned)min((long)1024, (P + 1023) / 1024);      // one 16-byte load per thread: the launch is latency, not bytes
         hipLaunchKernelGGL(delta_amax_kernel, dim3(sb), dim3(1024), 0, stream, reinterpret_cast<const f32x4*>(d_raw), P, slot);
-        return launch_dgrad_one<2, SplitF16>(ba, blocks, stream);
+        return launch_dgrad_one<SplitF16>(ba, blocks, stream);
     }
-    return launch_dgrad_one<2, SplitBF16>(ba, blocks, stream);
+    return launch_dgrad_one<SplitBF16>(ba, blocks, stream);
 }
 
 }  // namespace nerf

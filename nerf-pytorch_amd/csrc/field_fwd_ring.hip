@@ -1,11 +1,11 @@
-// field_fwd16r_kernel: the 16-point-per-wave three-term-split forward (field_fwd16_kernel of field_fwd_bf16.hip: encode + 8x256
-// trunk + density head + folded view branch -> raw[P,4]; run_nerf.py:37-51, run_nerf_helpers.py:15-45, :96-119) on the
-// weight RING of field_ring.h instead of the double-buffered weight stream.  Same fragment stream (P16F), same MFMA order
-// per accumulator, same encodings and heads: `raw`, the saved rows, encodings and ReLU bitmasks are BIT-IDENTICAL to
-// field_fwd16_kernel<SAVE> (tests/test_gpu_parity.py::test_ring_forward_bit_identical); what changes is when the weights
-// arrive and when the fragments are requested.  SAVE: 0 = inference, 2 = 16-bit rows (the default operand storage of the
-// weight-gradient GEMM); fp32 rows (SAVE 1) stay on field_fwd16_kernel<1>.  SP (split_types.h): bf16 split (bit-identical to
-// field_fwd16_kernel) or fp16 split (fp32-class products, 11-bit saved rows).
+// field_fwd16r_kernel: the 16-point-per-wave three-term-split forward (encode + 8x256 trunk + density head + folded view
+// branch -> raw[P,4]; run_nerf.py:37-51, run_nerf_helpers.py:15-45, :96-119) on the weight RING of field_ring.h.  Same fragment
+// stream (P16F), same MFMA order per accumulator, same encodings and heads as round 2's double-buffered kernel
+// (csrc/ref/field_fwd_bf16.hip, test-only library): with SP = SplitBF16 `raw`, the saved rows, encodings and ReLU bitmasks are
+// BIT-IDENTICAL to it (tests/test_gpu_parity.py::test_ring_forward_bit_identical); what changed is when the weights arrive and
+// when the fragments are requested.  SAVE: 0 = inference, 2 = 16-bit rows of the split's type (operands of the weight-gradient
+// GEMM).  SP (split_types.h): bf16 split or fp16 split (fp32-class products, 11-bit saved rows); RED: the reduced inference class
+// (field_ring8.h).
 #include "field_fwd_ring_body.h"
 
 namespace nerf {

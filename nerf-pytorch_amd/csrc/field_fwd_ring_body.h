@@ -62,7 +62,7 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     float e[16];
     encode_xyz(e, x0, x1, x2, q);
 
-    // ---- saving (layouts: nerf_common.h; identical to field_fwd16_kernel<2>)
+    // ---- saving (layouts: nerf_common.h)
     ActLayout3 al{};
     const size_t tile = (size_t)(p_raw >> 5);
     const int pp = (int)(p_raw & 31);
@@ -108,7 +108,7 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     };
     auto no_store = [](auto, auto, const u32x4&) __attribute__((always_inline)) {};
     // rows of the layer in h[] leave while the next contraction consumes them: unit (k-step kk, group gg) covers
-    // block 2 kk + (gg >> 1), rows 2 (gg & 1), 2 (gg & 1) + 1 (the store pattern of field_fwd16_kernel<2>)
+    // block 2 kk + (gg >> 1), rows 2 (gg & 1), 2 (gg & 1) + 1 (row16h order)
     size_t row_region = 0;
     // (the bf16 values of rows (r0, r0 + 1) of block nb ARE word g of the B operand's hi fragment of k-step kk)
     // ... and so do the bits of their ReLU mask: two compares per unit in the shadow of its MFMAs instead of 64 at the layer's

@@ -91,6 +91,6 @@ hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_
 hipError_t launch_field_fwd16r_last(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                                     int n_rays, int S, float* raw, hipStream_t stream);
 hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
-                                float* delta, int out16, int split, hipStream_t stream);
+                                float* delta, int split, hipStream_t stream);
 
 }  // namespace nerf

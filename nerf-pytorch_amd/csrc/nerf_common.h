@@ -197,8 +197,8 @@ constexpr int P3B_FEAT = P3B_VIEWS + KS3_HV * KSTEP3_W8;
 constexpr int P3B_L7 = P3B_FEAT + KS3_H * KSTEP3_W8;                    // then L6 .. L1
 constexpr int P3B_END = P3B_L7 + 7 * KS3_H * KSTEP3_W8;
 constexpr int P3_SMALL = P3B_END;                                       // fp32 small parameters, same order as SM_*
-// hi-only copy of the transposed streams (mixed-precision dgrad: W_hi^T * delta_hi needs no lo fragments, and half
-// the L2 -> LDS weight traffic is what that kernel is bound by): k-step = 8 blocks x 64 lanes x 16 B
+// hi-only copy of the transposed streams (round 3's mixed-precision delta chain, removed; the region keeps its place so that the
+// packed layout stays the one the test-reference kernels of csrc/ref read): k-step = 8 blocks x 64 lanes x 16 B
 constexpr int KSTEP1_W8 = 8 * 64 * 4;                                   // 2048 words = 8 KiB
 constexpr int P1B_KSTEPS = KS3_HV + KS3_H + 7 * KS3_H;                  // views^T 8 | feat^T 16 | L7^T..L1^T 7 x 16 = 136
 constexpr int P1B = P3_SMALL + (PACKED_FLOATS - SM_BIAS);
@@ -217,11 +217,11 @@ constexpr int P16F_FEAT = P16F_L6 + 2 * KS16_H * KSTEP16_W16;
 constexpr int P16F_VIEWS = P16F_FEAT + KS16_H * KSTEP16_W16;
 constexpr int P16F_WORDS = P16F_VIEWS + (KS16_H + KS16_DIR) * KSTEP16_W8;
 static_assert(P16F_WORDS == P3F_END && P16F % 4 == 0, "the 16-point forward stream has the 32-point stream's size");
-// ---- FOLDED FEATURE LAYER (split-bf16 and mixed datapaths).  feature_linear has no activation and feeds only
+// ---- FOLDED FEATURE LAYER (split datapaths).  feature_linear has no activation and feeds only
 // views_linears.0 (run_nerf_helpers.py:111-115), so the two consecutive linear maps compose:
 //     views_pre = Wv[:, :256] (Wf h7 + bf) + Wv[:, 256:] enc(dir) + bv = W' h7 + Wv[:, 256:] enc(dir) + b'
 //     W' = Wv[:, :256] Wf  [128][256],   b' = Wv[:, :256] bf + bv  [128]
-// The bf16x3 / mixed kernels evaluate the view branch directly on the trunk output with W' (one 256x256 layer less in
+// The split kernels evaluate the view branch directly on the trunk output with W' (one 256x256 layer less in
 // the forward, in dgrad and in the weight-gradient GEMM: -11 % MFMA work, and `feature` / its delta are neither saved
 // nor re-read: -4 KB of the 43 KB of HBM traffic per point and step).  The parameters stay Wf, bf, Wv, bv; their
 // gradients follow from ONE contraction G = delta_hv^T h7 [128][256] and dbv = sum delta_hv:
@@ -246,9 +246,9 @@ constexpr int PTS_PER_WAVE3 = 32;
 constexpr int FIELD3_WAVES = 4;                                         // 256-thread workgroups, 1 wave / SIMD
 constexpr int PTS_PER_WG3 = PTS_PER_WAVE3 * FIELD3_WAVES;
 
-// ---- saved activations / deltas of the bf16x3 datapath: 32-POINT TILES, FEATURE-MAJOR INSIDE A TILE.
+// ---- saved deltas and encodings of the split datapaths: 32-POINT TILES, FEATURE-MAJOR INSIDE A TILE (16-bit elements).
 // Element (point p, feature f) of an F-feature region lives at  (p >> 5) * F * 32 + f * 32 + (p & 31):
-//   * a wave of field_fwd3 / field_dgrad3 owns exactly one tile, and one store instruction writes one feature of its
+//   * a wave of the 32-point delta chain owns exactly one tile, and one store instruction writes one feature of its
 //     32 points per lane half = two full 128-byte lines (the point-major rows of the fp32 datapath would scatter
 //     64 x 16 B per instruction);
 //   * the weight-gradient GEMM contracts over points: a tile is its k-extent of 32, read as one contiguous block
@@ -256,25 +256,17 @@ constexpr int PTS_PER_WG3 = PTS_PER_WAVE3 * FIELD3_WAVES;
 // Regions are sized for P rounded up to a tile; the pad points of the last tile are never written and never used.
 __host__ __device__ constexpr size_t pad32(size_t P) { return (P + 31) & ~(size_t)31; }
 __host__ __device__ inline size_t tile_index(size_t p, int F, int f) { return (p >> 5) * (size_t)(F * 32) + (size_t)f * 32 + (p & 31); }
-// ---- 16-POINT TILES of the rows saved by the 16-point forward (field_fwd16_kernel<1>; regions h[0..7], feat, hv).
-// A wave of that kernel owns 16 points; lane (pt, q) holds features 16*nb + 4*q + j, so one store instruction (j fixed)
-// carries features {j, 4+j, 8+j, 12+j} of its 16 points = four runs of 64 B.  Non-temporal stores of HALF lines reach
-// only 3.2-3.6 TB/s on MI355X against 5.6-6.0 TB/s for full lines (tools/probe/wr_probe.hip: the 32-point tile layout,
-// where the other half of every line belongs to the partner wave, capped the saving forward at 2.9 TB/s), so the rows
-// are laid out so that each instruction's runs pair up into full 128-byte lines: inside a 16-feature block the feature
-// 4*q + j sits at row 8*(q>>1) + 2*j + (q&1), i.e. element (p, f) of an F-wide region lives at
-//     (p >> 4) * F * 16 + row16(f) * 16 + (p & 15).
-// Two consecutive 16-point tiles cover the same 32 points (and the same bytes) as one 32-point tile, so the
-// weight-gradient GEMM stages them as one contiguous block; it contracts over points and only has to know which
-// feature a staged row is (row16_feature).
-__host__ __device__ constexpr int row16(int f) { return (f & ~15) + 8 * ((f >> 3) & 1) + 2 * (f & 3) + ((f >> 2) & 1); }
-__host__ __device__ constexpr int row16_feature(int r) { return (r & ~15) + 8 * ((r >> 3) & 1) + 4 * (r & 1) + ((r >> 1) & 3); }
-// bf16 rows saved by field_fwd16_kernel<2> (operands of the bf16 weight-gradient GEMM): 16-point tiles of 2-byte
+// ---- 16-POINT TILES of the rows saved by the 16-point forward (regions h[0..7], hv).
+// A wave of that kernel owns 16 points; lane (pt, q) holds features 16*nb + 4*q + j.  Non-temporal stores of HALF lines reach
+// only 3.2-3.6 TB/s on MI355X against 5.6-6.0 TB/s for full lines (tools/probe/wr_probe.hip), so the rows are laid out so that
+// each store instruction's runs pair up into full 128-byte lines.  Two consecutive 16-point tiles cover the same 32 points (and
+// the same bytes) as one 32-point tile, so the weight-gradient GEMM stages them as one contiguous block; it contracts over points
+// and only has to know which feature a staged row is.
+// 16-bit rows (operands of the streaming weight-gradient GEMM): 16-point tiles of 2-byte
 // elements, 32 bytes per row; lane pairs store (row 4q + r, row 4q + r + 1) x 2 points per dword for r in {0, 2}, so the
 // feature 4*q + r sits at row 8*(r>>1) + 2*q + (r&1): the eight rows one instruction writes are contiguous (256 B).
 //     element (p, f): 2-byte index (p >> 4) * F * 16 + row16h(f) * 16 + (p & 15)
 __host__ __device__ constexpr int row16h(int f) { return (f & ~15) + 8 * ((f >> 1) & 1) + 2 * ((f >> 2) & 3) + (f & 1); }
-__host__ __device__ inline size_t tile16_index(size_t p, int F, int f) { return (p >> 4) * (size_t)(F * 16) + (size_t)row16(f) * 16 + (p & 15); }
 
 struct ActLayout3 {
     size_t h[D], feat;  // tiles of 256 features
@@ -282,7 +274,7 @@ struct ActLayout3 {
     size_t enc;         // tiles of 64 (canonical column order, feature 63 unused)
     size_t dir;         // [N][32] per ray, row-major (written by the forward)
     size_t dir_pt;      // tiles of 32: the same per point, expanded right before the weight-gradient GEMM
-    size_t mask;        // [9][P][2] x 128 ReLU sign bits in the lane order of field_fwd3 (9th = view branch)
+    size_t mask;        // [9][P][2] x 128 ReLU sign bits in the lane order of the split kernels (9th = view branch)
     size_t total;
 };
 __host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N) {

@@ -85,12 +85,12 @@ hipError_t field_backward(const NerfRenderCfg* c, const float* packed, const flo
     if (c->precision == 0) return nerf::launch_field_bwd(packed, act, d_raw, n, S, delta, partial, grad, accumulate, st);
     hipError_t e;
     if (c->precision == 3) {
-        e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, 1, 1, st);
+        e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, 1, st);
         if (e != hipSuccess) return e;
         tag_record(delta, 1, DELTA_TILE32_F16, n, S);
         return nerf::launch_field_wgrad(act, delta, d_raw, n, S, partial, grad, accumulate, 5, 7, st, params);
     }
-    e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, 1, 0, st);
+    e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, 0, st);
     if (e != hipSuccess) return e;
     tag_record(delta, 1, DELTA_TILE32_BF16, n, S);
     return nerf::launch_field_wgrad(act, delta, d_raw, n, S, partial, grad, accumulate, 4, 7, st, params);
