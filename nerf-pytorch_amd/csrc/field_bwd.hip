@@ -604,42 +604,37 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chu
 
 // Gradients of the two layers the split datapaths evaluate as one (nerf_common.h, folded feature layer), from
 // G = delta_hv^T h7 [128][256] and dbv [128]:   dWv[:, :256] = G Wf^T + dbv bf^T,  dWf = Wv[:, :256]^T G,
-// dbf = Wv[:, :256]^T dbv.   Plain fp32 FMA loops (K = 256 / 128): 16.8 MFLOP.  Eight lanes share one output (contraction index
-// part, part + 8, ...; shuffle reduction in a fixed order: deterministic): an eighth of the dependent loads per thread, and the
-// row of Wf that the first form walks is read by adjacent lanes (one thread per output: 14 us per launch, this form: ~5).
-constexpr int FOLD_OUTPUTS = WV * W + W * W + W;
+// dbf = Wv[:, :256]^T dbv.   Plain fp32 FMA loops (K = 256 / 128): 16.8 MFLOP, one thread per output
+// (eight lanes per output with a shuffle reduction, as derive_folded_kernel does, measured slower: 17.7 vs 14.2 us per launch).
 __global__ void wgrad_fold_kernel(const float* __restrict__ params, const float* __restrict__ scratch, float* __restrict__ grad,
                                   int accumulate) {
     constexpr Canon cn = canon();
     const float* G = scratch;
     const float* dbv = scratch + WV * W;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int part = tid & 7;
-    const int idx = min(tid >> 3, FOLD_OUTPUTS - 1);      // (every lane takes part in the shuffles)
-    float acc = 0.0f;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    float v;
     int dst;
     if (idx < WV * W) {                                 // dWv[k][i], i < 256
         const int k = idx / W, i = idx % W;
         const float* wf = params + cn.wf + i * W;
-#pragma unroll 8
-        for (int j = part; j < W; j += 8) acc = fmaf(G[k * W + j], wf[j], acc);
-        if (part == 0) acc = fmaf(dbv[k], params[cn.bf + i], acc);
+        float acc = 0.0f;
+        for (int j = 0; j < W; ++j) acc = fmaf(G[k * W + j], wf[j], acc);
+        v = fmaf(dbv[k], params[cn.bf + i], acc);
         dst = cn.wv + k * (W + IN_DIR) + i;
     } else if (idx < WV * W + W * W) {                  // dWf[i][j]
         const int t = idx - WV * W, i = t / W, j = t % W;
-#pragma unroll 8
-        for (int k = part; k < WV; k += 8) acc = fmaf(params[cn.wv + k * (W + IN_DIR) + i], G[k * W + j], acc);
+        float acc = 0.0f;
+        for (int k = 0; k < WV; ++k) acc = fmaf(params[cn.wv + k * (W + IN_DIR) + i], G[k * W + j], acc);
+        v = acc;
         dst = cn.wf + t;
-    } else {                                            // dbf[i]
+    } else if (idx < WV * W + W * W + W) {              // dbf[i]
         const int i = idx - WV * W - W * W;
-#pragma unroll 8
-        for (int k = part; k < WV; k += 8) acc = fmaf(params[cn.wv + k * (W + IN_DIR) + i], dbv[k], acc);
+        float acc = 0.0f;
+        for (int k = 0; k < WV; ++k) acc = fmaf(params[cn.wv + k * (W + IN_DIR) + i], dbv[k], acc);
+        v = acc;
         dst = cn.bf + i;
-    }
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    acc += __shfl_xor(acc, 4);
-    if (part == 0 && (tid >> 3) < FOLD_OUTPUTS) grad[dst] = accumulate ? grad[dst] + acc : acc;
+    } else return;
+    grad[dst] = accumulate ? grad[dst] + v : v;
 }
 
 // ------------------------------------------------------------------ host side
@@ -874,7 +869,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, stream,
                            (const float*)partial, n_chunks, grad, accumulate, fold ? 1 : 0, scratch, amax);
         if (fold)
-            hipLaunchKernelGGL(wgrad_fold_kernel, dim3((8 * FOLD_OUTPUTS + 255) / 256), dim3(256), 0, stream,
+            hipLaunchKernelGGL(wgrad_fold_kernel, dim3((WV * W + W * W + W + 255) / 256), dim3(256), 0, stream,
                                params, (const float*)scratch, grad, accumulate);
     }
     return hipGetLastError();

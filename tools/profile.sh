@@ -26,6 +26,19 @@ for f in glob.glob(f"{out}/stats/**/*kernel_stats.csv", recursive=True):
     keep = [rows[0]] + [r for r in rows[1:] if "nerf::" in r][:24]
     open(f"{out}/kernel_stats.csv", "w").write("\n".join(keep) + "\n")
     print("\n".join(keep[:12]))
+# per launch size: the coarse (262,144 points) and the fine (786,432 points) launch of a kernel are different rows
+by = collections.defaultdict(list)
+for f in glob.glob(f"{out}/stats/**/*kernel_trace.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "nerf::" in row["Kernel_Name"]:
+            k = (row["Kernel_Name"].replace("void ", "").split("(")[0], int(row["Grid_Size_X"]) // max(1, int(row["Workgroup_Size_X"])),
+                 row["Workgroup_Size_X"], row["VGPR_Count"], row["Accum_VGPR_Count"], row["LDS_Block_Size"])
+            by[k].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+with open(f"{out}/kernel_by_launch.csv", "w") as fo:
+    fo.write(f"# rocprofv3 --kernel-trace -- {cmd.replace(os.getcwd() + '/', '')}: every nerf:: kernel by launch size (workgroups)\n")
+    fo.write("kernel,workgroups,workgroup_size,vgprs,agprs,lds_bytes,dispatches,mean_ns,min_ns,max_ns\n")
+    for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        fo.write(",".join(str(x) for x in k) + f",{len(v)},{sum(v) / len(v):.0f},{min(v)},{max(v)}\n")
 agg = collections.defaultdict(lambda: [0, 0.0])
 for f in sorted(glob.glob(f"{out}/pmc_*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
