@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py (one datapath per call): kernel stats (timing) + separate PMC passes (HBM bytes, MFMA
-# busy, LDS, waits).  usage: tools/profile.sh <fp32|bf16x3|mixed> [extra bench flags]
+# busy, LDS, waits).  usage: tools/profile.sh <fp16x3|bf16x3|fp32> [extra bench flags]
 # Writes gpurun_out/prof_<prec>/ and the two summaries profiles/ expects:
 #   gpurun_out/prof_<prec>/kernel_stats.csv, gpurun_out/prof_<prec>/pmc_summary.csv
 PREC=${1:-fp16x3}; shift
