@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, precision="fp16x3"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), NERF_ALLOW_SHARED_GPU="1")
     for p in (ROOT, os.path.join(ROOT, "oracle")):
@@ -51,7 +51,7 @@ def _worker(rank, world, port, q):
     rnd_all = {k: v.to(dev) for k, v in wl.synthetic_randoms(n, 64, 128, seed=2).items() if k in ("t_rand", "u")}
     args = dict(chunk=1 << 15, ndc=False, near=cfg["near"], far=cfg["far"], use_viewdirs=True, network_fn=nc, network_query_fn=None,
                 N_samples=64, N_importance=128, network_fine=nf, perturb=1.0, white_bkgd=True, raw_noise_std=0.)
-    npa.set_precision("bf16x3")
+    npa.set_precision(precision)
 
     def grads(rays, tgt, rnd):
         for m in (nc, nf):
@@ -81,14 +81,15 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_on_one_gpu_match_the_full_batch():
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16x3"])
+def test_two_ranks_on_one_gpu_match_the_full_batch(precision):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, precision)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=480) for _ in range(world)], key=lambda t: t[0])
