@@ -170,12 +170,18 @@ int nerf_debug_pack16_table(int* out_host);
  * plus the two correction terms  W_hi8 x_lo8 + W_lo8 x_hi8  as block-scaled fp8 e4m3 MFMAs of K = 128 (v_mfma_scale_f32_16x16x128_
  * f8f6f4): ~2^-15 per product at 2 instead of 3 MFMA-equivalents (csrc/field_ring8.h).  Admitted for inference by the north-star
  * gate with >= 30x margin on both fixtures (profiles/r04_accuracy_classes.md), never used for training.  Activations must stay
- * below 224 in magnitude (NaN beyond).  nerf_field_fwd_last_sample re-evaluates every ray's LAST sample of a pass with the
- * three-term fp16 products (packed3 = the split = 1 repack of the same parameters) into the pass's raw: the reference's
- * dists[-1] = 1e10 (run_nerf.py:277-278) makes that sample's alpha a step function of the sign of its density (:293), the one
- * place where a 2^-15 error can move a ray's opacity by O(1); call it after the reduced pass, before raw2outputs. */
+ * below 224 in magnitude (NaN beyond).  split = 3: the same pass with sample n_samples - 1 of every ray left unwritten.
+ *   nerf_field_fwd_last_sample evaluates every ray's LAST sample of a pass with the three-term fp16 products (packed3 = the
+ * split = 1 repack of the same parameters) into the pass's raw: the reference's dists[-1] = 1e10 (run_nerf.py:277-278) makes that
+ * sample's alpha a step function of the sign of its density (:293), the one place where a 2^-15 error can move a ray's opacity
+ * by O(1).  Call it after a split = 2 pass or in any order with a split = 3 pass, before raw2outputs.
+ *   packed3_next (nullable): in the same launch, the last sample of the hierarchical pass that refines this one, evaluated by THAT
+ * pass's network into raw_next[n_rays][n_samples_next][4].  Its depth is this pass's last depth: sample_pdf draws inside
+ * [z_mid[0], z_mid[-1]] (run_nerf.py:392-396, helpers:196-239), so the sorted union of run_nerf.py:396 ends with z_vals[:, -1].
+ * (One launch costs one pass of a workgroup through the network, ~70 us, for one network or two.) */
 int nerf_field_fwd_last_sample(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                               int n_samples, float* raw, void* stream);
+                               int n_samples, float* raw, const float* packed3_next /* nullable */, float* raw_next,
+                               int n_samples_next, void* stream);
 /* ---- which layout a scratch buffer holds.  The save buffer of a forward and the delta buffer of a dgrad exist in three layouts each
  * (fp32 point-major rows; bf16 tiles; fp16 tiles: csrc/nerf_common.h); the entry point that writes a buffer decides, and the entry
  * points that read it must agree.  The library remembers per buffer ADDRESS what its own entry points last wrote there (host-side

@@ -332,8 +332,8 @@ int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride
                          int n_samples, float* raw, float* act, int split, void* stream) {
     REQUIRE(packed3 && rays && z_vals && raw, "null pointer");
     REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && split >= 0 && split <= 2, "bad size");
-    REQUIRE(split != 2 || !act, "split = 2 (fp16 main term + fp8 corrections) is an inference form: act must be NULL");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && split >= 0 && split <= 3, "bad size");
+    REQUIRE(split < 2 || !act, "split = 2 / 3 (fp16 main term + fp8 corrections) is an inference form: act must be NULL");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
     if (act) tag_record(act, 0, split ? ACT_TILE16_F16 : ACT_TILE16_BF16, n_rays, n_samples);
@@ -342,12 +342,15 @@ int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride
 }
 
 int nerf_field_fwd_last_sample(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
-                               int n_samples, float* raw, void* stream) {
+                               int n_samples, float* raw, const float* packed3_next, float* raw_next, int n_samples_next, void* stream) {
     REQUIRE(packed3 && rays && z_vals && raw, "null pointer");
     REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0, "packed/raw must be 16-byte aligned");
-    return done(__func__, nerf::launch_field_fwd16r_last(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, (hipStream_t)stream));
+    REQUIRE(!packed3_next || (raw_next && n_samples_next >= n_samples), "packed3_next needs raw_next and the refining pass's sample count");
+    REQUIRE((reinterpret_cast<uintptr_t>(packed3_next) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw_next) & 15) == 0, "packed/raw must be 16-byte aligned");
+    return done(__func__, nerf::launch_field_fwd16r_last(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, packed3_next, raw_next,
+                                                         n_samples_next, (hipStream_t)stream));
 }
 
 int nerf_pack_params_split(const float* params, float* packed3, int streams, int split, void* stream) {

@@ -29,14 +29,15 @@ static hipError_t launch_one(const FieldFwdRingArgs& a, unsigned blocks, hipStre
 }
 
 // split: 0 = bf16 (packed3 from the bf16 repack), 1 = fp16 (packed3 from the fp16 repack); split_types.h
-// 2 = fp16 main term + fp8 correction terms (field_ring8.h; inference only: act must be null; packed3 from the reduced repack)
+// 2 = fp16 main term + fp8 correction terms (field_ring8.h; inference only: act must be null; packed3 from the reduced repack);
+// 3 = the same, every ray's last sample left unwritten (launch_field_fwd16r_last evaluates it)
 hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                                int n_rays, int S, float* raw, float* act, int split, hipStream_t stream) {
-    FieldFwdRingArgs a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S, S, 0};
+    FieldFwdRingArgs a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S, S, 0, S, 0, split == 3 ? 1 : 0};
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((P + PTS_PER_WG - 1) / PTS_PER_WG);
-    if (split == 2) return act ? hipErrorInvalidValue : launch_one<0, SplitF16, true>(a, blocks, stream);
+    if (split >= 2) return act ? hipErrorInvalidValue : launch_one<0, SplitF16, true>(a, blocks, stream);
     if (split) return act ? launch_one<2, SplitF16>(a, blocks, stream) : launch_one<0, SplitF16>(a, blocks, stream);
     return act ? launch_one<2, SplitBF16>(a, blocks, stream) : launch_one<0, SplitBF16>(a, blocks, stream);
 }
@@ -46,11 +47,34 @@ hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_
 // function of the sign of its density (:293): a density within the product class's error of zero flips a ray's opacity
 // (tools/analysis_accuracy_classes.py).  Evaluating those n_rays points (1/64 and 1/192 of the passes) in the fp32-class products
 // makes flips as rare as on the fp16x3 datapath.  packed3: the fp16 three-term repack of the same parameters.
+//   packed3_next (nullable): in the SAME launch, the last sample of the hierarchical pass that refines this one, evaluated by that
+// pass's network into raw_next[n_rays][S_next][4].  Its depth is known before its samples are drawn: sample_pdf draws inside
+// [z_mid[0], z_mid[-1]] (run_nerf.py:392-396, helpers:196-239), so the sorted union keeps this pass's last depth as its last depth.
+// One launch of 2 x n_rays / 128 workgroups costs one pass of a workgroup through the network (~70 us) whether it evaluates one
+// network or two: a 4096-ray batch pays that once instead of twice.
+template <typename SP>
+__global__ __launch_bounds__(FIELD_WAVES * 64) void field_fwd16r_last2_kernel(FieldFwdRingArgs a, FieldFwdRingArgs b, unsigned blocks_a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (blockIdx.x < blocks_a) field_fwd16r_tile<0, SP>(a, lds, (long)blockIdx.x);
+    else field_fwd16r_tile<0, SP>(b, lds, (long)(blockIdx.x - blocks_a));
+}
+
 hipError_t launch_field_fwd16r_last(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
-                                    int n_rays, int S, float* raw, hipStream_t stream) {
+                                    int n_rays, int S, float* raw, const float* packed3_next, float* raw_next, int S_next,
+                                    hipStream_t stream) {
     if (n_rays <= 0) return hipSuccess;
-    FieldFwdRingArgs a{packed3, rays, z_vals, raw, nullptr, ray_stride, n_rays, 1, S, S - 1};
-    return launch_one<0, SplitF16>(a, (unsigned)((n_rays + PTS_PER_WG - 1) / PTS_PER_WG), stream);
+    const unsigned blocks = (unsigned)((n_rays + PTS_PER_WG - 1) / PTS_PER_WG);
+    FieldFwdRingArgs a{packed3, rays, z_vals, raw, nullptr, ray_stride, n_rays, 1, S, S - 1, S, S - 1, 0};
+    if (!packed3_next) return launch_one<0, SplitF16>(a, blocks, stream);
+    FieldFwdRingArgs b{packed3_next, rays, z_vals, raw_next, nullptr, ray_stride, n_rays, 1, S, S - 1, S_next, S_next - 1, 0};
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)field_fwd16r_last2_kernel<SplitF16>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((field_fwd16r_last2_kernel<SplitF16>), dim3(2 * blocks), dim3(FIELD_WAVES * 64), RING_LDS_FLOATS * 4, stream, a, b, blocks);
+    return hipGetLastError();
 }
 
 }  // namespace nerf

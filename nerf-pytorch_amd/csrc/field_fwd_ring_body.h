@@ -20,6 +20,10 @@ struct FieldFwdRingArgs {
     // for a whole pass; S = 1, z_stride = the pass's sample count, s_off = z_stride - 1 evaluates ONLY every ray's last sample into
     // the pass's raw (the guard of the reduced inference class: launch_field_fwd16r_last).  Saving needs the whole-pass form.
     int z_stride, s_off;
+    // raw row of that sample: (r * raw_stride + raw_off + s) * 4 -- the same numbers, unless a guard launch writes the last sample of
+    // ANOTHER pass (the hierarchical pass keeps the last depth of the pass it refines: launch_field_fwd16r_last)
+    int raw_stride, raw_off;
+    int skip_last;          // 1: sample S - 1 of every ray is left unwritten (the guard launch evaluates it)
 };
 
 // units of the P16F stream in consumption order: L0 8 | L1..L4 4 x 32 | L5 40 | L6 L7 2 x 32 | (feature_linear 32: skipped)
@@ -53,7 +57,9 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     stage_small_ring(a.packed3 + P3_SMALL, lds, FIELD_WAVES * 64);
 
     const float* rp = a.rays + (long)ray * a.ray_stride;
-    const long zi = (long)ray * a.z_stride + a.s_off + (p - (long)ray * a.S);
+    const long si = p - (long)ray * a.S;
+    const long zi = (long)ray * a.z_stride + a.s_off + si;
+    const long ri = (long)ray * a.raw_stride + a.raw_off + si;
     const float z = a.z_vals[zi];
     const float x0 = rp[0] + rp[3] * z;
     const float x1 = rp[1] + rp[4] * z;
@@ -187,7 +193,7 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
         for (int i = 0; i < 7; ++i) dv[i] = v7[i];
         dv[7] = 0.0f;
     }
-    if (SAVE && valid && (p - (long)ray * a.S) == 0) {
+    if (SAVE && valid && si == 0) {
         float* dout = a.act + al.dir + (size_t)ray * 32;
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
@@ -251,7 +257,7 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
         c1 = quarter_sum(c1) + ring_small_ptr(lds, SM_BRGB)[1];
         c2 = quarter_sum(c2) + ring_small_ptr(lds, SM_BRGB)[2];
     }
-    if (valid && q == 0) *reinterpret_cast<f32x4*>(a.raw + (size_t)zi * 4) = f32x4{c0, c1, c2, sigma};
+    if (valid && q == 0 && !(a.skip_last && si == a.S - 1)) *reinterpret_cast<f32x4*>(a.raw + (size_t)ri * 4) = f32x4{c0, c1, c2, sigma};
 }
 
 }  // namespace nerf

@@ -89,7 +89,8 @@ hipError_t launch_pack3_sel(const float* canon_params, float* packed, int stream
 hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                                int n_rays, int S, float* raw, float* act, int split, hipStream_t stream);
 hipError_t launch_field_fwd16r_last(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
-                                    int n_rays, int S, float* raw, hipStream_t stream);
+                                    int n_rays, int S, float* raw, const float* packed3_next, float* raw_next, int S_next,
+                                    hipStream_t stream);
 hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
                                 float* delta, int split, hipStream_t stream);
 

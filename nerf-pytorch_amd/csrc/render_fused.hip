@@ -71,7 +71,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void render_infer_kernel(RenderIn
         __syncthreads();        // depths of this pass visible; LDS free for the ring
         const bool second = t >= tiles_c;
         const FieldFwdRingArgs fa{second ? a.packed_f : a.packed_c, a.rays, second ? a.z_f : a.z_c, second ? a.raw_f : a.raw_c,
-                                  nullptr, a.ray_stride, a.n_rays, second ? S2 : Sc, second ? S2 : Sc, 0};
+                                  nullptr, a.ray_stride, a.n_rays, second ? S2 : Sc, second ? S2 : Sc, 0, second ? S2 : Sc, 0, 0};
         const long wg = second ? (long)blockIdx.x * tiles_f + (t - tiles_c) : (long)blockIdx.x * tiles_c + t;
         field_fwd16r_tile<0, SP, RED>(fa, lds, wg);
     }

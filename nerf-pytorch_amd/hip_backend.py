@@ -55,7 +55,7 @@ def _declare(lib):
         "nerf_pack_params_split": (i, [p, p, i, i, p]),
         "nerf_field_fwd_split": (i, [p, p, i, p, i, i, p, p, i, p]),
         "nerf_field_dgrad_split": (i, [p, p, p, i, i, p, i, p]),
-        "nerf_field_fwd_last_sample": (i, [p, p, i, p, i, i, p, p]),
+        "nerf_field_fwd_last_sample": (i, [p, p, i, p, i, i, p, p, p, i, p]),
         "nerf_debug_pack16_table": (i, [p]),
         "nerf_adam_step": (i, [p, p, p, p, i, f, f, f, f, i, p]),
         "nerf_render_workspace_floats": (sz, [p, i, i]),
@@ -502,11 +502,17 @@ def render_rays_infer(packed_c, packed_f, rays, n_coarse, n_fine, lindisp, white
     return {"rgb_f": rgb, "disp_f": disp, "acc_f": acc, "raw_f": raw, "rgb_c": rgb0, "disp_c": disp0, "acc_c": acc0, "z_std": z_std}
 
 
-def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32", guard_packed=None):
-    """guard_packed (precision "fp16_fp8c"): the fp16x3 repack of the same parameters for the last-sample guard"""
+def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32", guard_packed=None, raw=None, next_guard=None):
+    """guard_packed (precision "fp16_fp8c"): the fp16x3 repack of the same parameters for the last-sample guard, or the string
+    "done" when an earlier call's next_guard has already written this pass's last samples into `raw`.
+    next_guard = (fp16x3 repack of the refining pass's network, that pass's preallocated raw [n, S_next, 4]): the guard launch also
+    evaluates the refining pass's last sample (its depth is this pass's last depth)."""
     n, stride = rays.shape
     S = z_vals.shape[1]
-    raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
+    if raw is None:
+        raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
+    elif tuple(raw.shape) != (n, S, 4) or raw.dtype != torch.float32 or not raw.is_contiguous():
+        raise NerfHipError(f"field_fwd: raw= must be a contiguous float32 [{n}, {S}, 4] tensor")
     act = WORKSPACE.take(act_floats(n, S), rays.device) if save_act else None
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in SPLIT:
@@ -518,10 +524,13 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32", guard_pack
             raise NerfHipError("field_fwd: \"fp16_fp8c\" needs guard_packed= (the fp16x3 repack) for the last-sample guard")
         with _timed("field_fwd16r_kernel<fp16 + fp8c>", FLOP_FWD3_PER_POINT * n * S, nbytes):
             _check(lib().nerf_field_fwd_split(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
-                                              n, S, _ptr(raw), None, 2, _stream()), "nerf_field_fwd_split")
-        with _timed("field_fwd16r_kernel<fp16> (last samples)", FLOP_FWD3_PER_POINT * n, 16.0 * n):
-            _check(lib().nerf_field_fwd_last_sample(_ptr(guard_packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
-                                                    n, S, _ptr(raw), _stream()), "nerf_field_fwd_last_sample")
+                                              n, S, _ptr(raw), None, 3, _stream()), "nerf_field_fwd_split")
+        if not (isinstance(guard_packed, str) and guard_packed == "done"):
+            nxt, raw_n, S_n = (None, None, 0) if next_guard is None else (next_guard[0], next_guard[1], next_guard[1].shape[1])
+            with _timed("field_fwd16r_kernel<fp16> (last samples)", FLOP_FWD3_PER_POINT * n * (1 if nxt is None else 2), 16.0 * n):
+                _check(lib().nerf_field_fwd_last_sample(_ptr(guard_packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
+                                                        n, S, _ptr(raw), _ptr(nxt, "packed3", True), _ptr(raw_n, "raw", True), S_n,
+                                                        _stream()), "nerf_field_fwd_last_sample")
         return raw, act
     if precision == "fp16x3":
         with _timed("field_fwd16r_kernel<fp16" + (", save>" if save_act else ">"), FLOP_FWD3_PER_POINT * n * S,

@@ -133,16 +133,21 @@ def _field_pass(cfg, rays, rnd, model_c, model_f, save):
     guard = (lambda m: m.packed_params("fp16x3")) if prec == "fp16_fp8c" else (lambda m: None)
     r["packed_c"] = model_c.packed_params(prec)
     r["z_c"] = hb.sample_coarse(rays, _linspace01(n_c, dev), cfg["lindisp"], rnd.get("t_rand"))
-    r["raw_c"], r["act_c"] = hb.field_fwd(r["packed_c"], rays, r["z_c"], save_act=save, precision=prec, guard_packed=guard(model_c))
+    mf = model_c if (model_f is None or model_f is model_c) else model_f
+    nxt = raw_f = None
+    if prec == "fp16_fp8c" and n_f > 0:     # the guard launch of the coarse pass also evaluates the fine pass's last sample (hb.field_fwd)
+        raw_f = torch.empty((rays.shape[0], n_c + n_f, 4), dtype=torch.float32, device=dev)
+        nxt = (guard(mf), raw_f)
+    r["raw_c"], r["act_c"] = hb.field_fwd(r["packed_c"], rays, r["z_c"], save_act=save, precision=prec, guard_packed=guard(model_c), next_guard=nxt)
     r["rgb_c"], r["disp_c"], r["acc_c"], w_c, _ = hb.raw2outputs(r["raw_c"], r["z_c"], rays, rays.shape[1], rnd.get("noise_c"), std, wb,
                                                               want_weights=n_f > 0, want_depth=False, rays_d_offset=3)
     if n_f <= 0:
         return r
     u = rnd.get("u")
     r["z_f"], r["z_std"], _ = hb.sample_fine(r["z_c"], w_c, n_f, u, None if u is not None else _linspace01(n_f, dev))
-    mf = model_c if (model_f is None or model_f is model_c) else model_f
     r["packed_f"] = mf.packed_params(prec)
-    r["raw_f"], r["act_f"] = hb.field_fwd(r["packed_f"], rays, r["z_f"], save_act=save, precision=prec, guard_packed=guard(mf))
+    r["raw_f"], r["act_f"] = hb.field_fwd(r["packed_f"], rays, r["z_f"], save_act=save, precision=prec,
+                                          guard_packed="done" if raw_f is not None else guard(mf), raw=raw_f)
     r["rgb_f"], r["disp_f"], r["acc_f"], _, _ = hb.raw2outputs(r["raw_f"], r["z_f"], rays, rays.shape[1], rnd.get("noise_f"), std, wb,
                                                              want_weights=False, want_depth=False, rays_d_offset=3)
     return r

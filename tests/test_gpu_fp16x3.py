@@ -316,3 +316,35 @@ def test_reduced_class_renders_without_gradients_and_trains_on_fp16x3(npa, dev, 
     assert 0.0 < d <= 3e-4, d
     ref = orc.trace_rays(rays.cpu(), Pc, Pf, 64, 128, white_bkgd=True)
     assert maxdiff(out["fp16_fp8c"]["rgb0"], ref["rgb0"]) <= 3e-4
+
+
+@pytest.mark.parametrize("perturb,lindisp", [(0.0, False), (1.0, False), (1.0, True)])
+def test_one_guard_launch_for_both_passes(npa, dev, nets, perturb, lindisp):
+    """The guard launch of the coarse pass also evaluates the fine pass's last sample (nerf_field_fwd_last_sample(packed3_next)):
+    sample_pdf draws inside [z_mid[0], z_mid[-1]] (helpers:196-239), so the sorted union of run_nerf.py:396 ends with the coarse
+    pass's last depth -- checked here on the sampled depths themselves -- and the chain with ONE guard launch returns, bit for bit,
+    what the chain with one guard launch per pass returns."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    n, Sc, Sf = 300, 64, 128
+    rays = orc.synthetic_rays(n, seed=5).to(dev)
+    g = torch.Generator().manual_seed(11)
+    t_rand = torch.rand(n, Sc, generator=g).to(dev) if perturb > 0 else None
+    u = torch.rand(n, Sf, generator=g).to(dev) if perturb > 0 else None
+    t_lin = torch.linspace(0., 1., Sc, device=dev)
+    z_c = hb.sample_coarse(rays, t_lin, lindisp, t_rand)
+    p8c, p8f, p16c, p16f = nc.packed_params("fp16_fp8c"), nf.packed_params("fp16_fp8c"), nc.packed_params("fp16x3"), nf.packed_params("fp16x3")
+
+    def chain(one_launch):
+        raw_f = torch.full((n, Sc + Sf, 4), float("nan"), device=dev) if one_launch else None
+        raw_c, _ = hb.field_fwd(p8c, rays, z_c, precision="fp16_fp8c", guard_packed=p16c, next_guard=(p16f, raw_f) if one_launch else None)
+        _, _, _, w, _ = hb.raw2outputs(raw_c, z_c, rays, rays.shape[1], None, 0.0, True, want_weights=True, want_depth=False, rays_d_offset=3)
+        z_f, _, _ = hb.sample_fine(z_c, w, Sf, u, None if u is not None else torch.linspace(0., 1., Sf, device=dev))
+        raw_f, _ = hb.field_fwd(p8f, rays, z_f, precision="fp16_fp8c", guard_packed="done" if one_launch else p16f, raw=raw_f)
+        return raw_c, z_f, raw_f
+    rc1, zf1, rf1 = chain(True)
+    rc2, zf2, rf2 = chain(False)
+    assert torch.equal(zf1[:, -1], z_c[:, -1]) and torch.equal(zf1, zf2)
+    assert torch.equal(rc1, rc2) and torch.equal(rf1, rf2) and bool(torch.isfinite(rf1).all())
+    raw3, _ = hb.field_fwd(p16f, rays, zf1, precision="fp16x3")
+    assert torch.equal(rf1[:, -1], raw3[:, -1])
