@@ -188,20 +188,21 @@ __device__ inline f32x4 load_row4(const float* base, int ld, long row, bool row_
     return v;
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float sA[2][WG_STAGE][WG_TILE];
-    __shared__ __attribute__((aligned(16))) float sB[2][WG_STAGE][WG_TILE];
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One 128 x 128 output tile of a narrow job for one point chunk.  WN x WK = how the four waves share the tile: 2 x 2 (wave tile
+// 64 n x 64 k), 4 x 1 (32 n x 64 k: jobs whose tile has <= 64 valid k columns -- the encodings -- where the 2 x 2 form leaves the
+// two wave_k = 1 waves, i.e. two of the CU's four matrix pipes, without work), 1 x 4 (64 n x 32 k: the one-row / three-row jobs of
+// the heads).  Lane c of a wave holds NI (NJ) consecutive n (k) columns -- the NI x NJ blocks of 16 x 16 outputs interleave -- so a
+// fragment is one ds_read of 8 or 16 bytes.  Every output element accumulates its points in the same order in every form:
+// results are bit-identical to the 2 x 2 form.
+template <int WN, int WK>
+__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, const WgradJob& jb, float (*sA)[WG_STAGE][WG_TILE], float (*sB)[WG_STAGE][WG_TILE],
+                                           int n0, int k0, int tk, int chunk) {
+    constexpr int NI = WN == 4 ? 2 : 4, NJ = WK == 4 ? 2 : 4;       // 16-row blocks per wave along n / k (= floats per fragment read)
+    constexpr int WAVE_N = 16 * NI, WAVE_K = 16 * NJ;               // wave tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_n = wave >> 1, wave_k = wave & 1;
-    const int tile = blockIdx.x % a.total_tiles;
-    const int chunk = blockIdx.x / a.total_tiles;
-    int ji = 0;
-#pragma unroll 1
-    for (int j = 1; j < a.n_jobs; ++j) if (tile >= a.job[j].tile_base) ji = j;
-    const WgradJob& jb = a.job[ji];
-    const int lt = tile - jb.tile_base;
-    const int tn = lt / jb.tiles_k, tk = lt % jb.tiles_k;
-    const int n0 = tn * WG_TILE, k0 = tk * WG_TILE;
+    const int wave_n = WN == 1 ? 0 : (WN == 4 ? wave : wave >> 1), wave_k = WK == 1 ? 0 : (WK == 4 ? wave : wave & 1);
     const long p_begin = (long)chunk * a.chunk_pts;
     const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
     const int n_stages = (int)((p_end - p_begin + WG_STAGE - 1) / WG_STAGE);
@@ -229,66 +230,91 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bsum[i] = 0.f;
 
     gload(0);
     swrite(0);
     __syncthreads();
     const int c = lane & 15, pp = lane >> 4;
-    // narrow jobs (63 / 27 / 3 / 1 valid columns): a wave whose whole 64-wide n- or k-range is zero padding only helps
-    // with staging and leaves the MFMA pipe to the other workgroup resident on this CU
-    const bool wave_has_work = (wave_n * 64 < nA) && (wave_k * 64 < nB);
+    // a wave whose whole n- or k-range is zero padding only helps with staging
+    const bool wave_has_work = (wave_n * WAVE_N < nA) && (wave_k * WAVE_K < nB);
     for (int st = 0; st < n_stages; ++st) {
         const int buf = st & 1;
         if (st + 1 < n_stages) gload(st + 1);
         if (wave_has_work) {
 #pragma unroll
             for (int ps = 0; ps < WG_STAGE / 4; ++ps) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(&sA[buf][4 * ps + pp][wave_n * 64 + 4 * c]);
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(&sB[buf][4 * ps + pp][wave_k * 64 + 4 * c]);
-                bsum += av;
+                float av[NI], bv[NJ];
+                const float* ap = &sA[buf][4 * ps + pp][wave_n * WAVE_N + NI * c];
+                const float* bp = &sB[buf][4 * ps + pp][wave_k * WAVE_K + NJ * c];
+                if constexpr (NI == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(ap); av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3]; }
+                else { const f32x2 t = *reinterpret_cast<const f32x2*>(ap); av[0] = t[0]; av[1] = t[1]; }
+                if constexpr (NJ == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(bp); bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3]; }
+                else { const f32x2 t = *reinterpret_cast<const f32x2*>(bp); bv[0] = t[0]; bv[1] = t[1]; }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i) {
+                    bsum[i] += av[i];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
             }
         }
         if (st + 1 < n_stages) swrite(buf ^ 1);
         __syncthreads();
     }
 
-    // acc[i][j][r] = dW[n0 + wave_n*64 + 4*(4*pp + r) + i][k0 + wave_k*64 + 4*c + j]
+    // acc[i][j][r] = dW[n0 + wave_n*WAVE_N + NI*(4*pp + r) + i][k0 + wave_k*WAVE_K + NJ*c + j]
     float* out = a.partial + (size_t)chunk * N_PARAMS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = wave_n * 64 + 4 * (4 * pp + r) + i;
+            const int n = wave_n * WAVE_N + NI * (4 * pp + r) + i;
             if (n < nA) {
                 float* row = out + jb.c_off + (size_t)(n0 + n) * jb.ldc + k0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = wave_k * 64 + 4 * c + j;
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = wave_k * WAVE_K + NJ * c + j;
                     if (k < nB) row[k] = acc[i][j][r];
                 }
             }
         }
     if (jb.bias_off >= 0 && tk == 0 && wave_k == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             float v = bsum[i];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            const int n = wave_n * 64 + 4 * c + i;
+            const int n = wave_n * WAVE_N + NI * c + i;
             if (pp == 0 && n < nA) out[jb.bias_off + n0 + n] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[2][WG_STAGE][WG_TILE];
+    __shared__ __attribute__((aligned(16))) float sB[2][WG_STAGE][WG_TILE];
+    const int tile = blockIdx.x % a.total_tiles;
+    const int chunk = blockIdx.x / a.total_tiles;
+    int ji = 0;
+#pragma unroll 1
+    for (int j = 1; j < a.n_jobs; ++j) if (tile >= a.job[j].tile_base) ji = j;
+    const WgradJob& jb = a.job[ji];
+    const int lt = tile - jb.tile_base;
+    const int tn = lt / jb.tiles_k, tk = lt % jb.tiles_k;
+    const int n0 = tn * WG_TILE, k0 = tk * WG_TILE;
+    const int nA = jb.nA - n0, nB = jb.nB - k0;          // valid columns of this tile: how the four waves share it
+    if (nB <= 64 && nA > 64) wgrad_tile<4, 1>(a, jb, sA, sB, n0, k0, tk, chunk);
+    else if (nA <= 64 && nB > 64) wgrad_tile<1, 4>(a, jb, sA, sB, n0, k0, tk, chunk);
+    else wgrad_tile<2, 2>(a, jb, sA, sB, n0, k0, tk, chunk);
 }
 
 // Full-width jobs (256 x 256 outputs, 16-byte aligned rows): one workgroup owns the WHOLE output of a job for its
