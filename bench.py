@@ -904,7 +904,11 @@ def main():
                    "kernels": {k: round(v["avg_ms"], 4) for k, v in kernel_table(kern_r).items()},
                    "what": "no_grad render() of the same 4096-ray batches under set_precision('fp16_fp8c'): every product of the 256-wide layers = "
                            "W_hi16 x_hi16 (fp16 MFMA) + W_hi8 x_lo8 + W_lo8 x_hi8 (fp8 e4m3 MFMAs, K = 128), ~2^-15 per product, 2 instead of 3 "
-                           "MFMA-equivalents; every ray's last sample re-evaluated with the three-term fp16 products; chain of launches"}
+                           "MFMA-equivalents; every ray's last sample evaluated with the three-term fp16 products (one guard launch for both "
+                           "passes); chain of 7 launches"}
+            if default_run:     # BASELINE configs[4] on this class: 800x800 frames of the lego spiral
+                ef, _k = measure("fp16_fp8c", 2, 1, ses.frame_step, with_kernels=False)
+                out["render_only"] = {"rays_per_s": args.frame * args.frame * 2 / ef, "s_per_frame": ef / 2, "frame": args.frame, "chunk": args.chunk}
             if not args.no_gate:
                 g = ses.gate("fp16_fp8c", with_operands=False)
                 out["precision_gate"] = None if g is None else {k: g[k] for k in ("psnr_delta_db", "psnr_vs_ref_db", "target_psnr_db", "passed")}

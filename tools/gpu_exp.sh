@@ -1,6 +1,11 @@
 #!/bin/bash
-mkdir -p gpurun_out/r04
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q -k "fp32 or backward or golden or grad or fuzz" 2>&1 | tail -4
-timeout 300 python bench.py --no-cpu-baseline --no-eager-baseline --single-datapath --no-configs --no-gate --steps 10 --precision fp32 > gpurun_out/r04/q_fp32.json 2> gpurun_out/r04/q_fp32.err
-python -c "
-import json; d=json.loads([l for l in open('gpurun_out/r04/q_fp32.json') if l.startswith('{')][-1]); print('fp32', round(d['value']), round(d['ms_per_step'],3)); print({k: round(v['avg_ms'],4) for k,v in d['kernels'].items()})"
+mkdir -p gpurun_out
+timeout 900 python bench.py > gpurun_out/check_bench.json 2> gpurun_out/check_bench.err
+tail -c 300 gpurun_out/check_bench.err
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/check_bench.json') if l.startswith('{')][-1])
+print('value', round(d['value']), round(d['ms_per_step'],3), 'eager', round(d['rocm_eager_baseline']['train_rays_per_s']), round(d['rocm_eager_baseline']['infer_rays_per_s']), {k:round(v,2) for k,v in d['speedup_vs_rocm_eager'].items()})
+print('reduced', round(d['reduced_inference']['rays_per_s']), d['reduced_inference'].get('render_only'), 'infer', round(d['inference_rays_per_s']), 'render_only', d['configs']['render_only']['value'], d['configs']['render_only']['s_per_frame'], 'errors', d.get('errors'))
+print('f32', round(d['other_datapath']['value']))
+PY
