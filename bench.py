@@ -166,7 +166,7 @@ def cpu_baseline(cfg_name, n_rays=512):
                       f"{os.cpu_count()} host CPUs)"}
 
 
-def rocm_eager_baseline(cfg_name, dev, n_rays, steps=5):
+def rocm_eager_baseline(cfg_name, dev, n_rays, steps=5, frame=0, chunk=32768, pose=None):
     """Baseline leg: the reference's own algorithm as eager PyTorch-ROCm ops on this GPU (the oracle's torch ops with CUDA
     tensors = what run_nerf.py executes after set_default_tensor_type('torch.cuda.FloatTensor'), run_nerf.py:876), same
     workload shape, training step and no_grad render.  It is the denominator of the north-star '>= 10x' target; like
@@ -215,9 +215,31 @@ def rocm_eager_baseline(cfg_name, dev, n_rays, steps=5):
         times.sort()
         res[name] = n_rays / times[len(times) // 2]
         spread[name] = {"fastest_step_rays_per_s": n_rays / times[0], "slowest_step_rays_per_s": n_rays / times[-1]}
+    frame_leg = None
+    if frame > 0 and pose is not None and cfg_name == "lego":
+        # BASELINE configs[4]: one frame of the spiral as render_path runs it (run_nerf.py:137-175): get_rays for the full image,
+        # batchify_rays in chunks of `chunk`, the network in netchunk slices
+        focal = cfg["focal"] * frame / cfg["W"]
+        Kf = [[focal, 0, 0.5 * frame], [0, focal, 0.5 * frame], [0, 0, 1]]
+
+        ro, rd = orc.pinhole_rays(frame, frame, Kf, torch.as_tensor(pose[:3, :4], dtype=torch.float32))
+        ro, rd = ro.to(dev), rd.to(dev)         # (ray generation itself stays outside the timed frame: it favours the baseline)
+
+        def one_frame():
+            with torch.no_grad():
+                rays = orc.assemble_rays(ro, rd, cfg["near"], cfg["far"])
+                orc.trace_in_chunks(rays, chunk, P_coarse=Pc, P_fine=Pf, n_coarse=N_SAMPLES, n_fine=N_IMPORTANCE, perturb=0.0,
+                                    white_bkgd=cfg["white_bkgd"])
+        one_frame()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one_frame()
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - t0
+        frame_leg = {"rays_per_s": frame * frame / tf, "s_per_frame": tf, "frame": frame, "chunk": chunk}
     del Pc, Pf, opt
     torch.cuda.empty_cache()
-    return {"train_rays_per_s": res["train"], "infer_rays_per_s": res["infer"], "unit": "rays/s", "steps": steps,
+    return {"train_rays_per_s": res["train"], "infer_rays_per_s": res["infer"], "render_only": frame_leg, "unit": "rays/s", "steps": steps,
             "rate_of": "median step", "spread": spread,
             "what": f"reference algorithm as eager PyTorch-ROCm ops on this GPU (oracle ops on cuda tensors), {n_rays} rays x (64+128), "
                     f"{cfg_name} workload, torch {torch.__version__}, timed after the product legs (warm GPU)"}
@@ -1069,7 +1091,8 @@ def main():
             line["power"] = sustained["train"]["power"]
         eb = None
         if world == 1 and not args.no_eager_baseline and args.mode != "render_only":
-            eb = _guarded(errors, "rocm_eager_baseline", lambda: rocm_eager_baseline(args.config, dev, n))
+            eb = _guarded(errors, "rocm_eager_baseline", lambda: rocm_eager_baseline(
+                args.config, dev, n, frame=args.frame if default_run else 0, chunk=args.chunk, pose=ses.spiral[0]))
         if eb is not None:
             line["rocm_eager_baseline"] = eb
             ref = eb["train_rays_per_s"] if args.mode == "train" else eb["infer_rays_per_s"]
@@ -1084,6 +1107,10 @@ def main():
                 line["speedup_vs_rocm_eager"]["reduced_inference"] = reduced_infer["rays_per_s"] / eb["infer_rays_per_s"]
             if other_infer is not None:
                 line["speedup_vs_rocm_eager"]["inference"] = other_infer / eb["infer_rays_per_s"]
+            if eb.get("render_only") and legs and legs.get("render_only"):      # configs[4]: frames against frames
+                line["speedup_vs_rocm_eager"]["render_only"] = legs["render_only"]["value"] / eb["render_only"]["rays_per_s"]
+                if reduced_infer is not None and reduced_infer.get("render_only"):
+                    line["speedup_vs_rocm_eager"]["reduced_render_only"] = reduced_infer["render_only"]["rays_per_s"] / eb["render_only"]["rays_per_s"]
         if world == 1 and not args.no_cpu_baseline:
             cb = _guarded(errors, "cpu_baseline", lambda: cpu_baseline(args.config))
             if cb is not None:
