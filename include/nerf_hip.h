@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 7
+#define NERF_ABI_VERSION 8
 #define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
 
@@ -194,6 +194,14 @@ int nerf_field_fwd_last_sample(const float* packed3, const float* rays, int ray_
  * in 16-point tiles of bf16 / fp16 (nerf_field_fwd_split(split = 0 / 1)); delta (*is_delta = 1): 0 fp32 rows, 2 / 3 = 32-point
  * tiles of bf16 / fp16. */
 int nerf_buffer_layout(const float* buf, int* is_delta, int* n_rays, int* n_samples);
+/* test hook (host only): where the regions of such a buffer start, in floats from its base, for n_rays x n_samples points.
+ * family 0 = fp32 point-major rows, 1 = the split datapaths' tiles of 16-bit elements.  out_host[16]:
+ *   save buffer  (is_delta = 0): [0..7] post-ReLU rows of trunk layers 0..7, [8] feature (fp32 rows only; the split datapaths fold
+ *                that layer and use the slot as the dump tile of out-of-range waves), [9] view branch, [10] xyz encoding,
+ *                [11] direction encoding per ray, [12] its per-point / per-ray-record expansion, [13] ReLU bitmasks, [14] total;
+ *   delta buffer (is_delta = 1): [0..7], [8], [9] as above, [10] tiled copy of d_raw, [11] the launch's max|d_raw| word
+ *                (family 1 only), [14] total.   Unused slots are -1. */
+int nerf_debug_layout(int n_rays, int n_samples, int family, int is_delta, long long* out_host);
 /* The weight gradients dW = delta^T x, db = sum delta of one evaluation (the second half of nerf_field_bwd; the only form on the
  * split datapaths), split into launches a profiler can bracket: phases bit 0 = the GEMM jobs (fp32: the eight full-width 256x256
  * jobs; split datapaths: all 13 jobs on the streaming 16-bit GEMM), bit 1 = the six narrow jobs (fp32 datapath only), bit 2 =

@@ -160,6 +160,32 @@ size_t nerf_workspace_floats(int n_rays, int n_coarse, int n_fine, int training)
            nerf_delta_floats(n_rays, s_big) + nerf_wgrad_partial_floats(n_rays, s_big);
 }
 
+int nerf_debug_layout(int n_rays, int n_samples, int family, int is_delta, long long* out_host) {
+    REQUIRE(out_host, "null pointer");
+    REQUIRE(n_rays > 0 && n_samples > 0 && (family == 0 || family == 1), "bad size / family (0 fp32 rows, 1 split tiles)");
+    const size_t P = (size_t)n_rays * n_samples;
+    for (int i = 0; i < 16; ++i) out_host[i] = -1;
+    auto put = [&](int i, size_t v) { out_host[i] = (long long)v; };
+    if (!is_delta && family == 0) {
+        const nerf::ActLayout a = nerf::act_layout(P, (size_t)n_rays);
+        for (int l = 0; l < nerf::D; ++l) put(l, a.h[l]);
+        put(8, a.feat); put(9, a.hv); put(10, a.enc); put(11, a.dir); put(12, a.dir_pt); put(13, a.mask); put(14, a.total);
+    } else if (!is_delta) {
+        const nerf::ActLayout3 a = nerf::act_layout3(P, (size_t)n_rays);
+        for (int l = 0; l < nerf::D; ++l) put(l, a.h[l]);
+        put(8, a.feat); put(9, a.hv); put(10, a.enc); put(11, a.dir); put(12, a.dir_pt); put(13, a.mask); put(14, a.total);
+    } else if (family == 0) {
+        const nerf::DeltaLayout a = nerf::delta_layout(P);
+        for (int l = 0; l < nerf::D; ++l) put(l, a.h[l]);
+        put(8, a.feat); put(9, a.hv); put(14, a.total);
+    } else {
+        const nerf::DeltaLayout3 a = nerf::delta_layout3(P);
+        for (int l = 0; l < nerf::D; ++l) put(l, a.h[l]);
+        put(8, a.feat); put(9, a.hv); put(10, a.graw); put(11, a.scale); put(14, a.total);
+    }
+    return 0;
+}
+
 int nerf_buffer_layout(const float* buf, int* is_delta, int* n_rays, int* n_samples) {
     BufTag t;
     if (!buf || !tag_lookup(buf, &t)) return -1;

@@ -15,7 +15,7 @@ from . import build as _build
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
-ABI_VERSION = 7        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
+ABI_VERSION = 8        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
 
 
 class NerfHipError(RuntimeError):
@@ -37,6 +37,7 @@ def _declare(lib):
         "nerf_make_rays": (i, [i, i, p, p, p, i, f, f, p, i, p]),
         "nerf_assemble_rays": (i, [p, p, l, i, i, i, f, f, f, p, i, p]),
         "nerf_buffer_layout": (i, [p, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(i)]),
+        "nerf_debug_layout": (i, [i, i, i, i, ctypes.POINTER(ctypes.c_longlong)]),
         "nerf_act_floats": (sz, [i, i]),
         "nerf_workspace_floats": (sz, [i, i, i, i]),
         "nerf_field_fwd": (i, [p, p, i, p, i, i, p, p, p]),
@@ -80,7 +81,7 @@ def _declare(lib):
 
 
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
-           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_buffer_layout", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
+           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_buffer_layout", "nerf_debug_layout", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_debug_pack3_table",
@@ -421,38 +422,78 @@ def _row16h(f):
     return (f & ~15) + 8 * ((f >> 1) & 1) + 2 * ((f >> 2) & 3) + (f & 1)
 
 
-def saved_rows(buf, P, region, precision="fp32", tile16=None, bf16=None):
-    """Debug/test view of one saved region (activations or deltas) as a point-major [P, F] tensor.
-    region: "h0".."h7", "feat" (fp32 datapath only: the split datapaths fold feature_linear into the view branch and never write
-    it), "hv", "enc".  The fp32 datapath stores point-major fp32 rows (act_layout); the split datapaths store 16-bit elements
-    (bf16 / fp16 by `precision`) in tiles (act_layout3 in csrc/nerf_common.h) over P rounded up to 32: the 256- / 128-wide
-    activation rows saved by the forward in 16-point tiles with the row16h row order (tile16=True; default: what the library
-    recorded for the buffer), deltas and encodings in 32-point feature-major tiles."""
-    tiled = precision in SPLIT
-    kind, is_delta = buffer_layout(buf)[:2] if buf.is_cuda else (-1, False)
-    f16 = precision == "fp16x3"         # 16-bit elements are IEEE halves
-    if tile16 is None:
-        tile16 = kind in (3, 4, 5) and not is_delta
-    if bf16 is None:
-        bf16 = precision in SPLIT or kind in (2, 4, 5)
-    Pa = (P + 31) // 32 * 32 if tiled else P
-    widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
-    off = 0
-    for name, F in widths:
-        if name == region:
-            flat = buf[off:off + Pa * F]
-            if not tiled:
-                return flat.view(P, F)
-            if bf16:                        # 2-byte elements in the first half of the region
-                flat = flat.view(torch.float16 if f16 else torch.bfloat16)[:Pa * F].float()
-            if tile16 and F in (256, 128):
-                rows = flat.view(Pa // 16, F, 16).permute(0, 2, 1).reshape(Pa, F)[:P]      # [P, row]
-                if bf16:
-                    return rows[:, _row16h(torch.arange(F, device=rows.device))]         # bf16 tiles: feature f at row16h(f)
-                return rows[:, _row16(torch.arange(F, device=rows.device))]              # feature f sits at row16(f)
-            return flat.view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
-        off += Pa * F
-    raise KeyError(region)
+_REGIONS = {**{"h%d" % i: (i, 256) for i in range(8)}, "feat": (8, 256), "hv": (9, 128)}
+
+
+def buffer_regions(n_rays, n_samples, split, is_delta=False):
+    """nerf_debug_layout: region offsets (floats) of a save / delta buffer for n_rays x n_samples points; split = the split
+    datapaths' tiles of 16-bit elements (False: the fp32 datapath's point-major rows)."""
+    out = (ctypes.c_longlong * 16)()
+    _check(lib().nerf_debug_layout(int(n_rays), int(n_samples), int(bool(split)), int(bool(is_delta)), out), "nerf_debug_layout")
+    keys = [f"h{i}" for i in range(8)] + ["feat", "hv"] + (["graw", "scale"] if is_delta else ["enc", "dir", "dir_pt", "mask"])
+    reg = {k: int(out[i]) for i, k in enumerate(keys)}
+    reg["total"] = int(out[14])
+    return reg
+
+
+def _tile32(flat16, Pa, F, P):
+    """32-point feature-major tiles of 16-bit elements -> point-major [P, F] fp32"""
+    return flat16[:Pa * F].float().view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
+
+
+def saved_rows(buf, n_rays, n_samples, region, precision="fp32"):
+    """Debug / test view of one region of a save buffer as a point-major [P, F] fp32 tensor.  region: "h0".."h7", "hv", "enc", and
+    on the fp32 datapath "feat" (the split datapaths fold feature_linear into the view branch and never write it).  fp32 datapath:
+    point-major fp32 rows; split datapaths: 16-bit elements (fp16 / bf16 by `precision`), the 256- / 128-wide rows in 16-point tiles
+    with the row16h row order, the encoding in 32-point feature-major tiles (csrc/nerf_common.h)."""
+    split = precision in SPLIT
+    P = n_rays * n_samples
+    reg = buffer_regions(n_rays, n_samples, split)
+    F = 64 if region == "enc" else _REGIONS[region][1]
+    off = reg[region]
+    if not split:
+        return buf[off:off + P * F].view(P, F)
+    Pa = (P + 31) // 32 * 32
+    flat = buf[off:off + (Pa * F + 1) // 2].view(torch.bfloat16 if precision == "bf16x3" else torch.float16)
+    if region == "enc":
+        return _tile32(flat, Pa, F, P)
+    rows = flat[:Pa * F].float().view(Pa // 16, F, 16).permute(0, 2, 1).reshape(Pa, F)[:P]      # [P, row]
+    return rows[:, _row16h(torch.arange(F, device=rows.device))]                              # feature f sits at row16h(f)
+
+
+def saved_dir(buf, n_rays, n_samples, precision="fp32"):
+    """the per-ray direction encoding a saving forward wrote: [n_rays, 32] fp32 (27 used)"""
+    off = buffer_regions(n_rays, n_samples, precision in SPLIT)["dir"]
+    return buf[off:off + n_rays * 32].view(n_rays, 32)
+
+
+def saved_masks(buf, n_rays, n_samples, precision="fp32"):
+    """the ReLU bitmask words of a save buffer as int32 [9, P, 8] (layers 0..7 + view branch; 256 bits per point and layer, in the
+    lane order of the datapath's kernels: csrc/nerf_common.h)"""
+    P = n_rays * n_samples
+    off = buffer_regions(n_rays, n_samples, precision in SPLIT)["mask"]
+    return buf[off:off + 9 * P * 8].view(torch.int32).view(9, P, 8)
+
+
+def delta_rows(buf, n_rays, n_samples, region, precision="fp32"):
+    """Debug / test view of one region of a delta buffer as point-major [P, F] fp32: "h0".."h7", "hv", "feat" (fp32 datapath only),
+    "graw" (split datapaths: the tiled 4-wide copy of the scaled d_raw)."""
+    split = precision in SPLIT
+    P = n_rays * n_samples
+    reg = buffer_regions(n_rays, n_samples, split, is_delta=True)
+    F = 4 if region == "graw" else _REGIONS[region][1]
+    off = reg[region]
+    if not split:
+        return buf[off:off + P * F].view(P, F)
+    Pa = (P + 31) // 32 * 32
+    flat = buf[off:off + (Pa * F + 1) // 2].view(torch.bfloat16 if precision == "bf16x3" else torch.float16)
+    return _tile32(flat, Pa, F, P)
+
+
+def delta_scale_word(buf, n_rays, n_samples):
+    """fp16 split: the bit pattern of the launch's max|d_raw| the dgrad left in its delta buffer (int32 scalar tensor)"""
+    off = buffer_regions(n_rays, n_samples, True, is_delta=True)["scale"]
+    return buf[off:off + 1].view(torch.int32)
 
 
 # render_rays without gradients as ONE launch on the split datapaths (csrc/render_fused.hip; bit-identical to the

@@ -1,0 +1,201 @@
+"""Bit-stability of the kernels (-m gpu): SHA-256 digests of everything the field kernels, the per-ray kernels, the repack and the
+fused Adam write for fixed seeded inputs, compared with tests/golden/kernel_digests.json.
+
+Where the digests come from: they were recorded in round 5 from the library whose weight-ring kernels the round-4 suite had just
+proven bit-identical, word for word of every buffer, to the double-buffered kernels they replaced (tests
+`test_ring_forward_bit_identical` / `test_ring_dgrad_bit_identical` against the test-only libnerf_hip_ref.so, green in the same GPU
+run; that library and csrc/ref were deleted afterwards).  They are NOT parity evidence -- parity is the oracle / golden tests --
+they pin the arithmetic: a refactor of a kernel (register allocation, scratch layout, launch merging) must reproduce every
+digest, and a deliberate change of arithmetic must re-record them and say so in its commit.
+
+Digests are taken over LOGICAL views (hip_backend.saved_rows / delta_rows / saved_masks: point-major [P, F] tensors), so the
+physical layout of the scratch buffers may change without touching the fixture.
+
+    NERF_WRITE_DIGESTS=gpurun_out/kernel_digests.json python -m pytest tests/test_gpu_digests.py -m gpu    # re-record
+"""
+import hashlib
+import json
+import os
+
+import pytest
+import torch
+
+import nerf_oracle as orc
+import workloads as wl
+from test_gpu_parity import GOLD, dev, nets, npa  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+FIXTURE = os.path.join(GOLD, "kernel_digests.json")
+WRITE = os.environ.get("NERF_WRITE_DIGESTS")
+SHAPES = [(37, 5), (129, 64), (512, 192), (333, 77), (1, 1)]
+_RECORDED = {}
+
+
+def digest(t):
+    return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()[:20]
+
+
+def check(key, got):
+    """compare (or, under NERF_WRITE_DIGESTS, record) the digests of one case"""
+    if WRITE:
+        _RECORDED[key] = got
+        return
+    if not os.path.exists(FIXTURE):
+        pytest.fail(f"{FIXTURE} missing: record it with NERF_WRITE_DIGESTS=<path> on a GPU box")
+    want = json.load(open(FIXTURE)).get(key)
+    assert want is not None, f"no digests recorded for {key}"
+    diff = sorted(k for k in set(want) | set(got) if want.get(k) != got.get(k))
+    assert not diff, f"{key}: {len(diff)} of {len(want)} digests differ: {diff[:12]}"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_at_exit():
+    yield
+    if WRITE:
+        os.makedirs(os.path.dirname(os.path.abspath(WRITE)), exist_ok=True)
+        old = json.load(open(WRITE)) if os.path.exists(WRITE) else {}
+        old.update(_RECORDED)
+        json.dump(old, open(WRITE, "w"), indent=0, sort_keys=True)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3"])
+@pytest.mark.parametrize("n_rays,S", SHAPES)
+def test_field_kernels_are_bit_stable(npa, dev, nets, precision, n_rays, S):
+    """forward (inference == saving), every saved region, the delta chain's every region, the weight gradients"""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    g = torch.Generator().manual_seed(1000 * n_rays + S)
+    rays = orc.synthetic_rays(n_rays, seed=3).to(dev)
+    z = torch.sort(torch.rand(n_rays, S, generator=g) * 4 + 2, -1)[0].to(dev)
+    d_raw = (torch.randn(n_rays, S, 4, generator=g) * 1e-3).to(dev)
+    packed = nf.packed_params(precision)
+    raw_i, _ = hb.field_fwd(packed, rays, z, save_act=False, precision=precision)
+    raw, act = hb.field_fwd(packed, rays, z, save_act=True, precision=precision)
+    assert torch.equal(raw_i.view(torch.int32), raw.view(torch.int32))
+    got = {"raw": digest(raw)}
+    regions = [f"h{i}" for i in range(8)] + ["hv", "enc"] + (["feat"] if precision == "fp32" else [])
+    for r in regions:
+        rows = hb.saved_rows(act, n_rays, S, r, precision)
+        got["act." + r] = digest(rows[:, :63] if r == "enc" else rows)
+    got["act.dir"] = digest(hb.saved_dir(act, n_rays, S, precision)[:, :27])
+    got["act.mask"] = digest(hb.saved_masks(act, n_rays, S, precision))
+    # the delta chain and the weight gradients, through the binding's own sequence (hb.field_bwd) on a scratch we can look at
+    L = hb.lib()
+    delta = torch.zeros(L.nerf_delta_floats(n_rays, S), device=dev)
+    partial = torch.zeros(L.nerf_wgrad_partial_floats(n_rays, S), device=dev)
+    grad = torch.full((hb.N_PARAMS,), float("nan"), device=dev)
+    hb._field_bwd(L, packed, act, d_raw, grad, False, precision, delta, partial, n_rays, S, nf.flat_params())
+    for r in [f"h{i}" for i in range(8)] + ["hv"] + (["feat"] if precision == "fp32" else ["graw"]):
+        got["delta." + r] = digest(hb.delta_rows(delta, n_rays, S, r, precision))
+    if precision == "fp16x3":
+        got["delta.scale"] = digest(hb.delta_scale_word(delta, n_rays, S))
+    got["grad"] = digest(grad)
+    grad2 = grad.clone()
+    hb._field_bwd(L, packed, act, d_raw, grad2, True, precision, delta, partial, n_rays, S, nf.flat_params())
+    got["grad.accumulated"] = digest(grad2)
+    hb.WORKSPACE.give(act)
+    check(f"field[{precision},{n_rays}x{S}]", got)
+
+
+@pytest.mark.parametrize("n_rays,S", SHAPES)
+def test_reduced_forward_is_bit_stable(npa, dev, nets, n_rays, S):
+    """the reduced inference class: fp16 main term + fp8 correction terms, last samples on the three-term products"""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    g = torch.Generator().manual_seed(1000 * n_rays + S)
+    rays = orc.synthetic_rays(n_rays, seed=3).to(dev)
+    z = torch.sort(torch.rand(n_rays, S, generator=g) * 4 + 2, -1)[0].to(dev)
+    raw, _ = hb.field_fwd(nf.packed_params("fp16_fp8c"), rays, z, precision="fp16_fp8c", guard_packed=nf.packed_params("fp16x3"))
+    check(f"reduced[{n_rays}x{S}]", {"raw": digest(raw)})
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3", "fp16_fp8c"])
+@pytest.mark.parametrize("case", ["lego", "fern_noise_lindisp", "coarse_only"])
+def test_render_rays_is_bit_stable(npa, dev, nets, precision, case):
+    """render_rays end to end with injected draws: every output of the no-grad path (one launch on the split datapaths) and of the
+    training path, both networks' gradients, the parameters after one fused Adam step and their repack"""
+    nc0, nf0, Pc, Pf = nets
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    nc, nf = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
+    nc.load_state_dict(Pc)
+    nf.load_state_dict(Pf)
+    n = 257
+    g = torch.Generator().manual_seed(77)
+    rays = orc.synthetic_rays(n, seed=11).to(dev)
+    n_f = 0 if case == "coarse_only" else 128
+    noisy = case == "fern_noise_lindisp"
+    rnd = {"t_rand": torch.rand(n, 64, generator=g), "u": torch.rand(n, 128, generator=g),
+           "noise_c": torch.randn(n, 64, generator=g), "noise_f": torch.randn(n, 192, generator=g)}
+    target = torch.rand(n, 3, generator=g).to(dev)
+    kwargs = dict(N_samples=64, N_importance=n_f, network_fine=nf if n_f else None, perturb=1.0, retraw=True, white_bkgd=not noisy,
+                  raw_noise_std=1.0 if noisy else 0.0, lindisp=noisy, randoms=rnd)
+    prev = npa.get_precision()
+    npa.set_precision(precision)
+    try:
+        got = {}
+        with torch.no_grad():
+            out = npa.render_rays(rays, nc, None, **kwargs)
+        for k, v in out.items():
+            got["infer." + k] = digest(v)
+        out = npa.render_rays(rays, nc, None, **kwargs)
+        for k, v in out.items():
+            got["train." + k] = digest(v)
+        loss = npa.img2mse(out["rgb_map"], target) + (npa.img2mse(out["rgb0"], target) if n_f else 0.0)
+        got["loss"] = digest(loss)
+        opt = npa.FlatAdam(list(nc.parameters()) + (list(nf.parameters()) if n_f else []), lr=5e-4)
+        opt.zero_grad()
+        loss.backward()
+        got["grad_c"] = digest(nc.last_flat_grad)
+        if n_f:
+            got["grad_f"] = digest(nf.last_flat_grad)
+        opt.step()
+        got["params_c"] = digest(nc.flat_params())
+        train_prec = "fp16x3" if precision == "fp16_fp8c" else precision
+        got["packed_c"] = digest(nc.packed_params(train_prec))
+        if precision == "fp16_fp8c":
+            got["packed_c.reduced"] = digest(nc.packed_params("fp16_fp8c"))
+    finally:
+        npa.set_precision(prev)
+    check(f"render_rays[{precision},{case}]", got)
+
+
+def test_ray_kernels_are_bit_stable(npa, dev):
+    """ray records (pinhole + NDC), coarse depths, hierarchical sampling + sort, compositing and its adjoint, the loss"""
+    hb = npa.hip_backend
+    g = torch.Generator().manual_seed(5)
+    n, Sc, Sf = 333, 64, 128
+    K = [[407.5, 0, 252.0], [0, 407.5, 189.0], [0, 0, 1]]
+    pose = torch.as_tensor(wl.pose_spherical(30.0, -30.0, 4.0)[:3, :4], dtype=torch.float32)
+    got = {}
+    for ndc in (False, True):
+        rays = hb.make_rays(20, 30, K, pose, None, ndc, 0.0 if ndc else 2.0, 1.0 if ndc else 6.0, dev)
+        got[f"make_rays.ndc{int(ndc)}"] = digest(rays)
+    ro, rd = torch.randn(n, 3, generator=g).to(dev), torch.randn(n, 3, generator=g).to(dev)
+    rays = hb.assemble_rays(ro, rd, False, 400, 400, 555.5, 2.0, 6.0)
+    got["assemble_rays"] = digest(rays)
+    t_rand = torch.rand(n, Sc, generator=g).to(dev)
+    for lindisp in (False, True):
+        z = hb.sample_coarse(rays, torch.linspace(0, 1, Sc, device=dev), lindisp, t_rand)
+        got[f"sample_coarse.lindisp{int(lindisp)}"] = digest(z)
+    raw = (torch.randn(n, Sc, 4, generator=g) * 3).to(dev)
+    noise = torch.randn(n, Sc, generator=g).to(dev)
+    rgb, disp, acc, w, depth = hb.raw2outputs(raw, z, rays, 11, noise, 0.5, True, rays_d_offset=3)
+    for k, v in (("rgb", rgb), ("disp", disp), ("acc", acc), ("weights", w), ("depth", depth)):
+        got["raw2outputs." + k] = digest(v)
+    d_raw = hb.raw2outputs_bwd(raw, z, rays, 11, noise, 0.5, True, torch.randn(n, 3, generator=g).to(dev), torch.randn(n, generator=g).to(dev),
+                               torch.randn(n, generator=g).to(dev), rays_d_offset=3)
+    got["raw2outputs_bwd"] = digest(d_raw)
+    for det in (False, True):
+        u = None if det else torch.rand(n, Sf, generator=g).to(dev)
+        z_all, z_std, z_s = hb.sample_fine(z, w, Sf, u, torch.linspace(0, 1, Sf, device=dev) if det else None, want_samples=True)
+        got[f"sample_fine.det{int(det)}.z"] = digest(z_all)
+        got[f"sample_fine.det{int(det)}.z_std"] = digest(z_std)
+        got[f"sample_fine.det{int(det)}.samples"] = digest(z_s)
+    x = torch.randn(n, 3, generator=g).to(dev).requires_grad_(True)
+    loss = npa.img2mse(x, rgb)
+    loss.backward()
+    got["img2mse"] = digest(loss)
+    got["img2mse.grad"] = digest(x.grad)
+    got["embed10"] = digest(hb.embed(ro, 10))
+    check("ray_kernels", got)

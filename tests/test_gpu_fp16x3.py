@@ -71,12 +71,12 @@ def test_field_forward_fp16x3(npa, dev, nets, n_rays, S):
     feats = torch.cat([orc.posenc(pts.reshape(-1, 3).double(), 10), orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3).double(), 4)], -1)
     _, hidden, _, hv = orc.field_mlp(P64, feats, return_hidden=True)
     for l in (0, 3, 7):
-        got = hb.saved_rows(act, P, f"h{l}", precision="fp16x3").cpu().double()
+        got = hb.saved_rows(act, n_rays, S, f"h{l}", precision="fp16x3").cpu().double()
         tol = 2.0 ** -11 * float(hidden[l].abs().max()) + 2e-5
         assert maxdiff(got, hidden[l]) <= tol, (l, maxdiff(got, hidden[l]), tol)
-    got = hb.saved_rows(act, P, "hv", precision="fp16x3").cpu().double()
+    got = hb.saved_rows(act, n_rays, S, "hv", precision="fp16x3").cpu().double()
     assert maxdiff(got, hv) <= 2.0 ** -11 * float(hv.abs().max()) + 2e-5
-    got = hb.saved_rows(act, P, "enc", precision="fp16x3").cpu().double()[:, :63]
+    got = hb.saved_rows(act, n_rays, S, "enc", precision="fp16x3").cpu().double()[:, :63]
     assert maxdiff(got, feats[:, :63]) <= 2.0 ** -11 * float(feats[:, :63].abs().max()) + 1e-6
     hb.WORKSPACE.give(act)
 

@@ -712,7 +712,7 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     P = n_rays * S
     feats = torch.cat([orc.posenc(pts.reshape(-1, 3), 10), orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3), 4)], -1)
     _, hidden, feat, hv = orc.field_mlp(Pf, feats, return_hidden=True)
-    rows = lambda region: npa.hip_backend.saved_rows(act, P, region, "bf16x3").cpu()
+    rows = lambda region: npa.hip_backend.saved_rows(act, n_rays, S, region, "bf16x3").cpu()
     bf = 2.0 ** -8                              # bf16 rounding of the saved values
     for l in range(8):
         assert maxdiff(rows(f"h{l}"), hidden[l]) <= (bf + 3e-4) * max(1.0, float(hidden[l].abs().max())), l
@@ -721,11 +721,9 @@ def test_field_forward_bf16x3(npa, dev, nets, n_rays, S):
     assert maxdiff(rows("enc")[:, :63], feats[:, :63]) <= bf * float(feats[:, :63].abs().max()) + 5e-6
     # the ReLU bitmasks the backward reads must be exactly the signs of the rows saved next to them: word (layer, p,
     # half), bit i <-> feature 32*(i>>4) + d32row(i&15, half) (csrc/nerf_common.h)
-    Pp = (P + 31) // 32 * 32
-    mask_off = (Pp * (9 * 256 + 128 + 64) + n_rays * 32 + Pp * 32 + 3) // 4 * 4
     i = torch.arange(128)
     feat_of = lambda half: 32 * (i >> 4) + ((i & 15) & 3) + 8 * ((i & 15) >> 2) + 4 * half
-    words = act.cpu()[mask_off:mask_off + 9 * P * 8].view(torch.int32).view(9, P, 2, 4)
+    words = npa.hip_backend.saved_masks(act, n_rays, S, "bf16x3").cpu().view(9, P, 2, 4)
     for layer, region, width in [(l, f"h{l}", 256) for l in range(8)] + [(8, "hv", 128)]:
         pos = rows(region) > 0
         for half in range(2):

@@ -118,12 +118,10 @@ def test_ring_dgrad_bit_identical(npa, dev, nets, n_rays, S):
 
 
 # ---------------------------------------------------------------- split-bf16 backward: arithmetic error vs kink flips
-def _decode_masks(npa, act, P, n_rays):
+def _decode_masks(npa, act, P, n_rays, precision="bf16x3"):
     """ReLU bitmasks of a split-bf16 save buffer as 9 boolean tensors [P, width] (layers 0..7: 256, view branch: 128);
     word (layer, p, half), bit i <-> feature 32*(i>>4) + d32row(i&15, half) (csrc/nerf_common.h)"""
-    Pp = (P + 31) // 32 * 32
-    mask_off = (Pp * (9 * 256 + 128 + 64) + n_rays * 32 + Pp * 32 + 3) // 4 * 4
-    words = act[mask_off:mask_off + 9 * P * 8].view(torch.int32).view(9, P, 2, 4).cpu()
+    words = npa.hip_backend.saved_masks(act, n_rays, P // n_rays, precision).view(9, P, 2, 4).cpu()
     i = torch.arange(128)
     out = []
     for layer in range(9):

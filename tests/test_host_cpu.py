@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/nerf_hip.h but not exported"
     assert declared == set(npa.hip_backend.EXPORTS), declared ^ set(npa.hip_backend.EXPORTS)
     L = npa.hip_backend.lib()
-    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 7 and L.nerf_param_count() == 595844
+    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 8 and L.nerf_param_count() == 595844
     assert L.nerf_packed_floats() % 4 == 0
 
 
@@ -257,35 +257,46 @@ def test_precision_selection_and_saved_row_views():
                 npa.set_precision(bad)
     finally:
         npa.set_precision(prev)
-    P, Pp = 70, 96
-    widths = [("h%d" % i, 256) for i in range(8)] + [("feat", 256), ("hv", 128), ("enc", 64)]
-    total = sum(Pp * F for _, F in widths)
-    flat = torch.arange(P * 2688, dtype=torch.float32)
-    assert torch.equal(npa.hip_backend.saved_rows(flat, P, "h1", "fp32"), flat[P * 256:2 * P * 256].view(P, 256))
+    hb = npa.hip_backend
+    n_rays, S, P = 10, 7, 70
+    reg = hb.buffer_regions(n_rays, S, False)
+    flat = torch.arange(reg["total"], dtype=torch.float32)
+    assert torch.equal(hb.saved_rows(flat, n_rays, S, "h1", "fp32"), flat[reg["h1"]:reg["h1"] + P * 256].view(P, 256))
+    widths = [("h%d" % i, 256) for i in range(8)] + [("hv", 128), ("enc", 64)]
     for precision, dt in (("bf16x3", torch.bfloat16), ("fp16x3", torch.float16)):
+        reg, dreg = hb.buffer_regions(n_rays, S, True), hb.buffer_regions(n_rays, S, True, is_delta=True)
+        assert all(reg[k] % 4 == 0 and dreg.get(k, 0) % 4 == 0 for k in reg)           # 16-byte aligned regions
         want = {name: torch.randn(P, F).to(dt).float() for name, F in widths}
-        # 32-point feature-major tiles of 2-byte elements (deltas, encodings), same float offsets as fp32 regions
-        buf16 = torch.zeros(total).view(dt)
-        # rows saved by the forward: 16-point tiles, row16h row order (one paired store instruction = 8 consecutive rows = two full
-        # lines); the 64-wide encoding stays in 32-point tiles
-        bufh = torch.zeros(total).view(dt)
-        off = 0
-        for name, F in widths:
+        wantd = {name: torch.randn(P, F).to(dt).float() for name, F in widths + [("graw", 4)] if name != "enc"}
+        act, delta = torch.zeros(reg["total"]), torch.zeros(dreg["total"])
+        a16, d16 = act.view(dt), delta.view(dt)
+        for name, F in widths + [("graw", 4)]:
             p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
-            buf16[2 * off + (p // 32) * F * 32 + f * 32 + p % 32] = want[name].to(dt)
+            tile32 = (p // 32) * F * 32 + f * 32 + p % 32                              # 32-point feature-major tiles
             rowh = (f // 16) * 16 + 8 * ((f >> 1) & 1) + 2 * ((f >> 2) & 3) + (f & 1)     # feature 4q + r at row 8*(r>>1) + 2q + (r&1)
-            idx = (p // 16) * F * 16 + rowh * 16 + p % 16 if F in (256, 128) else (p // 32) * F * 32 + f * 32 + p % 32
-            bufh[2 * off + idx] = want[name].to(dt)
-            off += Pp * F
+            if name != "graw":
+                # rows saved by the forward: 16-point tiles, row16h row order (one paired store instruction = 8 consecutive rows = two
+                # full lines); the 64-wide encoding stays in 32-point tiles
+                a16[2 * reg[name] + ((p // 16) * F * 16 + rowh * 16 + p % 16 if F in (256, 128) else tile32)] = want[name].to(dt)
+            if name != "enc":
+                d16[2 * dreg[name] + tile32] = wantd[name].to(dt)
         for name, F in widths:
-            assert torch.equal(npa.hip_backend.saved_rows(buf16.view(torch.float32), P, name, precision, tile16=False), want[name]), name
-            assert torch.equal(npa.hip_backend.saved_rows(bufh.view(torch.float32), P, name, precision, tile16=True), want[name]), name
+            assert torch.equal(hb.saved_rows(act, n_rays, S, name, precision), want[name]), name
+        for name in wantd:
+            assert torch.equal(hb.delta_rows(delta, n_rays, S, name, precision), wantd[name]), name
+        # regions do not overlap: every region ends before the next one starts (16-bit elements over P rounded up to a tile)
+        Pa = (P + 31) // 32 * 32
+        order = sorted((reg[k], k) for k in reg if k not in ("total", "feat"))
+        sizes = {**{n_: Pa * F // 2 for n_, F in widths}, "dir": n_rays * 32, "mask": 9 * P * 8}
+        for (o0, k0), (o1, _k1) in zip(order, order[1:]):
+            assert o0 + sizes.get(k0, 0) <= o1, (k0, o0, o1)
+        assert order[-1][0] + sizes.get(order[-1][1], 0) <= reg["total"]
     # one store instruction of that kernel (j fixed, q = 0..3) covers rows {2j, 2j+1} and {8+2j, 8+2j+1}: two full lines
-    r16 = npa.hip_backend._row16
-    for j in range(4):
-        rows = sorted(r16(4 * q + j) for q in range(4))
-        assert rows == [2 * j, 2 * j + 1, 8 + 2 * j, 9 + 2 * j]
-    assert sorted(r16(f) for f in range(256)) == list(range(256))
+    r16h = npa.hip_backend._row16h
+    for r0 in (0, 2):
+        rows = sorted(r16h(4 * q + r) for q in range(4) for r in (r0, r0 + 1))
+        assert rows == list(range(4 * r0, 4 * r0 + 8))
+    assert sorted(r16h(f) for f in range(256)) == list(range(256))
 
 
 def test_flat_adam_rejects_options_the_fused_kernel_ignores():

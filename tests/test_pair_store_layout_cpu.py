@@ -53,13 +53,12 @@ def test_fwd16_paired_rows_fill_a_16_point_tile_in_row16h_order():
     assert torch.equal(got[row16h].T, want)
     # and the host-side view of a whole region made of such tiles
     P = 48
-    region = torch.zeros(((P + 31) // 32 * 32) * F // 2)                                    # floats holding 2-byte elements
+    reg = npa.hip_backend.buffer_regions(P, 1, True)
+    full = torch.zeros(reg["total"])                                                        # floats holding 2-byte elements
     vals = torch.randn(P, F).bfloat16()
-    buf16 = region.view(torch.bfloat16)
     p, f = torch.meshgrid(torch.arange(P), torch.arange(F), indexing="ij")
-    buf16[(p // 16) * F * 16 + npa.hip_backend._row16h(f) * 16 + p % 16] = vals
-    full = torch.cat([region, torch.zeros(1)])                                              # h0 is the first region of the layout
-    assert torch.equal(npa.hip_backend.saved_rows(full, P, "h0", "bf16x3", tile16=True, bf16=True), vals.float())
+    full.view(torch.bfloat16)[2 * reg["h3"] + (p // 16) * F * 16 + npa.hip_backend._row16h(f) * 16 + p % 16] = vals
+    assert torch.equal(npa.hip_backend.saved_rows(full, P, 1, "h3", "bf16x3"), vals.float())
 
 
 def test_dgrad_paired_deltas_fill_a_32_point_tile():
