@@ -360,6 +360,8 @@ int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride
     REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
     REQUIRE(n_rays >= 0 && n_samples >= 1 && split >= 0 && split <= 3, "bad size");
     REQUIRE(split < 2 || !act, "split = 2 / 3 (fp16 main term + fp8 corrections) is an inference form: act must be NULL");
+    REQUIRE((long)n_rays * n_samples <= nerf::FWD16R_MAX_POINTS && (!act || (long)n_rays * n_samples <= nerf::FWD16R_MAX_SAVED_POINTS),
+            "too many points for one launch (2^31 - 1; 2^26 when saving): split the ray batch");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
     if (act) tag_record(act, 0, split ? ACT_TILE16_F16 : ACT_TILE16_BF16, n_rays, n_samples);

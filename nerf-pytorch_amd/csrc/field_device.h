@@ -14,6 +14,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <typename T>
 __device__ inline void nt_store(T* ptr, T v) { __builtin_nontemporal_store(v, ptr); }
 
+// The same store with the address given as (wave-uniform 64-bit base in scalar registers) + (32-bit byte offset of the lane):
+// written as asm because the compiler, given the sum, hoists `base + lane offset` into a 64-bit VGPR pair per base.
+__device__ __forceinline__ void nt_store_saddr(const void* uniform_base, unsigned lane_bytes, unsigned v) {
+    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(lane_bytes), "v"(v), "s"(uniform_base) : "memory");
+}
+
+typedef unsigned u32x4_st __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store_saddr(const void* uniform_base, unsigned lane_bytes, u32x4_st v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_bytes), "v"(v), "s"(uniform_base) : "memory");
+}
+
 #define NERF_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define NERF_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 

@@ -36,6 +36,8 @@ hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_
     FieldFwdRingArgs a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S, S, 0, S, 0, split == 3 ? 1 : 0};
     const long P = (long)n_rays * S;
     if (P <= 0) return hipSuccess;
+    // the kernel's point arithmetic is 32-bit, and a saving launch addresses its rows with 32-bit lane offsets (field_fwd_ring_body.h)
+    if (P > FWD16R_MAX_POINTS || (act && P > FWD16R_MAX_SAVED_POINTS)) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((P + PTS_PER_WG - 1) / PTS_PER_WG);
     if (split >= 2) return act ? hipErrorInvalidValue : launch_one<0, SplitF16, true>(a, blocks, stream);
     if (split) return act ? launch_one<2, SplitF16>(a, blocks, stream) : launch_one<0, SplitF16>(a, blocks, stream);

@@ -46,54 +46,57 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4;
-    const long P = (long)a.n_rays * a.S;
-    const long p_raw = (wg * FIELD_WAVES + wave) * PTS_PER_WAVE + (lane & 15);
+    // point indices are 32-bit (the launchers refuse n_rays * S >= 2^31): the wave's 16-point tile number is wave-uniform (SGPR),
+    // a lane adds its point, and ray / sample follow from ONE 32-bit division
+    const unsigned P = (unsigned)a.n_rays * (unsigned)a.S;
+    const unsigned tile16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wg * FIELD_WAVES + wave));
+    const unsigned p_raw = tile16 * PTS_PER_WAVE + (unsigned)(lane & 15);
     const bool valid = p_raw < P;
-    const long p = valid ? p_raw : P - 1;
-    const int ray = (int)(p / a.S);
+    const unsigned p = valid ? p_raw : P - 1u;
+    const unsigned ray = p / (unsigned)a.S;
+    const unsigned si = p - ray * (unsigned)a.S;
 
     WeightRing ring;
     ring.start(a.packed3 + P16F, lds, wave, lane, FWD16_UNITS_TRUNK, FWD16_UNITS_SKIP, FWD16_UNITS);
     stage_small_ring(a.packed3 + P3_SMALL, lds, FIELD_WAVES * 64);
 
-    const float* rp = a.rays + (long)ray * a.ray_stride;
-    const long si = p - (long)ray * a.S;
-    const long zi = (long)ray * a.z_stride + a.s_off + si;
-    const long ri = (long)ray * a.raw_stride + a.raw_off + si;
+    const float* rp = a.rays + (size_t)ray * (size_t)a.ray_stride;
+    const size_t zi = (size_t)ray * (size_t)a.z_stride + (size_t)(a.s_off + (int)si);
     const float z = a.z_vals[zi];
     const float x0 = rp[0] + rp[3] * z;
     const float x1 = rp[1] + rp[4] * z;
     const float x2 = rp[2] + rp[5] * z;
-    const float vd0 = rp[8], vd1 = rp[9], vd2 = rp[10];
     float e[16];
     encode_xyz(e, x0, x1, x2, q);
 
-    // ---- saving (layouts: nerf_common.h)
+    // ---- saving (layouts: nerf_common.h).  Every store address is a WAVE-UNIFORM 64-bit base (region, tile: scalar registers)
+    // plus a 32-bit byte offset of the lane that does not change along the trunk -- no per-lane 64-bit pointers are carried
+    // (the launchers refuse to save more than 2^26 points per launch, so the lane offsets fit 32 bits).
     ActLayout3 al{};
-    const size_t tile = (size_t)(p_raw >> 5);
-    const int pp = (int)(p_raw & 31);
     const size_t layer_floats = pad32((size_t)P) * W;
-    const unsigned tile16 = (unsigned)__builtin_amdgcn_readfirstlane((int)((wg * FIELD_WAVES + wave)));
     const unsigned odd = (unsigned)lane & 1u;
     const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;      // v_perm_b32 bytes of {neighbour word, own word}
-    const unsigned lane_pair_off = (unsigned)((2 * q + (int)odd) * 8 + ((lane & 15) >> 1));
+    const unsigned lane_pair_bytes = 4u * (unsigned)((2 * q + (int)odd) * 8 + ((lane & 15) >> 1));
     const bool tile_ok = (size_t)tile16 * 16 < pad32((size_t)P);
+    char* const act_bytes = reinterpret_cast<char*>(a.act);
     // rows (r0, r0 + 1) of block nb of this lane's point, paired with the neighbour point: one dword store (unconditional;
     // a wave whose tile lies beyond the padded range writes to the unused `feat` region)
     auto store_word = [&](size_t region, int F, int nb, int r0, unsigned own) __attribute__((always_inline)) {
         const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
         const unsigned word = __builtin_amdgcn_perm(nbr, own, pair_sel);
-        unsigned* tile_base = reinterpret_cast<unsigned*>(a.act + (tile_ok ? region : al.feat))
-                              + (tile_ok ? (size_t)tile16 * (size_t)(F * 8) : (size_t)0);
-        nt_store(tile_base + (16 * nb + 4 * r0) * 8 + lane_pair_off, word);
+        char* tile_base = act_bytes + 4 * (tile_ok ? region : al.feat) + (tile_ok ? (size_t)tile16 * (size_t)(F * 32) : (size_t)0)
+                          + (size_t)((16 * nb + 4 * r0) * 32);
+        nt_store_saddr(tile_base, lane_pair_bytes, word);
     };
     if (SAVE) {
         al = act_layout3((size_t)P, (size_t)a.n_rays);
         if (valid) {
+            char* enc_tile = act_bytes + 4 * al.enc + (size_t)(tile16 >> 1) * (size_t)(64 * 32 * 2);     // the wave's 32-point tile (uniform)
+            const unsigned pp2 = 2u * (p_raw & 31u);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int col = encslot(s, q);
-                if (col >= 0) nt_store(reinterpret_cast<unsigned short*>(a.act + al.enc) + tile * (size_t)(64 * 32) + (size_t)col * 32 + pp, SP::cvt1(e[s]));
+                if (col >= 0) nt_store(reinterpret_cast<unsigned short*>(enc_tile + ((unsigned)col * 64u + pp2)), SP::cvt1(e[s]));
             }
         }
     }
@@ -120,12 +123,14 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     // ... and so do the bits of their ReLU mask: two compares per unit in the shadow of its MFMAs instead of 64 at the layer's
     // end, where neither wave of the SIMD has an MFMA in flight (mw: the four mask words of the layer in h[], without the
     // lane-dependent shift)
-    unsigned mw[4] = {0u, 0u, 0u, 0u};
+    // Two registers hold the four words: word i sits in mw[i & 1] shifted left by 4 (i >> 1) -- a word uses only the low nibble of
+    // each byte before the lane-dependent shift.
+    unsigned mw[2] = {0u, 0u};
     auto mask_bits = [&](auto nbc, auto rc) __attribute__((always_inline)) {
         constexpr int nb = decltype(nbc)::value, r = decltype(rc)::value;
-        unsigned b = h[4 * nb + r] > 0.0f ? 1u << (8 * (nb & 3) + r) : 0u;
+        unsigned b = h[4 * nb + r] > 0.0f ? 1u << (8 * (nb & 3) + r + 4 * (nb >> 3)) : 0u;
         asm volatile("" : "+v"(b));
-        mw[nb >> 2] |= b;
+        mw[(nb >> 2) & 1] |= b;
     };
     auto store_rows = [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
         if (!SAVE) return;
@@ -137,15 +142,17 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     };
     auto finish_mask = [&](int layer) __attribute__((always_inline)) {     // the words save_mask16 builds, bit for bit
         if (!SAVE) return;
+        unsigned w4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            mw[i] <<= 4 * (q >> 1);
-            mw[i] |= __shfl_xor(mw[i], 32);
+            w4[i] = ((mw[i & 1] >> (4 * (i >> 1))) & 0x0f0f0f0fu) << (4 * (q >> 1));
+            w4[i] |= __shfl_xor(w4[i], 32);
         }
-        if (valid && q < 2)
-            nt_store(reinterpret_cast<u32x4*>(a.act + al.mask) + ((size_t)layer * P + p) * 2 + q, u32x4{mw[0], mw[1], mw[2], mw[3]});
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mw[i] = 0u;
+        if (valid && q < 2) {
+            char* layer_base = act_bytes + 4 * al.mask + (size_t)layer * (size_t)P * 32;        // uniform
+            nt_store_saddr(layer_base, p * 32u + (unsigned)q * 16u, u32x4{w4[0], w4[1], w4[2], w4[3]});
+        }
+        mw[0] = mw[1] = 0u;
     };
 
     ring.ready();
@@ -172,10 +179,17 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
         finish_mask(l - 1);
         take();
     }
+    // What is needed from here on is re-derived from the point and ray NUMBERS (two registers carried through the trunk) and from the
+    // hardware's lane number, behind an opaque copy -- otherwise the view direction, the sample index, the output address and a
+    // dozen lane-derived selections of the prologue stay live (or spill) along the trunk.
+    unsigned ray_l = ray, p_l = p;
+    int q_l = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 4);
+    asm volatile("" : "+v"(ray_l), "+v"(p_l), "+v"(q_l));
+    const unsigned si_l = p_l - ray_l * (unsigned)a.S;
     // ---- density head: alpha_linear 256 -> 1 (VALU dot + quarter reduction)
     float sigma = 0.0f;
     {
-        const float* wa = ring_small_ptr(lds, SM_WALPHA) + 4 * q;
+        const float* wa = ring_small_ptr(lds, SM_WALPHA) + 4 * q_l;
 #pragma unroll
         for (int nb = 0; nb < 16; ++nb) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(wa + 16 * nb);
@@ -187,22 +201,23 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     // ---- view branch on the trunk output (feature_linear folded: W', b'): [h7, enc(dir)] -> 128, ReLU
     float dv[8];
     {
+        const float* rp_l = a.rays + (size_t)ray_l * (size_t)a.ray_stride;
         float v7[7];
-        encode_dir(v7, vd0, vd1, vd2, q);
+        encode_dir(v7, rp_l[8], rp_l[9], rp_l[10], q_l);
 #pragma unroll
         for (int i = 0; i < 7; ++i) dv[i] = v7[i];
         dv[7] = 0.0f;
     }
-    if (SAVE && valid && si == 0) {
-        float* dout = a.act + al.dir + (size_t)ray * 32;
+    if (SAVE && valid && si_l == 0) {
+        float* dout = a.act + al.dir + (size_t)ray_l * 32;
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
-            const int col = dirslot(s, q);
+            const int col = dirslot(s, q_l);
             if (col >= 0) nt_store(dout + col, dv[s]);
         }
     }
     f32x4 av[8];
-    load_bias<8>(av, ring_small_ptr(lds, SM_BVIEWS), q);
+    load_bias<8>(av, ring_small_ptr(lds, SM_BVIEWS), q_l);
     {   // layer 7's rows leave under the 16 units of the trunk part: k-step kk = blocks 2 kk, 2 kk + 1, half of them per unit
         row_region = (size_t)(D - 1) * layer_floats;
         auto store_rows_v = [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
@@ -231,16 +246,18 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[nb >> 2] |= (hv[4 * nb + r] > 0.0f ? 1u : 0u) << (8 * (nb & 3) + 4 * (q >> 1) + r);
+            for (int r = 0; r < 4; ++r) w[nb >> 2] |= (hv[4 * nb + r] > 0.0f ? 1u : 0u) << (8 * (nb & 3) + 4 * (q_l >> 1) + r);
 #pragma unroll
         for (int i = 0; i < 2; ++i) w[i] |= __shfl_xor(w[i], 32);
-        if (valid && q < 2)
-            nt_store(reinterpret_cast<u32x4*>(a.act + al.mask) + ((size_t)D * P + p) * 2 + q, u32x4{w[0], w[1], w[2], w[3]});
+        if (valid && q_l < 2) {
+            char* layer_base = act_bytes + 4 * al.mask + (size_t)D * (size_t)P * 32;
+            nt_store_saddr(layer_base, p_l * 32u + (unsigned)q_l * 16u, u32x4{w[0], w[1], w[2], w[3]});
+        }
     }
     // ---- rgb_linear 128 -> 3
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     {
-        const float* wr = ring_small_ptr(lds, SM_WRGB) + 4 * q;
+        const float* wr = ring_small_ptr(lds, SM_WRGB) + 4 * q_l;
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + 16 * nb);
@@ -257,7 +274,10 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
         c1 = quarter_sum(c1) + ring_small_ptr(lds, SM_BRGB)[1];
         c2 = quarter_sum(c2) + ring_small_ptr(lds, SM_BRGB)[2];
     }
-    if (valid && q == 0 && !(a.skip_last && si == a.S - 1)) *reinterpret_cast<f32x4*>(a.raw + (size_t)ri * 4) = f32x4{c0, c1, c2, sigma};
+    if (valid && q_l == 0 && !(a.skip_last && (int)si_l == a.S - 1)) {
+        const size_t ri = (size_t)ray_l * (size_t)a.raw_stride + (size_t)(a.raw_off + (int)si_l);
+        *reinterpret_cast<f32x4*>(a.raw + ri * 4) = f32x4{c0, c1, c2, sigma};
+    }
 }
 
 }  // namespace nerf

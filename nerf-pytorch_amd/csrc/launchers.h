@@ -85,6 +85,8 @@ void pack_table_host(int* out);
 void pack3_table_host(int* out);
 void pack16_table_host(int* out);
 hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream, int split = 0);
+// largest launches of the 16-point forward: n_rays * S points in all, and with saving (4.8 KB per point: 2^26 points = 320 GB)
+constexpr long FWD16R_MAX_POINTS = (1L << 31) - 1, FWD16R_MAX_SAVED_POINTS = 1L << 26;
 // split (ring kernels, repack, streaming weight-gradient GEMM): 0 = bf16 three-term split, 1 = fp16 (csrc/split_types.h)
 hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                                int n_rays, int S, float* raw, float* act, int split, hipStream_t stream);

@@ -97,7 +97,8 @@ def lib():
     """Load (once) and return the shared library.  Raises if it has not been built."""
     global _LIB
     if _LIB is None:
-        path = _build.LIB_PATH
+        # (NERF_HIP_LIB: another build of the same ABI -- kernel A/B timing on one box, tools/time_kernels.py)
+        path = os.environ.get("NERF_HIP_LIB") or _build.LIB_PATH
         if not os.path.exists(path):
             raise NerfHipError(
                 f"{path} not found: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
