@@ -76,6 +76,19 @@ int nerf_make_rays(int H, int W, const float* K_host, const float* c2w_host, con
 int nerf_assemble_rays(const float* rays_o, const float* rays_d, long n_rays, int ndc, int H, int W, float focal, float near,
                        float far, float* rays, int ray_stride, void* stream);
 
+/* ---- the ray batch of one train() step in the reference's 'no_batching' mode (run_nerf.py:726-757): n_rand DISTINCT pixels of one
+ * image -- of the window (h0, w0, nh, nw): the central crop of the first precrop_iters steps (:738-747), or the whole image --, their
+ * rays as get_rays gives them (run_nerf_helpers.py:153-162) and their colours:
+ *   batch_rays[2][n_rand][3] = (rays_o, rays_d), target[n_rand][3] = image[j][i], pixels[n_rand] = j * W + i (nullable).
+ * The reference builds the [H,W,3] ray grid and a meshgrid and draws np.random.choice(H*W, N_rand, replace=False) on the host every
+ * step; here pixel k of the batch is perm(k), a keyed bijection of [0, nh*nw) (6-round Feistel network, cycle-walked): distinct by
+ * construction, and WHICH subset is decided by (key0, key1), two words the host draws per step from its own generator -- no O(H*W)
+ * work, no device synchronisation.  K_host: HOST 3x3 intrinsics; pose: DEVICE c2w[:3,:4], rows pose_row_stride floats apart (a
+ * slice of a [N,4,4] pose table stays where it is); image: DEVICE [H][W][3] fp32. */
+int nerf_sample_ray_batch(int H, int W, const float* K_host, const float* pose, int pose_row_stride, const float* image, int h0,
+                          int w0, int nh, int nw, int n_rand, unsigned key0, unsigned key1, float* batch_rays, float* target,
+                          int* pixels /* nullable */, void* stream);
+
 /* ---- network_query_fn(pts, viewdirs, network_fn) with pts = o + d*z
  * (run_nerf.py:381,385 -> run_network :37-51 -> Embedder :44-45 -> NeRF.forward helpers:96-119).
  * raw[n_rays][n_samples][4] = (rgb pre-sigmoid, sigma pre-relu).

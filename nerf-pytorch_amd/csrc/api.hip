@@ -128,6 +128,19 @@ int nerf_assemble_rays(const float* rays_o, const float* rays_d, long n_rays, in
                                                      (hipStream_t)stream));
 }
 
+int nerf_sample_ray_batch(int H, int W, const float* K_host, const float* pose, int pose_row_stride, const float* image, int h0,
+                          int w0, int nh, int nw, int n_rand, unsigned key0, unsigned key1, float* batch_rays, float* target,
+                          int* pixels, void* stream) {
+    REQUIRE(K_host && pose && image && batch_rays && target, "null pointer");
+    REQUIRE(H > 0 && W > 0 && nh > 0 && nw > 0 && h0 >= 0 && w0 >= 0 && h0 + nh <= H && w0 + nw <= W, "the crop window must lie inside the image");
+    REQUIRE((long)H * W < (1L << 31), "image too large");
+    REQUIRE(n_rand >= 0 && (long)n_rand <= (long)nh * nw, "cannot take more distinct pixels than the window holds (np.random.choice(..., replace=False) raises too)");
+    REQUIRE(pose_row_stride >= 4, "pose rows are at least 4 floats apart");
+    REQUIRE(K_host[0] != 0.0f && K_host[4] != 0.0f, "K has a zero focal length");
+    return done(__func__, nerf::launch_sample_ray_batch(H, W, K_host, pose, pose_row_stride, image, h0, w0, nh, nw, n_rand, key0, key1,
+                                                        batch_rays, target, pixels, (hipStream_t)stream));
+}
+
 int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int n_samples,
                        int lindisp, const float* t_rand, float* z_vals, void* stream) {
     REQUIRE(rays && t_vals && z_vals, "null pointer");

@@ -67,6 +67,9 @@ hipError_t launch_make_rays(int H, int W, const float* K9, const float* pose12, 
                             float near, float far, float* rays, int ray_stride, hipStream_t stream);
 hipError_t launch_assemble_rays(const float* rays_o, const float* rays_d, long n, int ndc, int H, int W, float focal,
                                 float near, float far, float* rays, int ray_stride, hipStream_t stream);
+hipError_t launch_sample_ray_batch(int H, int W, const float* K9, const float* pose_dev, int pose_stride, const float* image, int h0, int w0,
+                                   int nh, int nw, int n_rand, unsigned key0, unsigned key1, float* rays, float* target, int* pixels,
+                                   hipStream_t stream);
 hipError_t launch_composite(const CompositeArgs& a, bool bwd, hipStream_t stream);
 hipError_t launch_sample_fine(const FineArgs& a, hipStream_t stream);
 hipError_t launch_field_fwd(const float* packed, const float* rays, int ray_stride, const float* z_vals,

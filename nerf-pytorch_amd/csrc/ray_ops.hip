@@ -127,6 +127,80 @@ __global__ void make_rays_kernel(RayGenArgs a) {
     r[8] = v0; r[9] = v1; r[10] = v2;
 }
 
+// ------------------------------------------------------------------ ray-batch selection of train() (run_nerf.py:726-757)
+// N_rand DISTINCT pixels of one image (of its central crop during the precrop iterations), their rays as get_rays gives them
+// (run_nerf_helpers.py:153-162) and their colours, in one launch of N_rand threads.  The reference draws
+// np.random.choice(H*W, N_rand, replace=False) on the host (an O(H*W) permutation per step) and builds the full [H,W,3] ray grid
+// first; here pixel k of the batch is perm(k), a KEYED BIJECTION of [0, nh*nw): a 6-round Feistel network over the next power
+// of four, cycle-walked back into range (a value >= n is permuted again: still a bijection of [0, n)).  Distinct by construction;
+// which subset comes out is decided by the two key words the host draws per step from its own generator.
+__device__ inline unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ inline unsigned keyed_perm(unsigned k, unsigned n, int half_bits, unsigned key0, unsigned key1) {
+    const unsigned mask = (1u << half_bits) - 1u;
+    unsigned v = k;
+    do {
+        unsigned L = v >> half_bits, R = v & mask;
+#pragma unroll
+        for (unsigned r = 0; r < 6; ++r) {
+            const unsigned F = mix32((R + 0x9e3779b9u * (r + 1u)) ^ (r & 1u ? key1 : key0)) & mask;
+            const unsigned t = L ^ F;
+            L = R;
+            R = t;
+        }
+        v = (L << half_bits) | R;
+    } while (v >= n);
+    return v;
+}
+struct RayBatchArgs {
+    int H, W, h0, w0, nh, nw, n_rand, half_bits;
+    unsigned key0, key1;
+    float fx, fy, cx, cy;
+    const float* pose; int pose_stride;     // c2w[:3,:4] on the DEVICE, rows pose_stride floats apart
+    const float* image;                     // [H][W][3]
+    float* rays;                            // [2][n_rand][3] = (rays_o, rays_d)
+    float* target;                          // [n_rand][3]
+    int* pixels;                            // [n_rand] j * W + i of every selected pixel (nullable)
+};
+__global__ void sample_ray_batch_kernel(RayBatchArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_rand) return;
+    const unsigned sel = keyed_perm((unsigned)k, (unsigned)(a.nh * a.nw), a.half_bits, a.key0, a.key1);
+    const int jj = a.h0 + (int)(sel / (unsigned)a.nw), ii = a.w0 + (int)(sel % (unsigned)a.nw);
+    float m[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[4 * r + c] = a.pose[r * a.pose_stride + c];
+    const float dx = ((float)ii - a.cx) / a.fx, dy = -((float)jj - a.cy) / a.fy, dz = -1.0f;
+    float o[3], d[3];
+    camera_ray(m, dx, dy, dz, o, d);
+    const float* px = a.image + ((long)jj * a.W + ii) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.rays[(long)k * 3 + c] = o[c];
+        a.rays[((long)a.n_rand + k) * 3 + c] = d[c];
+        a.target[(long)k * 3 + c] = px[c];
+    }
+    if (a.pixels) a.pixels[k] = jj * a.W + ii;
+}
+hipError_t launch_sample_ray_batch(int H, int W, const float* K9, const float* pose_dev, int pose_stride, const float* image, int h0, int w0,
+                                   int nh, int nw, int n_rand, unsigned key0, unsigned key1, float* rays, float* target, int* pixels,
+                                   hipStream_t stream) {
+    if (n_rand <= 0) return hipSuccess;
+    RayBatchArgs a{};
+    a.H = H; a.W = W; a.h0 = h0; a.w0 = w0; a.nh = nh; a.nw = nw; a.n_rand = n_rand;
+    a.half_bits = 1;
+    while ((1ull << (2 * a.half_bits)) < (unsigned long long)nh * (unsigned long long)nw) ++a.half_bits;
+    a.key0 = key0; a.key1 = key1;
+    a.fx = K9[0]; a.cx = K9[2]; a.fy = K9[4]; a.cy = K9[5];
+    a.pose = pose_dev; a.pose_stride = pose_stride; a.image = image; a.rays = rays; a.target = target; a.pixels = pixels;
+    hipLaunchKernelGGL(sample_ray_batch_kernel, dim3((unsigned)((n_rand + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ launchers
 // ------------------------------------------------------------------ img2mse (run_nerf_helpers.py:11) and its gradient
 // mean((x - y)^2) over n elements in ONE launch, deterministic: every block sums its contiguous slice in a fixed tree, writes its

@@ -20,6 +20,7 @@ struct RenderWs {
     size_t z_c, raw_c, w_c;         // coarse pass: depths, raw, compositing weights
     size_t z_f;                     // sorted union of coarse and fine depths
     size_t act_c, act_f, d_raw, delta, partial;     // training only
+    size_t zero_rgb;                // training only: [N][3] zeros, the d_rgb of a pass that receives only d_disp / d_acc
     size_t total;
 };
 RenderWs render_ws(int n_rays, int Sc, int Sf, int training) {
@@ -39,6 +40,7 @@ RenderWs render_ws(int n_rays, int Sc, int Sf, int training) {
         w.d_raw = o; o += up4(N * (size_t)S2 * 4);
         w.delta = o; o += up4(nerf_delta_floats(n_rays, S2));
         w.partial = o; o += up4(nerf_wgrad_partial_floats(n_rays, S2));
+        w.zero_rgb = o; o += up4(N * 3);
     }
     w.total = o;
     return w;
@@ -220,10 +222,10 @@ int nerf_render_rays_bwd(const NerfRenderCfg* cfg, const float* packed_c, const 
         float* d_raw = ws + w.d_raw;
         const size_t n4 = (size_t)n_rays * S * 4;
         if (g_rgb || g_disp || g_acc) {
-            if (!g_rgb) {       // d_disp / d_acc without d_rgb: a zero d_rgb (the partial-sum region is free until field_backward)
-                hipError_t err = hipMemsetAsync(ws + w.partial, 0, (size_t)n_rays * 3 * sizeof(float), st);
+            if (!g_rgb) {       // d_disp / d_acc without d_rgb: a zero d_rgb (its own region of the workspace)
+                hipError_t err = hipMemsetAsync(ws + w.zero_rgb, 0, (size_t)n_rays * 3 * sizeof(float), st);
                 if (err != hipSuccess) return err;
-                g_rgb = ws + w.partial;
+                g_rgb = ws + w.zero_rgb;
             }
             nerf::CompositeArgs a{raw_p, z, rays + 3, cfg->raw_noise_std > 0.0f ? noise : nullptr, cfg->raw_noise_std, ray_stride, n_rays, S,
                                   cfg->white_bkgd, nullptr, nullptr, nullptr, nullptr, nullptr, g_rgb, g_acc, g_disp, d_raw, nullptr, nullptr};

@@ -26,7 +26,7 @@ namespace nerf {
 // workgroup is wavefront k mod 8's in the per-ray phases
 constexpr int FUSED_SCRATCH_FLOATS = 2048;  // LDS floats per wavefront in the per-ray phases (the weight ring is idle then)
 
-template <int FUSED_RAYS, typename SP, bool RED = false>
+template <int FUSED_RAYS, typename SP>
 __global__ __launch_bounds__(FIELD_WAVES * 64) void render_infer_kernel(RenderInferArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void render_infer_kernel(RenderIn
         const FieldFwdRingArgs fa{second ? a.packed_f : a.packed_c, a.rays, second ? a.z_f : a.z_c, second ? a.raw_f : a.raw_c,
                                   nullptr, a.ray_stride, a.n_rays, second ? S2 : Sc, second ? S2 : Sc, 0, second ? S2 : Sc, 0, 0};
         const long wg = second ? (long)blockIdx.x * tiles_f + (t - tiles_c) : (long)blockIdx.x * tiles_c + t;
-        field_fwd16r_tile<0, SP, RED>(fa, lds, wg);
+        field_fwd16r_tile<0, SP>(fa, lds, wg);
     }
     // ---- 5. colours of the last pass
     __syncthreads();
@@ -103,16 +103,16 @@ bool render_infer_fused_ok(int n_c, int n_f) {
            2 * S2 <= FUSED_SCRATCH_FLOATS && 3 * n_c + np2 <= FUSED_SCRATCH_FLOATS;
 }
 
-template <int R, typename SP, bool RED = false>
+template <int R, typename SP>
 static hipError_t launch_infer_one(const RenderInferArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)render_infer_kernel<R, SP, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)render_infer_kernel<R, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const dim3 grid((unsigned)((a.n_rays + R - 1) / R)), block(FIELD_WAVES * 64);
-    hipLaunchKernelGGL((render_infer_kernel<R, SP, RED>), grid, block, RING_LDS_FLOATS * 4, stream, a);
+    hipLaunchKernelGGL((render_infer_kernel<R, SP>), grid, block, RING_LDS_FLOATS * 4, stream, a);
     return hipGetLastError();
 }
 
@@ -129,11 +129,7 @@ hipError_t launch_render_infer(const RenderInferArgs& a, hipStream_t stream) {
         if ((double)wg8 >= 0.95 * (double)(((wg8 + 255) / 256) * 256)) R = 8;
     }
     if (force && tiles(atoi(force))) R = atoi(force);       // (only 4, 8, 16; anything else is ignored)
-    if (a.split == 2) {
-        if (R == 4) return launch_infer_one<4, SplitF16, true>(a, stream);
-        if (R == 8) return launch_infer_one<8, SplitF16, true>(a, stream);
-        return launch_infer_one<16, SplitF16, true>(a, stream);
-    }
+    if (a.split != 0 && a.split != 1) return hipErrorInvalidValue;      // (the reduced class needs its guard launch between the passes)
     if (a.split) {
         if (R == 4) return launch_infer_one<4, SplitF16>(a, stream);
         if (R == 8) return launch_infer_one<8, SplitF16>(a, stream);

@@ -34,6 +34,7 @@ def _declare(lib):
         "nerf_debug_pack_table": (i, [p]),
         "nerf_embed": (i, [p, l, i, p, p]),
         "nerf_sample_coarse": (i, [p, i, i, p, i, i, p, p, p]),
+        "nerf_sample_ray_batch": (i, [i, i, p, p, i, p, i, i, i, i, i, ctypes.c_uint, ctypes.c_uint, p, p, p, p]),
         "nerf_make_rays": (i, [i, i, p, p, p, i, f, f, p, i, p]),
         "nerf_assemble_rays": (i, [p, p, l, i, i, i, f, f, f, p, i, p]),
         "nerf_buffer_layout": (i, [p, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(i)]),
@@ -81,7 +82,7 @@ def _declare(lib):
 
 
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
-           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_buffer_layout", "nerf_debug_layout", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
+           "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_sample_ray_batch", "nerf_buffer_layout", "nerf_debug_layout", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
            "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_debug_pack3_table",
@@ -329,7 +330,28 @@ def assemble_rays(rays_o, rays_d, ndc, H, W, focal, near, far):
     return rays
 
 
-def act_floats(n_rays, n_samples):
+def sample_ray_batch(H, W, K, pose, image, n_rand, window, key, want_pixels=False):
+    """nerf_sample_ray_batch: n_rand distinct pixels of `image` inside window = (h0, w0, nh, nw), their rays and colours in one launch.
+    pose: device tensor holding c2w[:3,:4] (a view into a [N,4,4] pose table is fine); key: two 32-bit words."""
+    import numpy as np
+    Kh = np.ascontiguousarray(np.asarray(K.detach().cpu().numpy() if isinstance(K, torch.Tensor) else K, dtype=np.float32)[:3, :3])
+    if not (isinstance(pose, torch.Tensor) and pose.is_cuda and pose.dtype == torch.float32 and pose.dim() == 2 and pose.shape[0] >= 3
+            and pose.shape[1] >= 4 and pose.stride(1) == 1):
+        raise NerfHipError("sample_ray_batch: pose must be a float32 [3+, 4] device tensor with contiguous rows")
+    dev = image.device
+    rays = torch.empty((2, n_rand, 3), dtype=torch.float32, device=dev)
+    target = torch.empty((n_rand, 3), dtype=torch.float32, device=dev)
+    pix = torch.empty((n_rand,), dtype=torch.int32, device=dev) if want_pixels else None
+    h0, w0, nh, nw = (int(v) for v in window)
+    _check(lib().nerf_sample_ray_batch(int(H), int(W), Kh.ctypes.data_as(ctypes.c_void_p), pose.data_ptr(), int(pose.stride(0)),
+                                       _ptr(image, "image"), h0, w0, nh, nw, int(n_rand), int(key[0]) & 0xffffffff, int(key[1]) & 0xffffffff,
+                                       _ptr(rays), _ptr(target), pix.data_ptr() if pix is not None else None, _stream()),
+           "nerf_sample_ray_batch")
+    return (rays, target, pix) if want_pixels else (rays, target)
+
+
+def act_floats(n_rays, n_samples, precision="fp32"):
+    """floats of a save buffer for this datapath (nerf_act_floats: the fp32 datapath's fp32 rows are the largest layout)"""
     return lib().nerf_act_floats(n_rays, n_samples)
 
 
@@ -367,6 +389,10 @@ class Workspace:
         if len(free) > self.MAX_FREE:       # (list.remove would compare tensors elementwise)
             free.pop(min(range(len(free)), key=lambda i: free[i].numel()))
 
+    def idle_bytes(self, device):
+        """bytes of the idle leases on `device` (memory the next take() can re-use instead of allocating)"""
+        return 4 * sum(t.numel() for t in self._free.get(str(device), []))
+
     def clear(self):
         self._free.clear()
 
@@ -391,9 +417,9 @@ def max_saved_rays(n_coarse, n_fine):
     return max(1, SAVE_BUDGET_BYTES // max(per_1024, 1)) * 1024
 
 
-def saved_bytes(n_rays, n_coarse, n_fine):
+def saved_bytes(n_rays, n_coarse, n_fine, precision="fp32"):
     """bytes of saved activations (both passes) a training render_rays call over n_rays keeps until its backward"""
-    return 4 * (act_floats(n_rays, n_coarse) + (act_floats(n_rays, n_coarse + n_fine) if n_fine > 0 else 0))
+    return 4 * (act_floats(n_rays, n_coarse, precision) + (act_floats(n_rays, n_coarse + n_fine, precision) if n_fine > 0 else 0))
 
 
 class NerfRenderCfg(ctypes.Structure):
@@ -504,8 +530,11 @@ INFER_ONE_LAUNCH = os.environ.get("NERF_INFER_ONE_LAUNCH", "1") != "0"
 
 
 def render_cfg(n_coarse, n_fine, lindisp, white_bkgd, raw_noise_std, precision):
+    if precision == "fp16_fp8c":
+        raise NerfHipError("render_cfg: the one-call entry points run the fp32 / bf16x3 / fp16x3 datapaths; the reduced inference class "
+                           "\"fp16_fp8c\" is a chain of launches with its last-sample guard in between (render._field_pass)")
     return NerfRenderCfg(int(n_coarse), int(n_fine), int(bool(lindisp)), int(bool(white_bkgd)), float(raw_noise_std),
-                         {"fp32": 0, "bf16x3": 1, "fp16x3": 3, "fp16_fp8c": 3}[precision], 1)
+                         {"fp32": 0, "bf16x3": 1, "fp16x3": 3}[precision], 1)
 
 
 def render_infer_supported(n_coarse, n_fine, precision):
@@ -705,20 +734,27 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
 # Bumped by every raw-pointer update of parameters (the fused Adam kernel writes through data_ptr(), which does not
 # advance the tensors' autograd version counters): NeRF.packed_params() keys its fragment-repack cache on it.
 PARAM_EPOCH = 0             # total number of raw-pointer updates (any vector)
-_PARAM_EPOCHS = {}          # ... per updated vector (keyed by its device address)
+_PARAM_EPOCHS = {}          # ... per updated vector (keyed by the device address of its storage)
+
+
+def _epoch_key(t):
+    # the STORAGE a vector lives in, not the address of its first element: FlatAdam hands the kernel the run of parameters that
+    # have gradients, which starts anywhere inside a network's flat vector (frozen first layer, heads-only fine-tuning)
+    return t.untyped_storage().data_ptr()
 
 
 def param_epoch(flat):
-    """number of raw-pointer (fused Adam) updates of THIS flat parameter vector: an optimizer step on an unrelated network
-    neither invalidates another network's fragment repack nor trips the stale-parameter guard of its pending backward"""
-    return _PARAM_EPOCHS.get(flat.data_ptr(), 0)
+    """number of raw-pointer (fused Adam) updates of the storage THIS flat parameter vector lives in: an optimizer step on an
+    unrelated network neither invalidates another network's fragment repack nor trips the stale-parameter guard of its pending
+    backward; a step on any part of this network's vector does both"""
+    return _PARAM_EPOCHS.get(_epoch_key(flat), 0)
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     """In-place fused Adam over flat fp32 vectors (one launch)."""
     global PARAM_EPOCH
     PARAM_EPOCH += 1
-    _PARAM_EPOCHS[params.data_ptr()] = _PARAM_EPOCHS.get(params.data_ptr(), 0) + 1
+    _PARAM_EPOCHS[_epoch_key(params)] = _PARAM_EPOCHS.get(_epoch_key(params), 0) + 1
     n = params.numel()
     _check(lib().nerf_adam_step(_ptr(params, "params"), _ptr(grads, "grads"), _ptr(exp_avg, "exp_avg"),
                                 _ptr(exp_avg_sq, "exp_avg_sq"), n, float(lr), float(beta1), float(beta2), float(eps),

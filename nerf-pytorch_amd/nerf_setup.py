@@ -108,10 +108,12 @@ def config_parser():
     return parser
 
 
-def create_nerf(args, device=None, fused_adam=False):
+def create_nerf(args, device=None, fused_adam=None):
     """run_nerf.py:178-259: (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer).
-    fused_adam=True returns nerf_pytorch_amd.FlatAdam (same arithmetic and state_dict as torch.optim.Adam, one HIP
-    launch per network) instead of torch.optim.Adam."""
+    The optimizer is nerf_pytorch_amd.FlatAdam -- torch.optim.Adam's arithmetic, param_groups and state_dict (the reference's
+    checkpoints load into it and its checkpoints load into torch.optim.Adam), ONE HIP launch per network instead of foreach kernels
+    over 48 tensors -- whenever the networks are the fused architecture on a GPU (fused_adam=None, the default); fused_adam=False
+    returns torch.optim.Adam itself, fused_adam=True forces FlatAdam."""
     if device is None:
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
@@ -140,6 +142,8 @@ def create_nerf(args, device=None, fused_adam=False):
     network_query_fn = lambda inputs, viewdirs, network_fn: run_network(
         inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=netchunk)
 
+    if fused_adam is None:      # the configuration bench.py measures: fused kernels + fused optimizer
+        fused_adam = isinstance(model, NeRF) and (model_fine is None or isinstance(model_fine, NeRF)) and torch.device(device).type == "cuda"
     if fused_adam:
         from .optim import FlatAdam
         optimizer = FlatAdam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# Tests that do not name a datapath are the tests of the exact-fp32 ANCHOR (their tolerances are the fp32 datapath's); the package
+# default a user gets is fp16x3 (tests/test_host_cpu.py::test_package_defaults checks that in a clean subprocess).
+os.environ.setdefault("NERF_PRECISION", "fp32")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
