@@ -396,7 +396,7 @@ int nerf_field_fwd_last_sample(const float* packed3, const float* rays, int ray_
 
 int nerf_pack_params_split(const float* params, float* packed3, int streams, int split, void* stream) {
     REQUIRE(params && packed3, "null pointer");
-    REQUIRE(streams >= 0 && streams <= 15 && split >= 0 && split <= 2, "streams is a mask of bits 0..3, split 0 (bf16), 1 (fp16) or 2 (reduced inference stream)");
+    REQUIRE(streams >= 0 && (streams & ~5) == 0 && split >= 0 && split <= 2, "streams is a mask of 1 (forward stream) and 4 (transposed streams of the delta chain); split 0 (bf16), 1 (fp16) or 2 (reduced inference stream)");
     REQUIRE(split != 2 || (streams & 1), "split = 2 refills the 16-point forward stream: streams must include bit 0");
     return done(__func__, nerf::launch_pack3_sel(params, packed3, streams, (hipStream_t)stream, split));
 }

@@ -121,16 +121,9 @@ __device__ inline const float* small_ptr(const float* lds, int sm_offset) {
     return lds + 2 * CHUNK_FLOATS + (sm_offset - SM_BIAS);
 }
 
-// chunk sizes (32-bit words) of the four weight streams, in consumption order
-//   MODE 0: fp32 forward   1: fp32 backward   2: bf16x3 forward   3: bf16x3 backward   4: hi-only backward (mixed)
+// chunk sizes (32-bit words) of the two weight streams of the exact-fp32 kernels, in consumption order (MODE 0 forward, 1 backward)
 template <int MODE>
-__device__ constexpr int stream_chunk_words(int c) {
-    if (MODE == 0) return fwd_chunk_floats(c);
-    if (MODE == 1) return bwd_chunk_floats(c);
-    if (MODE == 2) return c < 36 ? CHUNK_FLOATS : (c == 36 ? KS3_DIR * KSTEP3_W4 : 0);   // 34 full + views 2 x 8 k-steps + 2 k-steps
-    if (MODE == 4) return c < 17 ? CHUNK_FLOATS : 0;                                    // views^T 1 | feat^T 2 | L7..L1 14
-    return c < 34 ? CHUNK_FLOATS : 0;                                                  // views^T 2 | feat^T 4 | L7..L1 28
-}
+__device__ constexpr int stream_chunk_words(int c) { return MODE == 0 ? fwd_chunk_floats(c) : bwd_chunk_floats(c); }
 
 // Double-buffered weight stream.  acquire() = "chunk c has landed for every wave,
 // nobody still reads the other buffer" -> start DMA of chunk c+1 -> hand out chunk c.

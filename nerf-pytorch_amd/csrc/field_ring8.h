@@ -79,7 +79,9 @@ __device__ __forceinline__ void ring_units8(WeightRingT<NW>& ring, Frag& fa, Fra
         const float v0 = v[32 * t + 2 * pr], v1 = v[32 * t + 2 * pr + 1];
         // the fp16 pair of these two values is word pr of the main operands of this T (op[0] = values 0..15, dead as an MFMA operand
         // by now; op[1] = values 16..31, in use, read only).  Pair pr overwrites word pr >> 1 of op[0], which pair pr >> 1 has read.
-        const unsigned h = pr < 8 ? op[0][pr] : op[1][pr - 8];
+        unsigned h;
+        if constexpr (pr < 8) h = op[0][pr];
+        else h = op[1][pr - 8];
         float l0, l1;
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h), "v"(v0));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h), "v"(v1));

@@ -167,46 +167,22 @@ namespace nerf {
 __host__ __device__ constexpr int d32row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 // hidden vector, 16 k-steps of 16 slots: k-step s, lane half, element j (0..7) -> feature
 __host__ __device__ constexpr int h3slot(int s, int half, int j) { return 32 * (s >> 1) + d32row(8 * (s & 1) + j, half); }
-// xyz encoding, 4 k-steps: lane half 0 owns (freq,axis) pairs 0..15, half 1 pairs 16..29 + identity + pad;
-// lane value v = 8*s + j; pairs are (sin, cos) adjacent
-__host__ __device__ constexpr int enc3slot(int v, int half) {
-    if (half == 0) { const int i = v >> 1, fn = v & 1; return 3 + (i / 3) * 6 + fn * 3 + (i % 3); }
-    if (v < 28) { const int i = 16 + (v >> 1), fn = v & 1; return 3 + (i / 3) * 6 + fn * 3 + (i % 3); }
-    return v < 31 ? v - 28 : -1;
-}
-// dir encoding, 2 k-steps: half 0 owns pairs 0..7, half 1 pairs 8..11 + identity + pad; lane value v = 8*s + j
-__host__ __device__ constexpr int dir3slot(int v, int half) {
-    if (half == 0) { const int i = v >> 1, fn = v & 1; return 3 + (i / 3) * 6 + fn * 3 + (i % 3); }
-    if (v < 8) { const int i = 8 + (v >> 1), fn = v & 1; return 3 + (i / 3) * 6 + fn * 3 + (i % 3); }
-    return v < 11 ? v - 8 : -1;
-}
-constexpr int KS3_H = 16, KS3_ENC = 4, KS3_DIR = 2, KS3_HV = 8;
-// one k-step of an NB-block layer = NB * 2 (hi, lo) * 64 lanes * 16 B; sizes below in 32-bit words
+constexpr int KS3_H = 16, KS3_HV = 8;
+// The packed buffer of the split datapaths ("packed3", 32-bit words):
+//   [ transposed (hi, lo) fragment streams of the delta chain | fp32 small parameters | 16-point forward stream | derived W', b' ]
+// (rounds 1-4 also kept a 32-point forward stream and a hi-only copy of the transposed streams for kernels that no longer exist.)
+// one k-step of an 8-block layer = 8 blocks x 2 (hi, lo) x 64 lanes x 16 B; sizes below in 32-bit words
 constexpr int KSTEP3_W8 = 8 * 2 * 64 * 4;      // 4096 words = 16 KiB (256 outputs)
-constexpr int KSTEP3_W4 = 4 * 2 * 64 * 4;      // 2048 words (128 outputs)
 // element (nb, hl, lane, j) of a k-step lives at 16-bit index (((nb*2 + hl)*64 + lane)*8 + j)
-constexpr int P3F_L0 = 0;
-constexpr int P3F_L1 = P3F_L0 + KS3_ENC * KSTEP3_W8;                    // layers 1..4
-constexpr int P3F_L5 = P3F_L1 + 4 * KS3_H * KSTEP3_W8;
-constexpr int P3F_L6 = P3F_L5 + (KS3_ENC + KS3_H) * KSTEP3_W8;          // layers 6, 7
-constexpr int P3F_FEAT = P3F_L6 + 2 * KS3_H * KSTEP3_W8;
-constexpr int P3F_VIEWS = P3F_FEAT + KS3_H * KSTEP3_W8;
-constexpr int P3F_END = P3F_VIEWS + (KS3_H + KS3_DIR) * KSTEP3_W4;
-constexpr int P3B_VIEWS = P3F_END;                                      // transposed streams, all 8 blocks
-constexpr int P3B_FEAT = P3B_VIEWS + KS3_HV * KSTEP3_W8;
-constexpr int P3B_L7 = P3B_FEAT + KS3_H * KSTEP3_W8;                    // then L6 .. L1
+constexpr int P3B_VIEWS = 0;                                            // transposed streams of the delta chain, all 8 blocks:
+constexpr int P3B_FEAT = P3B_VIEWS + KS3_HV * KSTEP3_W8;                // W'^T | feature_linear^T (skipped by the kernel) |
+constexpr int P3B_L7 = P3B_FEAT + KS3_H * KSTEP3_W8;                    // L7^T .. L1^T
 constexpr int P3B_END = P3B_L7 + 7 * KS3_H * KSTEP3_W8;
 constexpr int P3_SMALL = P3B_END;                                       // fp32 small parameters, same order as SM_*
-// hi-only copy of the transposed streams (round 3's mixed-precision delta chain, removed; the region keeps its place so that the
-// packed layout stays the one the test-reference kernels of csrc/ref read): k-step = 8 blocks x 64 lanes x 16 B
-constexpr int KSTEP1_W8 = 8 * 64 * 4;                                   // 2048 words = 8 KiB
-constexpr int P1B_KSTEPS = KS3_HV + KS3_H + 7 * KS3_H;                  // views^T 8 | feat^T 16 | L7^T..L1^T 7 x 16 = 136
-constexpr int P1B = P3_SMALL + (PACKED_FLOATS - SM_BIAS);
-// forward (hi, lo) fragments for the 16-point-per-wave inference kernel (v_mfma_f32_16x16x32_bf16: lane = (row l&15,
-// k-group l>>4), 8 consecutive contraction slots per lane; the contraction slots are the fp32 datapath's hcol /
-// encslot / dirslot maps with value index 8*s + j).  k-step = NB blocks x (hi, lo) x 64 lanes x 16 B; same region
-// sizes and chunking as the 32-point forward stream (P3F_*): L0 | L1..L4 | L5(enc,h) | L6 L7 | FEAT | VIEWS(feat,dir)
-constexpr int P16F = P1B + P1B_KSTEPS * KSTEP1_W8;
+// forward (hi, lo) fragments of the 16-point-per-wave kernels (v_mfma_f32_16x16x32_{f16,bf16}: lane = (row l&15, k-group l>>4), 8
+// consecutive contraction slots per lane; the contraction slots are the fp32 datapath's hcol / encslot / dirslot maps with value
+// index 8*s + j).  k-step = NB blocks x (hi, lo) x 64 lanes x 16 B: L0 | L1..L4 | L5(enc,h) | L6 L7 | FEAT (skipped) | VIEWS(h7,dir)
+constexpr int P16F = P3_SMALL + (PACKED_FLOATS - SM_BIAS);
 constexpr int KSTEP16_W16 = 16 * 2 * 64 * 4;                             // 8192 words = 32 KiB (256 outputs)
 constexpr int KSTEP16_W8 = 8 * 2 * 64 * 4;                               // 4096 words (128 outputs)
 constexpr int KS16_ENC = 2, KS16_H = 8, KS16_DIR = 1;                    // k-steps of 32 contraction slots
@@ -216,7 +192,7 @@ constexpr int P16F_L6 = P16F_L5 + (KS16_ENC + KS16_H) * KSTEP16_W16;
 constexpr int P16F_FEAT = P16F_L6 + 2 * KS16_H * KSTEP16_W16;
 constexpr int P16F_VIEWS = P16F_FEAT + KS16_H * KSTEP16_W16;
 constexpr int P16F_WORDS = P16F_VIEWS + (KS16_H + KS16_DIR) * KSTEP16_W8;
-static_assert(P16F_WORDS == P3F_END && P16F % 4 == 0, "the 16-point forward stream has the 32-point stream's size");
+static_assert(P16F_WORDS == 593920 && P16F % 4 == 0, "16-point forward stream");
 // ---- FOLDED FEATURE LAYER (split datapaths).  feature_linear has no activation and feeds only
 // views_linears.0 (run_nerf_helpers.py:111-115), so the two consecutive linear maps compose:
 //     views_pre = Wv[:, :256] (Wf h7 + bf) + Wv[:, 256:] enc(dir) + bv = W' h7 + Wv[:, 256:] enc(dir) + b'
@@ -234,13 +210,8 @@ constexpr int DERIVED_WVF = N_PARAMS;
 constexpr int DERIVED_BV = DERIVED_WVF + WV * W;
 constexpr int N_DERIVED = WV * W + WV;                                   // 32,896 floats
 constexpr int P3_DERIVED = P16F + P16F_WORDS;                            // offset of (W', b') inside the packed3 buffer
-constexpr int FOLD_SKIP_CHUNKS_FWD = 4;                                  // feature_linear chunks skipped in the forward streams
-constexpr int FOLD_SKIP_CHUNKS_BWD = 4;                                  // feature_linear^T chunks skipped in the dgrad stream
-constexpr int FOLD_SKIP_CHUNKS_BWD_HI = 2;                               // ... in the hi-only (mixed) dgrad stream
 constexpr int PACKED3_WORDS = P3_DERIVED + N_DERIVED;
 static_assert(P3_DERIVED % 4 == 0, "alignment of the derived parameters");
-static_assert(P1B % 4 == 0 && (P1B_KSTEPS * KSTEP1_W8) % 16384 == 0, "hi-only stream: whole 64 KiB chunks");
-static_assert(P3F_VIEWS % 4096 == 0 && P3B_VIEWS % 4 == 0, "chunk alignment");
 
 constexpr int PTS_PER_WAVE3 = 32;
 constexpr int FIELD3_WAVES = 4;                                         // 256-thread workgroups, 1 wave / SIMD

@@ -74,49 +74,26 @@ __global__ void pack_params_kernel(const float* __restrict__ canon_params, float
     packed[idx] = src < 0 ? 0.0f : canon_params[src];
 }
 
-// ---- split-bf16 repack: every weight becomes (hi, lo) bf16; layout in nerf_common.h (bf16x3 section)
-// returns the canonical source index of 16-bit element e16 of the weight streams (-1: zero padding);
-// *is_lo tells whether the element is the low part
+// ---- three-term-split repack: every weight becomes (hi, lo) 16-bit parts; layout in nerf_common.h
+// returns the canonical source index of 16-bit element e16 of the TRANSPOSED streams of the delta chain (-1: zero padding);
+// *is_lo tells whether the element is the low part.  Output row = input feature k of the layer, contraction slot = output feature n.
 __host__ __device__ inline int pack3_source(int e16, int* is_lo) {
     constexpr Canon c = canon();
     const int word = e16 >> 1;
-    int base, kind;          // kind: 0..7 trunk layer fwd, 8 feature fwd, 9 views fwd, 10 views^T, 11 feat^T, 12+l: layer l ^T
-    if (word < P3F_L1) { base = P3F_L0; kind = 0; }
-    else if (word < P3F_L5) { kind = 1 + (word - P3F_L1) / (KS3_H * KSTEP3_W8); base = P3F_L1 + (kind - 1) * KS3_H * KSTEP3_W8; }
-    else if (word < P3F_L6) { base = P3F_L5; kind = 5; }
-    else if (word < P3F_FEAT) { kind = 6 + (word - P3F_L6) / (KS3_H * KSTEP3_W8); base = P3F_L6 + (kind - 6) * KS3_H * KSTEP3_W8; }
-    else if (word < P3F_VIEWS) { base = P3F_FEAT; kind = 8; }
-    else if (word < P3F_END) { base = P3F_VIEWS; kind = 9; }
-    else if (word < P3B_FEAT) { base = P3B_VIEWS; kind = 10; }
-    else if (word < P3B_L7) { base = P3B_FEAT; kind = 11; }
-    else { const int t = (word - P3B_L7) / (KS3_H * KSTEP3_W8); kind = 12 + (7 - t); base = P3B_L7 + t * KS3_H * KSTEP3_W8; }
-    const int nblk = kind == 9 ? 4 : 8;
-    const int per_kstep16 = nblk * 2 * 64 * 8;
+    int base, kind;          // kind: 0 = W'^T (folded view matrix), 1 = feature_linear^T, 2 + t: layer (7 - t)^T
+    if (word < P3B_FEAT) { base = P3B_VIEWS; kind = 0; }
+    else if (word < P3B_L7) { base = P3B_FEAT; kind = 1; }
+    else { const int t = (word - P3B_L7) / (KS3_H * KSTEP3_W8); kind = 2 + t; base = P3B_L7 + t * KS3_H * KSTEP3_W8; }
+    const int per_kstep16 = 8 * 2 * 64 * 8;
     const int r = e16 - 2 * base;
     const int s = r / per_kstep16, rem = r % per_kstep16;
     const int nb = rem / 1024, hl = (rem / 512) & 1, lane = (rem >> 3) & 63, j = rem & 7;
     const int row = 32 * nb + (lane & 31), half = lane >> 5;
     *is_lo = hl;
-    if (kind <= 7) {
-        const int ld = fan_in(kind);
-        if (kind == 0) { const int e = enc3slot(8 * s + j, half); return e < 0 ? -1 : c.w[0] + row * ld + e; }
-        if (kind == SKIP + 1) {
-            if (s < KS3_ENC) { const int e = enc3slot(8 * s + j, half); return e < 0 ? -1 : c.w[kind] + row * ld + e; }
-            return c.w[kind] + row * ld + IN_XYZ + h3slot(s - KS3_ENC, half, j);
-        }
-        return c.w[kind] + row * ld + h3slot(s, half, j);
-    }
-    if (kind == 8) return c.wf + row * W + h3slot(s, half, j);
-    if (kind == 9) {        // view branch on the trunk output: folded W' (nerf_common.h)
-        if (s < KS3_H) return DERIVED_WVF + row * W + h3slot(s, half, j);
-        const int d = dir3slot(8 * (s - KS3_H) + j, half);
-        return d < 0 ? -1 : c.wv + row * (W + IN_DIR) + W + d;
-    }
-    // transposed: output row = input feature k of the layer, contraction slot = output feature n
     const int n = h3slot(s, half, j);
-    if (kind == 10) return DERIVED_WVF + n * W + row;      // W'^T
-    if (kind == 11) return c.wf + n * W + row;               // (feature_linear^T: packed, skipped by the kernels)
-    const int l = kind - 12;
+    if (kind == 0) return DERIVED_WVF + n * W + row;        // W'^T
+    if (kind == 1) return c.wf + n * W + row;               // (feature_linear^T: packed, skipped by the kernel)
+    const int l = 7 - (kind - 2);
     if (l == SKIP + 1) return c.w[l] + n * (W + IN_XYZ) + IN_XYZ + row;
     return c.w[l] + n * W + row;
 }
@@ -195,15 +172,13 @@ void pack3_table_host(int* out) {
     for (int e = 0; e < 2 * P3B_END; ++e) { int lo; const int s = pack3_source(e, &lo); out[e] = s < 0 ? -1 : 2 * s + lo; }
 }
 
-// ONE repack launch for everything a split-bf16 step reads (after derive_folded, which it depends on).  `streams` selects
-// the fragment streams to write: bit 0 = 16-point forward (P16F), bit 1 = 32-point forward (P3F), bit 2 = transposed (hi, lo)
-// streams of the delta chain (P3B), bit 3 = their hi-only copy (P1B, mixed-precision chain).  The small fp32 parameters
-// are always written.  The default configuration (16-point forward + split-bf16 chain) needs bits 0 | 2: 2.3 M of the
-// 4.1 M 16-bit elements, in one launch instead of four.
+// ONE repack launch for everything a split-datapath step reads (after derive_folded, which it depends on).  `streams` selects
+// the fragment streams to write: bit 0 = 16-point forward (P16F), bit 2 = transposed (hi, lo) streams of the delta chain (P3B)
+// (bits 1 and 3 named streams of kernels that no longer exist).  The small fp32 parameters are always written.
 // SP (split_types.h): the 16-bit type the weights are split into -- the same buffer layout either way.
 template <typename SP>
 __global__ void pack3_all_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived, float* __restrict__ packed,
-                                 int n16f, int n3f, int n3b, int n1b) {
+                                 int n16f, int n3b) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned short* p16 = reinterpret_cast<unsigned short*>(packed);
     auto emit = [&](unsigned short* dst, int src, int is_lo) {
@@ -221,30 +196,13 @@ __global__ void pack3_all_kernel(const float* __restrict__ canon_params, const f
         return;
     }
     idx -= n16f;
-    if (idx < n3f) {                                         // 32-point forward stream
+    if (idx < n3b) {                                         // transposed streams
         int lo;
         const int src = pack3_source((int)idx, &lo);
-        emit(p16 + idx, src, lo);
-        return;
-    }
-    idx -= n3f;
-    if (idx < n3b) {                                         // transposed streams
-        const int e16 = 2 * P3F_END + (int)idx;
-        int lo;
-        const int src = pack3_source(e16, &lo);
-        emit(p16 + e16, src, lo);
+        emit(p16 + 2L * P3B_VIEWS + idx, src, lo);
         return;
     }
     idx -= n3b;
-    if (idx < n1b) {                                         // hi-only copy of the transposed streams: element (s, nb, lane, j)
-        const int j = (int)idx & 7, lane = ((int)idx >> 3) & 63, nb = ((int)idx >> 9) & 7, ks = (int)idx >> 12;
-        const int e16 = 2 * P3B_VIEWS + (((ks * 16 + nb * 2) * 64 + lane) << 3) + j;
-        int lo;
-        const int src = pack3_source(e16, &lo);
-        emit(p16 + 2L * P1B + idx, src, 0);
-        return;
-    }
-    idx -= n1b;
     if (idx < PACKED_FLOATS - SM_BIAS) {                     // small fp32 parameters (b' replaces the view-branch bias)
         const int i = (int)idx, pidx = SM_BIAS + i;
         if (pidx >= SM_BVIEWS && pidx < SM_WALPHA) { packed[P3_SMALL + i] = derived[WV * W + (pidx - SM_BVIEWS)]; return; }
@@ -362,12 +320,11 @@ hipError_t launch_pack3_sel(const float* canon_params, float* packed, int stream
     const int threads = 256;
     float* derived = packed + P3_DERIVED;
     hipLaunchKernelGGL(derive_folded_kernel, dim3((8 * N_DERIVED + threads - 1) / threads), dim3(threads), 0, stream, canon_params, derived);
-    const int n16f = (streams & 1) ? 2 * P16F_WORDS : 0, n3f = (streams & 2) ? 2 * P3F_END : 0;
-    const int n3b = (streams & 4) ? 2 * (P3B_END - P3F_END) : 0, n1b = (streams & 8) ? 2 * P1B_KSTEPS * KSTEP1_W8 : 0;
-    const long total = (long)n16f + n3f + n3b + n1b + (PACKED_FLOATS - SM_BIAS);
+    const int n16f = (streams & 1) ? 2 * P16F_WORDS : 0, n3b = (streams & 4) ? 2 * (P3B_END - P3B_VIEWS) : 0;
+    const long total = (long)n16f + n3b + (PACKED_FLOATS - SM_BIAS);
     const dim3 grid((unsigned)((total + threads - 1) / threads));
-    if (split) hipLaunchKernelGGL(pack3_all_kernel<SplitF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3f, n3b, n1b);
-    else hipLaunchKernelGGL(pack3_all_kernel<SplitBF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3f, n3b, n1b);
+    if (split) hipLaunchKernelGGL(pack3_all_kernel<SplitF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3b);
+    else hipLaunchKernelGGL(pack3_all_kernel<SplitBF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3b);
     if (split == 2) {       // reduced inference stream on top of the fp16 three-term stream (its narrow units and small parameters stay)
         hipLaunchKernelGGL(weight_scale_kernel, dim3(N_RED_MATRICES), dim3(1024), 0, stream, canon_params, (const float*)derived, packed);
         const long n8 = 2L * P16F_WORDS + 1;

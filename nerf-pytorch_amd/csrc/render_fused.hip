@@ -52,19 +52,23 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void render_infer_kernel(RenderIn
         if (fine && t == tiles_c) {
             // ---- 3. raw of all coarse tiles is visible to the workgroup; the weight ring is idle: its LDS is scratch
             __syncthreads();
+            // (an opaque copy of the lane number: everything the per-ray phase derives from it is computed HERE -- hoisted out of
+            // the tile loop it would be carried through the network tiles, whose register file is full: 256 VGPRs + scratch)
+            int lane_p = lane;
+            asm volatile("" : "+v"(lane_p));
 #pragma unroll 1
             for (int k = wave; k < FUSED_RAYS; k += FIELD_WAVES) {     // ray k of the workgroup: wavefront k mod 8
                 const int r = ray0 + k;
                 if (r >= a.n_rays) break;
                 CompositeArgs ca{a.raw_c, a.z_c, a.rays + 3, a.noise_c, a.noise_std, a.ray_stride, a.n_rays, Sc, a.white_bkgd,
                                  a.rgb_c, a.disp_c, a.acc_c, a.w_c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-                composite_ray<false>(ca, r, lane, sm);
+                composite_ray<false>(ca, r, lane_p, sm);
                 // the weights this wavefront just stored are read back (other lanes) by the sampling below
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 FineArgs fa{a.z_c, a.w_c, a.u, nullptr, a.z_f, nullptr, a.z_std, a.n_rays, Sc, a.n_f, 0};
-                sample_fine_ray<WaveSync>(fa, r, lane, sm);
+                sample_fine_ray<WaveSync>(fa, r, lane_p, sm);
                 WaveSync::sync();
             }
         }
@@ -77,6 +81,8 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void render_infer_kernel(RenderIn
     }
     // ---- 5. colours of the last pass
     __syncthreads();
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
 #pragma unroll 1
     for (int k = wave; k < FUSED_RAYS; k += FIELD_WAVES) {
         const int r = ray0 + k;
@@ -84,11 +90,11 @@ __global__ __launch_bounds__(FIELD_WAVES * 64) void render_infer_kernel(RenderIn
         if (fine) {
             CompositeArgs ca{a.raw_f, a.z_f, a.rays + 3, a.noise_f, a.noise_std, a.ray_stride, a.n_rays, S2, a.white_bkgd,
                              a.rgb_f, a.disp_f, a.acc_f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-            composite_ray<false>(ca, r, lane, sm);
+            composite_ray<false>(ca, r, lane_e, sm);
         } else {
             CompositeArgs ca{a.raw_c, a.z_c, a.rays + 3, a.noise_c, a.noise_std, a.ray_stride, a.n_rays, Sc, a.white_bkgd,
                              a.rgb_c, a.disp_c, a.acc_c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-            composite_ray<false>(ca, r, lane, sm);
+            composite_ray<false>(ca, r, lane_e, sm);
         }
         WaveSync::sync();
     }

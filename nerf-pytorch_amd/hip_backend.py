@@ -234,18 +234,18 @@ SPLIT = ("fp16x3", "bf16x3", "fp16_fp8c")       # datapaths on the three-term-sp
 
 
 def pack_table3():
-    """Host-side gather table of the split-bf16 repack: per 16-bit element 2*canonical_index + is_lo, -1 = padding."""
+    """Host-side gather table of the TRANSPOSED (hi, lo) fragment streams of the delta chain (the first region of the packed3 buffer:
+    W'^T | feature_linear^T | L7^T .. L1^T): per 16-bit element 2*canonical_index + is_lo, -1 = padding."""
     import numpy as np
     L = lib()
-    # packed3 = (hi, lo) fragment streams | fp32 small parameters | hi-only copy of the transposed streams (136 k-steps
-    # x 2048 words, csrc/nerf_common.h P1B) | 16-point forward stream (P16F); the table covers the fragment streams
-    n16 = 2 * (L.nerf_packed3_floats() - (L.nerf_packed_floats() - _small_offset()) - 136 * 2048 - P16F_WORDS - N_DERIVED)
+    # packed3 = transposed (hi, lo) streams | fp32 small parameters | 16-point forward stream (P16F) | derived W', b'
+    n16 = 2 * (L.nerf_packed3_floats() - (L.nerf_packed_floats() - _small_offset()) - P16F_WORDS - N_DERIVED)
     tab = np.empty(n16, dtype=np.int32)
     _check(L.nerf_debug_pack3_table(tab.ctypes.data_as(ctypes.c_void_p)), "nerf_debug_pack3_table")
     return tab
 
 
-P16F_WORDS = 593920        # csrc/nerf_common.h: the 16-point forward stream has the 32-point forward stream's size
+P16F_WORDS = 593920        # csrc/nerf_common.h: words of the 16-point forward stream
 N_DERIVED = 128 * 256 + 128  # csrc/nerf_common.h: W' = Wv[:, :256] Wf and b' (folded feature layer), appended to packed3;
 #                              in the pack tables they are "canonical" indices N_PARAMS + k*256 + j, N_PARAMS + 32768 + k
 

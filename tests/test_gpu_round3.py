@@ -15,59 +15,9 @@ from test_gpu_parity import GOLD, _golden_randoms, dev, maxdiff, nets, npa  # no
 pytestmark = pytest.mark.gpu
 
 
-# ---------------------------------------------------------------- weight-ring kernels vs the kernels they replaced
-_REF = None
-
-
-def _ref_lib(npa):
-    """libnerf_hip_ref.so: the superseded double-buffered split-bf16 kernels (csrc/ref/), built for these tests only -- they are not
-    part of the product library or of include/nerf_hip.h (round 4)."""
-    global _REF
-    if _REF is None:
-        import ctypes
-        lib = ctypes.CDLL(npa.build.build_ref())
-        i, p = ctypes.c_int, ctypes.c_void_p
-        lib.nerf_ref_field_fwd16.argtypes = [p, p, i, p, i, i, p, p, i, p]
-        lib.nerf_ref_field_dgrad3.argtypes = [p, p, p, i, i, p, i, p]
-        _REF = lib
-    return _REF
-
-
-@pytest.mark.parametrize("n_rays,S", [(37, 5), (129, 64), (512, 192), (333, 77), (1, 1)])
-def test_ring_forward_bit_identical(npa, dev, nets, n_rays, S):
-    """field_fwd16r_kernel (weight ring, csrc/field_ring.h) against field_fwd16_kernel (double-buffered stream): the same
-    fragment stream in the same order per accumulator, so `raw` and EVERY word of the save buffer (bf16 rows in 16-point
-    tiles, encodings, ReLU bitmasks) must be bit-identical -- ragged tiles, odd point counts and single points included."""
-    nc, nf, Pc, Pf = nets
-    hb = npa.hip_backend
-    L = hb.lib()
-    p3 = nf.packed_params("bf16x3")
-    rays = orc.synthetic_rays(n_rays, seed=3).to(dev)
-    z = torch.sort(torch.rand(n_rays, S, generator=torch.Generator().manual_seed(S)) * 4 + 2, -1)[0].to(dev)
-    s = torch.cuda.current_stream().cuda_stream
-    outs = {}
-    for kind in ("stream", "ring"):
-        for save in (False, True):
-            raw = torch.zeros(n_rays, S, 4, device=dev)
-            act = torch.zeros(hb.act_floats(n_rays, S), device=dev) if save else None
-            a = act.data_ptr() if save else None
-            if kind == "stream":
-                rc = _ref_lib(npa).nerf_ref_field_fwd16(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n_rays, S, raw.data_ptr(), a, 1, s)
-            else:
-                rc = L.nerf_field_fwd_split(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n_rays, S, raw.data_ptr(), a, 0, s)
-            assert rc == 0, L.nerf_last_error()
-            outs[(kind, save)] = (raw, act)
-    torch.cuda.synchronize()
-    for save in (False, True):
-        r0, a0 = outs[("stream", save)]
-        r1, a1 = outs[("ring", save)]
-        assert torch.equal(r0.view(torch.int32), r1.view(torch.int32)), (save, maxdiff(r0, r1))
-        if save:
-            assert int((a1 != 0).sum()) > 0
-            assert torch.equal(a0.view(torch.int32), a1.view(torch.int32))
-    assert torch.equal(outs[("ring", False)][0], outs[("ring", True)][0])      # inference == saving forward
-
-
+# ---------------------------------------------------------------- weight-ring kernels
+# (rounds 3-4 compared them bit for bit with the double-buffered kernels they replaced, kept in a test-only library; that library is
+# gone -- tests/test_gpu_digests.py holds digests of every buffer recorded while those comparisons were green)
 def test_the_split_forward_is_the_ring_kernel(npa, dev, nets):
     """hip_backend routes the split forwards (inference and saving, either 16-bit type) through the weight-ring kernel.  Checked
     through the per-kernel timer labels bench.py reports."""
@@ -85,36 +35,6 @@ def test_the_split_forward_is_the_ring_kernel(npa, dev, nets):
     finally:
         hb.TIMER = None
     assert names == {"field_fwd16r_kernel", "field_fwd16r_kernel<save bf16>", "field_fwd16r_kernel<fp16>", "field_fwd16r_kernel<fp16, save>"}, names
-
-
-@pytest.mark.parametrize("n_rays,S", [(37, 5), (129, 64), (256, 192), (333, 77), (1, 1)])
-def test_ring_dgrad_bit_identical(npa, dev, nets, n_rays, S):
-    """field_dgrad3r_kernel (weight ring, every MFMA with its share of the other work in its shadow) against
-    field_dgrad3_kernel (double-buffered stream, work in bursts between the chunks): same transposed stream, same order
-    per accumulator, so every word of the delta buffer (bf16 deltas, the tiled copy of d_raw) is bit-identical."""
-    nc, nf, Pc, Pf = nets
-    hb = npa.hip_backend
-    L = hb.lib()
-    p3 = nf.packed_params("bf16x3")
-    g = torch.Generator().manual_seed(n_rays + S)
-    rays = orc.synthetic_rays(n_rays, seed=5).to(dev)
-    z = torch.sort(torch.rand(n_rays, S, generator=g) * 4 + 2, -1)[0].to(dev)
-    d_raw = torch.randn(n_rays, S, 4, generator=g).to(dev)
-    s = torch.cuda.current_stream().cuda_stream
-    raw = torch.empty(n_rays, S, 4, device=dev)
-    act = torch.zeros(hb.act_floats(n_rays, S), device=dev)
-    assert L.nerf_field_fwd_split(p3.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n_rays, S, raw.data_ptr(), act.data_ptr(), 0, s) == 0
-    out = []
-    for ring in (False, True):
-        delta = torch.zeros(L.nerf_delta_floats(n_rays, S), device=dev)
-        if ring:
-            assert L.nerf_field_dgrad_split(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n_rays, S, delta.data_ptr(), 0, s) == 0, L.nerf_last_error()
-        else:
-            assert _ref_lib(npa).nerf_ref_field_dgrad3(p3.data_ptr(), act.data_ptr(), d_raw.data_ptr(), n_rays, S, delta.data_ptr(), 2, s) == 0
-        out.append(delta)
-    torch.cuda.synchronize()
-    assert int((out[1] != 0).sum()) > 0
-    assert torch.equal(out[0].view(torch.int32), out[1].view(torch.int32))
 
 
 # ---------------------------------------------------------------- split-bf16 backward: arithmetic error vs kink flips

@@ -448,3 +448,33 @@ def test_buffer_tags_refuse_mismatched_pairings():
     # buffers the library never wrote are not checked (datapath must then be given)
     assert L.nerf_field_wgrad_phase(0x900000, 0xA00000, d_raw, 0, 64, partial, grad, 0, 5, 7, params, None) == 0
     assert L.nerf_field_wgrad_phase(0x900000, 0xA00000, d_raw, 0, 64, partial, grad, 0, -1, 7, params, None) == -1
+
+
+# ---------------------------------------------------------------- build hygiene: no heavy kernel spills
+HEAVY_KERNELS = ["field_fwd16r_kernel<2, nerf::SplitF16, false>", "field_fwd16r_kernel<0, nerf::SplitF16, false>",
+                 "field_fwd16r_kernel<0, nerf::SplitF16, true>", "field_fwd16r_last2_kernel<nerf::SplitF16>",
+                 "field_dgrad3r_kernel<nerf::SplitF16>", "wgrad1_kernel<nerf::SplitF16>", "wgrad256_kernel", "wgrad_kernel",
+                 "render_infer_kernel<16, nerf::SplitF16>", "field_fwd_kernel<true>", "field_fwd_kernel<false>", "field_dgrad_kernel"]
+
+
+def test_no_heavy_kernel_spills():
+    """hipcc's -Rpass-analysis=kernel-resource-usage table of the build that produced the library (build.py records it next to the
+    library at every build): every MFMA kernel of the three datapaths has ScratchSize 0 and no spilled registers, and the two-waves-
+    per-SIMD kernels stay at 2 (round 4's saving forward sat at 256 VGPRs + 44 B/lane of scratch)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_nerf_build", os.path.join(ROOT, "nerf-pytorch_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    table = b.resource_usage()
+    assert table, "libnerf_hip.resources.json missing: the library was not built by build.py"
+    for want in HEAVY_KERNELS:
+        rows = {k: v for k, v in table.items() if want in k}
+        assert rows, f"{want}: not in the resource table ({len(table)} kernels)"
+        for k, v in rows.items():
+            assert v["scratch_bytes_per_lane"] == 0, (k, v)
+            assert v.get("vgpr_spills", 0) == 0, (k, v)      # (SGPR "spills" go to VGPR lanes, not to memory: counted in vgprs)
+            assert v["vgprs"] + v["agprs"] <= 512, (k, v)
+            if "dgrad3r" not in k:              # the delta chain runs one wave per SIMD by design (458 registers)
+                assert v["occupancy_waves_per_simd"] >= 2, (k, v)
+    spilling = sorted(k for k, v in table.items() if v.get("scratch_bytes_per_lane", 0))
+    assert not spilling, spilling
