@@ -19,10 +19,35 @@ import os
 import torch
 import torch.distributed as dist
 
+# NERF_FORCE_PROCESS_GROUP=1 (or init_distributed(force_group=True)): build the process group and run EVERY collective of this module
+# even when the world is one rank.  A 1-GPU box then executes the RCCL branch as written -- ProcessGroupNCCL, the communicator's
+# stream, the async work objects GradientSync waits on, broadcast, all-gather -- instead of the world-size-1 short cuts.
+FORCE_GROUP = os.environ.get("NERF_FORCE_PROCESS_GROUP") == "1"
 
-def init_distributed(backend=None):
+
+def _single(group=None):
+    """True when the collectives of this module have nothing to do: no process group, or a world of one that was not forced"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and not FORCE_GROUP
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init_distributed(backend=None, force_group=None):
     """Initialise from torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
-    Returns (rank, world_size, device).  A single process (no env) is world_size 1."""
+    Returns (rank, world_size, device).  A single process (no env) is world_size 1 and builds no process group unless
+    force_group / NERF_FORCE_PROCESS_GROUP=1 asks for a one-rank group (FORCE_GROUP above)."""
+    global FORCE_GROUP
+    if force_group is not None:
+        FORCE_GROUP = bool(force_group)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -33,10 +58,10 @@ def init_distributed(backend=None):
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_GROUP) and not dist.is_initialized():
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("MASTER_PORT", "29500" if world > 1 else str(_free_port()))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this host driver
         kw = {}
         if backend is None:
@@ -65,7 +90,7 @@ def init_distributed(backend=None):
 def ranks_seen(group=None):
     """Sorted list of the ranks that answer a collective (all-gather of every rank's id): world_size entries 0..G-1 when
     the communicator really spans every process."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group):
         return [0]
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     mine = torch.tensor([dist.get_rank(group)], dtype=torch.int64, device=dev)
@@ -77,7 +102,7 @@ def ranks_seen(group=None):
 def ranks_identical(tensors, group=None):
     """True when every rank holds bit-identical copies of `tensors` (all-gather of a 64-bit checksum of their bytes): the
     data-parallel invariant after broadcast + identical Adam steps on averaged gradients."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group):
         return True
     sums = []
     for t in tensors:
@@ -137,9 +162,9 @@ def _flat_grad_of(model):
 def allreduce_gradients(models, group=None):
     """Average gradients over ranks: one all-reduce per network on its flat gradient bucket
     (falls back to a packed copy when the .grad tensors are not views of one bucket)."""
-    world_ = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world_ == 1:
+    if _single(group):
         return
+    world_ = dist.get_world_size(group)
     for m in models:
         if m is None:
             continue
@@ -223,7 +248,7 @@ class GradientSync:
         return False
 
     def _on_ready(self, model, flat):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if _single(self.group):
             return
         if not any(model is m for m in self.models) or id(model) in self.multi:
             return
@@ -243,11 +268,11 @@ class GradientSync:
         self.started += 1
 
     def finish(self):
-        world_ = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world_ == 1:
+        if _single(self.group):
             self.pending.clear()
             self.multi.clear()
             return
+        world_ = dist.get_world_size(self.group)
         try:
             rest = []
             for m in self.models:
@@ -270,7 +295,7 @@ class GradientSync:
 
 def broadcast_parameters(models, src=0, group=None):
     """Make every rank start from rank `src`'s parameters (one broadcast per network)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _single(group):
         return
     for m in models:
         if m is None:
@@ -288,7 +313,7 @@ def broadcast_parameters(models, src=0, group=None):
 
 def gather_frames(local_frames, frame_ids, n_frames, group=None):
     """Collect per-rank rendered frames (numpy arrays) on rank 0 in frame order."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _single(group):
         return local_frames
     gathered = [None] * dist.get_world_size(group)
     dist.all_gather_object(gathered, (frame_ids, local_frames), group=group)

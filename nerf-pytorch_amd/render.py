@@ -17,7 +17,8 @@ _LINSPACE_CACHE = {}
 # The datapath a user gets without asking (round 5): the fp16 three-term split -- fp32-class products (~2^-22), the configuration
 # bench.py's headline measures and the north-star gate admits at 4e-6 dB.  NERF_PRECISION=fp32 (or set_precision("fp32")) selects the
 # exact-fp32 anchor; the test suite runs under it unless a test names a datapath (tests/conftest.py).
-_PRECISION = __import__("os").environ.get("NERF_PRECISION", "fp16x3")
+DEFAULT_PRECISION = "fp16x3"
+_PRECISION = __import__("os").environ.get("NERF_PRECISION", DEFAULT_PRECISION)
 if _PRECISION not in hb.PRECISIONS:
     raise ValueError(f"NERF_PRECISION={_PRECISION!r}: must be one of {hb.PRECISIONS}")
 
@@ -689,7 +690,18 @@ def img2mse(x, y):
             and y.dtype == torch.float32 and x.shape == y.shape and x.numel() > 0):
         return _Img2Mse.apply(x, y)
     return torch.mean((x - y) ** 2)
-mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device if isinstance(x, torch.Tensor) else None))
+
+
+_LOG10 = {}
+
+
+def mse2psnr(x):
+    """run_nerf_helpers.py:12, same arithmetic and result shape ([1]); log(10) lives on x's device once instead of being uploaded at
+    every call (a pageable host-to-device copy per step would make the host wait for the stream in the train() loop)"""
+    t = _LOG10.get(x.device)
+    if t is None:
+        t = _LOG10[x.device] = torch.log(torch.tensor([10.])).to(x.device)
+    return -10. * torch.log(x) / t
 
 
 def _write_png(path, rgb8):

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import nerf_oracle as orc
-from test_gpu_parity import GOLD, GOLD_TOL, PARITY_DATAPATHS, _check_golden, dev, nets, npa  # noqa: F401  (fixtures)
+from test_gpu_parity import GOLD, GOLD_TOL, PARITY_DATAPATHS, _check_golden, _check_golden_forward_reduced, dev, nets, npa  # noqa: F401  (fixtures)
 
 pytestmark = pytest.mark.gpu
 
@@ -98,3 +98,30 @@ def test_golden_cfg4_32768_rays_in_one_chunk(npa, dev, nets, precision):
     report["grad vs 8 x 4096-ray calls (rel L2)"] = rel
     print("lego_cfg4_forward", precision, report)
     assert rel <= (1e-5 if precision == "fp32" else 1e-4), rel
+
+
+# ---------------------------------------------------------------- the reduced inference class at BASELINE's batch sizes (round 5)
+def test_golden_cfg2_lego_4096_rays_reduced_inference_class(npa, dev, nets):
+    """configs[1]'s 4096 lego rays, forward maps of the no_grad path on fp16 main + fp8 correction products vs the reference's"""
+    _check_golden_forward_reduced(npa, dev, nets, "lego_cfg2_train", dict(perturb=1.0), 1234, render=(orc.LEGO, orc.lego_batch(4096, seed=17)),
+                                  n=4096, raw_ray_stride=16)
+
+
+def test_golden_cfg3_fern_ndc_4096_rays_reduced_inference_class(npa, dev, nets):
+    """configs[2]'s 4096 fern / NDC rays with raw_noise_std = 1 -- the fixture on which bf16x3's last-sample flips show (70.4 dB)"""
+    _check_golden_forward_reduced(npa, dev, nets, "fern_cfg3_train", dict(perturb=1.0, raw_noise_std=1.0, white_bkgd=False, N_importance=128), 4321,
+                                  render=(orc.FERN, orc.fern_batch(4096, seed=13)), n=4096, raw_ray_stride=16)
+
+
+def test_golden_cfg4_32768_rays_reduced_inference_class(npa, dev, nets):
+    """configs[3]'s 32,768-ray batch in one chunk -- the fixture that found bf16x3's flip ray #32156 (run_nerf.py:277-278, :293)"""
+    n = 32768
+    torch.manual_seed(2024)
+    rnd = {"t_rand": torch.rand(n, 64), "u": torch.rand(n, 128)}
+    import test_gpu_parity as tp
+    keep = tp._golden_randoms
+    tp._golden_randoms = lambda seed, n_, args: rnd          # this fixture's draw order: t_rand [32768, 64] then u [32768, 128]
+    try:
+        _check_golden_forward_reduced(npa, dev, nets, "lego_cfg4_forward", dict(perturb=1.0), 2024, render=(orc.LEGO, orc.lego_batch(n, seed=19)), n=n)
+    finally:
+        tp._golden_randoms = keep

@@ -567,12 +567,111 @@ def _check_golden(npa, dev, nets, name, kw, seed, precision="fp32", render=None,
     assert not fails, {k: report[k] for k in fails}
 
 
+# ---- the reduced INFERENCE class (fp16_fp8c: fp16 main term + fp8 correction terms, ~2^-15 per product, no_grad rendering only) against
+# the same reference-produced fixtures, forward maps only.  Coarse-pass quantities per ray (measured bound, 10x above the three-term
+# fp16 class as the products are 2^7 coarser -- and counted against the fp16x3 bound as well), the fine pass in the p95 + worst-ray +
+# image form of the split datapaths, the image at >= 85 dB of the reference's, and the count of FLIP rays: rays whose last sample's
+# density changes sign under the datapath's rounding, which dists[-1] = 1e10 (run_nerf.py:277-278) turns into a step of the ray's
+# opacity (bf16x3 has three of them among 32,768 rays).  The reduced class evaluates every ray's last sample on the three-term
+# products (the guard launch), so the expected count is 0.
+REDUCED_TOL = dict(coarse=3e-4, fine_floor=3e-4, fine_max=5e-3, zstd_floor=1e-3, raw_floor=2e-2, disp_rel=1e-3, img_psnr_db=85.0, flip=1e-2)
+
+
+def _check_golden_forward_reduced(npa, dev, nets, name, kw, seed, render=None, n=256, raw_ray_stride=1, tol=None):
+    """no_grad render_rays / render() on the reduced inference class vs the reference's forward maps of fixture `name`"""
+    nc, nf, Pc, Pf = nets
+    T = dict(REDUCED_TOL, **(tol or {}))
+    gold = np.load(f"{GOLD}/{name}.npz")
+    args = dict(N_samples=64, retraw=True, N_importance=128, network_fine=nf, perturb=0., white_bkgd=True, raw_noise_std=0., lindisp=False)
+    args.update(kw)
+    n_f = args["N_importance"]
+    randoms = _golden_randoms(seed, n, args)
+    npa.set_precision("fp16_fp8c")
+    try:
+        with torch.no_grad():
+            if render is None:
+                rays = orc.synthetic_rays(n, seed=7)
+                assert abs(float(rays.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-6
+                out = npa.render_rays(rays.to(dev), nc, None, randoms=randoms, **args)
+            else:
+                cfg, batch = render
+                assert abs(float(batch.double().abs().sum()) - float(gold["rays_checksum"])) < 1e-4
+                H, W, K = (800, 800, orc.intrinsics(dict(orc.LEGO, H=800, W=800, focal=1111.0))) if n > 4096 else (cfg["H"], cfg["W"], orc.intrinsics(cfg))
+                rgb, disp, acc, extras = npa.render(H, W, K, chunk=1024 * 32, rays=batch.to(dev), ndc=cfg["ndc"], near=cfg["near"], far=cfg["far"],
+                                                    use_viewdirs=True, network_fn=nc, network_query_fn=None, randoms=randoms, **args)
+                out = dict(extras, rgb_map=rgb, disp_map=disp, acc_map=acc)
+                rays = orc.assemble_render_rays(H, W, K, batch[0], batch[1], cfg["ndc"], cfg["near"], cfg["far"])
+    finally:
+        npa.set_precision("fp32")
+    out = {k: v.detach().cpu() for k, v in out.items()}
+    stable = torch.ones(n, dtype=torch.bool)
+    if n_f > 0 and args["perturb"] == 0.:
+        o = orc.trace_rays(rays, Pc, Pf, 64, n_f, perturb=0., white_bkgd=args["white_bkgd"], lindisp=args["lindisp"])
+        stable = ~orc.endpoint_unstable(o["_weights0"])
+    noise = lambda k: float(gold["noise/" + k]) if ("noise/" + k) in gold.files else 0.0
+    report, fails = {}, []
+
+    def per_ray(a, b):
+        d = (a.double() - b.double()).abs()
+        d = d.masked_fill(torch.isnan(a) & torch.isnan(b), 0.0).nan_to_num(nan=float("inf"))
+        return d.reshape(d.shape[0], -1).max(-1)[0]
+    flips = torch.zeros(n, dtype=torch.bool)
+    for k in (("rgb0", "acc0") if n_f > 0 else ("rgb_map", "acc_map")):       # the coarse pass (no hierarchical sampling upstream): per ray
+        if k not in gold.files:
+            continue
+        err = per_ray(out[k], torch.tensor(gold[k]))
+        report[k] = float(err.max())
+        report[k + " rays over the fp16x3 bound"] = int((err > GOLD_TOL["fp16x3"]["coarse"]).sum())
+        flips |= err > T["flip"]
+        if report[k] > T["coarse"]:
+            fails.append(k)
+    report["flip rays"] = int(flips.sum())
+    if report["flip rays"]:
+        fails.append("flip rays")
+    if n_f > 0:
+        for k in ("rgb_map", "acc_map", "z_std"):
+            if k not in gold.files:
+                continue
+            err = per_ray(out[k][stable], torch.tensor(gold[k])[stable])
+            floor = T["zstd_floor"] if k == "z_std" else T["fine_floor"]
+            report[k + " p95"] = float(torch.quantile(err, 0.95))
+            report[k + " max"] = float(err.max())
+            if report[k + " p95"] > max(floor, 10 * noise(k)):
+                fails.append(k + " p95")
+            if report[k + " max"] > max(T["fine_max"], 10 * noise(k), 1e-2 if k == "z_std" else 0.0):
+                fails.append(k + " max")
+    if "raw" in gold.files:
+        graw = torch.tensor(gold["raw"])
+        err = per_ray(out["raw"][::raw_ray_stride, ::8][stable[::raw_ray_stride]], graw[stable[::raw_ray_stride]])
+        report["raw p95"] = float(torch.quantile(err, 0.95)) if n_f > 0 else float(err.max())
+        if report["raw p95"] > max(T["raw_floor"] * max(1.0, float(graw.abs().max()) / 10), 10 * noise("raw")):
+            fails.append("raw p95")
+    mse_img = float(((out["rgb_map"].double() - torch.tensor(gold["rgb_map"]).double()) ** 2).mean())
+    report["psnr_vs_ref_dB"] = orc.psnr(max(mse_img, 1e-30))
+    if report["psnr_vs_ref_dB"] < T["img_psnr_db"]:
+        fails.append("psnr_vs_ref_dB")
+    print(name, "fp16_fp8c", report)
+    assert not fails, {k: report.get(k) for k in fails}
+
+
 PARITY_DATAPATHS = ["fp32", "bf16x3", "fp16x3"]
 
 
 @pytest.mark.parametrize("precision", PARITY_DATAPATHS)
 def test_golden_lego_det(npa, dev, nets, precision):
     _check_golden(npa, dev, nets, "lego_det", {}, None, precision)
+
+
+def test_golden_lego_det_reduced_inference_class(npa, dev, nets):
+    _check_golden_forward_reduced(npa, dev, nets, "lego_det", {}, None)
+
+
+def test_golden_fern_train_reduced_inference_class(npa, dev, nets):
+    _check_golden_forward_reduced(npa, dev, nets, "fern_train", dict(perturb=1.0, raw_noise_std=1.0, white_bkgd=False, N_importance=64, lindisp=True), 321)
+
+
+def test_golden_coarse_only_reduced_inference_class(npa, dev, nets):
+    _check_golden_forward_reduced(npa, dev, nets, "lego_coarse_only", dict(perturb=1.0, N_importance=0, network_fine=None), 11)
 
 
 @pytest.mark.parametrize("precision", PARITY_DATAPATHS)

@@ -154,3 +154,49 @@ def test_shard_slice_requires_even_split():
     with pytest.raises(ValueError):
         parallel.shard_slice(10, 0, 4)
     assert parallel.frames_of_rank(40, 3, 8) == [3, 11, 19, 27, 35]
+
+
+def _forced_worker(q):
+    """one rank, NERF_FORCE_PROCESS_GROUP semantics (init_distributed(force_group=True)): every collective runs over the one-rank group"""
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    import sys
+    import nerf_pytorch_amd as npa
+    from nerf_pytorch_amd import parallel
+    assert parallel._single() and parallel.ranks_seen() == [0]
+    r, w, dev = parallel.init_distributed(backend="gloo", force_group=True)
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1 and not parallel._single()
+    render = sys.modules[parallel.__name__.rsplit(".", 1)[0] + ".render"]
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    net = npa.NeRF(**kw)
+    net._packed, net._packed_key = {"fp32": "stale repack"}, ("stale",)
+    parallel.broadcast_parameters([net])
+    assert net._packed is None                      # the broadcast ran (and dropped the cached repack)
+    sync = parallel.GradientSync([net])
+    flat = torch.arange(npa.hip_backend.N_PARAMS, dtype=torch.float32)
+    want = flat.clone()
+    render._grad_ready(net, flat)
+    assert sync.started == 1 and id(net) in sync.pending        # a real (gloo) work object is pending
+    for nm, off, shape in npa.hip_backend.param_table():
+        dict(net.named_parameters())[nm].grad = flat[off:off + int(np.prod(shape))].view(shape)
+    net.last_flat_grad = flat
+    sync.finish()
+    sync.close()
+    ok = bool(torch.equal(flat, want))               # sum over one rank / 1
+    seen, same = parallel.ranks_seen(), parallel.ranks_identical([net.flat_params()])
+    dist.destroy_process_group()
+    q.put((ok, seen, same))
+
+
+@pytest.mark.timeout(300)
+def test_forced_one_rank_group_runs_the_collectives():
+    """NERF_FORCE_PROCESS_GROUP / init_distributed(force_group=True): the world-size-1 short cuts are off (the 1-GPU box executes
+    the RCCL branch this way, tests/test_rccl_one_rank_gpu.py; here over gloo)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(q,))
+    p.start()
+    ok, seen, same = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert ok and seen == [0] and same is True
