@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 8
+#define NERF_ABI_VERSION 9
 #define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
 
@@ -100,6 +100,13 @@ size_t nerf_act_floats(int n_rays, int n_samples);
  * owns this memory (persistent across steps; any datapath); 0 when training == 0 -- inference needs no scratch.
  * = nerf_act_floats(coarse) + nerf_act_floats(fine) + nerf_delta_floats(larger) + nerf_wgrad_partial_floats(larger). */
 size_t nerf_workspace_floats(int n_rays, int n_coarse, int n_fine, int training);
+/* The same three sizes for ONE datapath (ABI v9).  datapath: 0 = exact fp32 (fp32 rows, 10.6 KB / point each way), 1 = the split
+ * datapaths (16-bit tiles of either type, 4.8 / 4.4 KB / point); the two-argument forms above return the larger of the two, i.e. a
+ * buffer any datapath may write.  A caller that knows its datapath keeps ~2.2x more rays resident per GB of HBM with these:
+ * the 32,768-ray batch of BASELINE configs[3] holds ~40 GB of saved activations on the split datapaths instead of ~90 GB. */
+size_t nerf_act_floats_dp(int n_rays, int n_samples, int datapath);
+size_t nerf_delta_floats_dp(int n_rays, int n_samples, int datapath);
+size_t nerf_workspace_floats_dp(int n_rays, int n_coarse, int n_fine, int training, int datapath);
 int nerf_field_fwd(const float* packed, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                    int n_samples, float* raw, float* act, void* stream);
 

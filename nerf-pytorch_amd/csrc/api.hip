@@ -149,16 +149,22 @@ int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const floa
                                                      z_vals, (hipStream_t)stream));
 }
 
-size_t nerf_act_floats(int n_rays, int n_samples) {
-    if (n_rays <= 0 || n_samples <= 0) return 0;
-    const size_t P = (size_t)n_rays * n_samples;      // covers both datapaths' layouts
-    const size_t a = nerf::act_layout(P, (size_t)n_rays).total, b = nerf::act_layout3(P, (size_t)n_rays).total;
+size_t nerf_act_floats_dp(int n_rays, int n_samples, int datapath) {
+    if (n_rays <= 0 || n_samples <= 0 || datapath < 0 || datapath > 1) return 0;
+    const size_t P = (size_t)n_rays * n_samples;
+    return datapath == 0 ? nerf::act_layout(P, (size_t)n_rays).total : nerf::act_layout3(P, (size_t)n_rays).total;
+}
+size_t nerf_delta_floats_dp(int n_rays, int n_samples, int datapath) {
+    if (n_rays <= 0 || n_samples <= 0 || datapath < 0 || datapath > 1) return 0;
+    const size_t P = (size_t)n_rays * n_samples;
+    return datapath == 0 ? nerf::delta_layout(P).total : nerf::delta_layout3(P).total;
+}
+size_t nerf_act_floats(int n_rays, int n_samples) {       // a buffer either datapath may write
+    const size_t a = nerf_act_floats_dp(n_rays, n_samples, 0), b = nerf_act_floats_dp(n_rays, n_samples, 1);
     return a > b ? a : b;
 }
 size_t nerf_delta_floats(int n_rays, int n_samples) {
-    if (n_rays <= 0 || n_samples <= 0) return 0;
-    const size_t P = (size_t)n_rays * n_samples;
-    const size_t a = nerf::delta_layout(P).total, b = nerf::delta_layout3(P).total;
+    const size_t a = nerf_delta_floats_dp(n_rays, n_samples, 0), b = nerf_delta_floats_dp(n_rays, n_samples, 1);
     return a > b ? a : b;
 }
 size_t nerf_wgrad_partial_floats(int n_rays, int n_samples) {
@@ -171,6 +177,12 @@ size_t nerf_workspace_floats(int n_rays, int n_coarse, int n_fine, int training)
     const int s_big = n_coarse + n_fine;
     return nerf_act_floats(n_rays, n_coarse) + (n_fine > 0 ? nerf_act_floats(n_rays, s_big) : 0) +
            nerf_delta_floats(n_rays, s_big) + nerf_wgrad_partial_floats(n_rays, s_big);
+}
+size_t nerf_workspace_floats_dp(int n_rays, int n_coarse, int n_fine, int training, int datapath) {
+    if (!training || n_rays <= 0 || n_coarse <= 0 || n_fine < 0 || datapath < 0 || datapath > 1) return 0;
+    const int s_big = n_coarse + n_fine;
+    return nerf_act_floats_dp(n_rays, n_coarse, datapath) + (n_fine > 0 ? nerf_act_floats_dp(n_rays, s_big, datapath) : 0) +
+           nerf_delta_floats_dp(n_rays, s_big, datapath) + nerf_wgrad_partial_floats(n_rays, s_big);
 }
 
 int nerf_debug_layout(int n_rays, int n_samples, int family, int is_delta, long long* out_host) {

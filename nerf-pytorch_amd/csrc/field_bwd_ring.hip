@@ -178,7 +178,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
         for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
-        store_region = (size_t)l * pad32(P) * W;                            // dl.h[l]: delta of layer l = input of this step
+        store_region = (size_t)l * region_words3(pad32(P), W);              // dl.h[l]: delta of layer l = input of this step
         ring_units<SP, 32, 2, 0, false, NP>(ring, fa, fb, fl, acc, d, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
             constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;        // unit 0..31: 128 values -> 4 per unit
 #pragma unroll

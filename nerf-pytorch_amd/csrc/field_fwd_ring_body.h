@@ -73,7 +73,7 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     // plus a 32-bit byte offset of the lane that does not change along the trunk -- no per-lane 64-bit pointers are carried
     // (the launchers refuse to save more than 2^26 points per launch, so the lane offsets fit 32 bits).
     ActLayout3 al{};
-    const size_t layer_floats = pad32((size_t)P) * W;
+    const size_t layer_floats = region_words3(pad32((size_t)P), W);       // words of one 256-wide region of 16-bit rows (== al.h[1] - al.h[0])
     const unsigned odd = (unsigned)lane & 1u;
     const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;      // v_perm_b32 bytes of {neighbour word, own word}
     const unsigned lane_pair_bytes = 4u * (unsigned)((2 * q + (int)odd) * 8 + ((lane & 15) >> 1));

@@ -239,12 +239,20 @@ __host__ __device__ inline size_t tile_index(size_t p, int F, int f) { return (p
 //     element (p, f): 2-byte index (p >> 4) * F * 16 + row16h(f) * 16 + (p & 15)
 __host__ __device__ constexpr int row16h(int f) { return (f & ~15) + 8 * ((f >> 1) & 1) + 2 * ((f >> 2) & 3) + (f & 1); }
 
+// Offsets are in 32-bit words (the buffers are float* at the C ABI); a region of F 16-bit features holds Pp * F / 2 words -- rounds
+// 1-4 sized these regions as if their elements were fp32 (twice the bytes), round 5 sizes them for what they hold: 4.8 KB / point
+// saved, 4.4 KB / point of deltas, 40 GB instead of 90 GB for the 32,768-ray batch of BASELINE configs[3].
+constexpr size_t DUMP_WORDS3 = 8192;     // >= one 32-point tile of 256 16-bit features (4096 words)
+__host__ __device__ constexpr size_t region_words3(size_t Pp, int F) { return Pp * (size_t)(F / 2); }
 struct ActLayout3 {
-    size_t h[D], feat;  // tiles of 256 features
+    size_t h[D];        // tiles of 256 features (16-bit elements)
+    size_t feat;        // DUMP_WORDS3 words nobody reads: waves whose tile lies beyond the padded point range store here
+    //                    (unconditional stores, split_types.h) -- the feature layer itself is folded, it saves nothing
     size_t hv;          // tiles of 128
     size_t enc;         // tiles of 64 (canonical column order, feature 63 unused)
-    size_t dir;         // [N][32] per ray, row-major (written by the forward)
-    size_t dir_pt;      // tiles of 32: the same per point, expanded right before the weight-gradient GEMM
+    size_t dir;         // [N][32] fp32 per ray, row-major (written by the forward)
+    size_t dir_pt;      // 16-bit tiles of 32: the same per point (or [N][32][8 copies] when a ray's samples fill whole tiles), expanded
+    //                    right before the weight-gradient GEMM
     size_t mask;        // [9][P][2] x 128 ReLU sign bits in the lane order of the split kernels (9th = view branch)
     size_t total;
 };
@@ -252,12 +260,13 @@ __host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N) {
     ActLayout3 a{};
     const size_t Pp = pad32(P);
     size_t o = 0;
-    for (int i = 0; i < D; ++i) { a.h[i] = o; o += Pp * W; }
-    a.feat = o; o += Pp * W;
-    a.hv = o;   o += Pp * WV;
-    a.enc = o;  o += Pp * 64;
+    for (int i = 0; i < D; ++i) { a.h[i] = o; o += region_words3(Pp, W); }
+    a.feat = o; o += DUMP_WORDS3;
+    a.hv = o;   o += region_words3(Pp, WV);
+    a.enc = o;  o += region_words3(Pp, 64);
     a.dir = o;  o += N * 32;
-    a.dir_pt = o; o += Pp * 32;
+    const size_t per_point = region_words3(Pp, 32), per_ray = N * 32 * 4;     // [N][32] x 8 copies x 2 bytes
+    a.dir_pt = o; o += per_point > per_ray ? per_point : per_ray;
     o = (o + 3) & ~(size_t)3;
     a.mask = o; o += (size_t)(D + 1) * P * 8;
     o += 2048;          // slack for the weight-gradient staging's reads past a narrow operand's last tile
@@ -268,15 +277,15 @@ __host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N) {
 // (delta_amax_kernel, field_bwd_ring.hip) -- the fp16 split's delta chain runs on s * d_raw, s = delta_scale_of(max) an exact
 // power of two, so that the deltas sit in fp16's range; every stored delta and every partial weight gradient carries the factor
 // s, wgrad_reduce_kernel removes it (both kernels derive s / 1/s from the same word).
-struct DeltaLayout3 { size_t h[D], feat, hv, graw, scale, total; };
+struct DeltaLayout3 { size_t h[D], feat, hv, graw, scale, total; };       // feat: dump region, as in ActLayout3
 __host__ __device__ inline DeltaLayout3 delta_layout3(size_t P) {
     DeltaLayout3 a{};
     const size_t Pp = pad32(P);
     size_t o = 0;
-    for (int i = 0; i < D; ++i) { a.h[i] = o; o += Pp * W; }
-    a.feat = o; o += Pp * W;
-    a.hv = o;   o += Pp * WV;
-    a.graw = o; o += Pp * 4;
+    for (int i = 0; i < D; ++i) { a.h[i] = o; o += region_words3(Pp, W); }
+    a.feat = o; o += DUMP_WORDS3;
+    a.hv = o;   o += region_words3(Pp, WV);
+    a.graw = o; o += region_words3(Pp, 4);
     o += 2048;          // the weight-gradient staging reads 64 rows of 128 B from a tile of this 4-row region
     a.scale = o; o += 4;
     a.total = o;

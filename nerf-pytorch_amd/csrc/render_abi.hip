@@ -23,7 +23,8 @@ struct RenderWs {
     size_t zero_rgb;                // training only: [N][3] zeros, the d_rgb of a pass that receives only d_disp / d_acc
     size_t total;
 };
-RenderWs render_ws(int n_rays, int Sc, int Sf, int training) {
+RenderWs render_ws(int n_rays, int Sc, int Sf, int training, int precision) {
+    const int dp = precision == 0 ? 0 : 1;          // scratch regions sized for the configured datapath (16-bit tiles on the split ones)
     RenderWs w{};
     const size_t N = (size_t)n_rays;
     const int S2 = Sc + Sf;
@@ -35,10 +36,10 @@ RenderWs render_ws(int n_rays, int Sc, int Sf, int training) {
     w.w_c = o;   o += up4(N * Sc);
     w.z_f = o;   o += up4(Sf > 0 ? N * S2 : 0);
     if (training) {
-        w.act_c = o; o += up4(nerf_act_floats(n_rays, Sc));
-        w.act_f = o; o += up4(Sf > 0 ? nerf_act_floats(n_rays, S2) : 0);
+        w.act_c = o; o += up4(nerf_act_floats_dp(n_rays, Sc, dp));
+        w.act_f = o; o += up4(Sf > 0 ? nerf_act_floats_dp(n_rays, S2, dp) : 0);
         w.d_raw = o; o += up4(N * (size_t)S2 * 4);
-        w.delta = o; o += up4(nerf_delta_floats(n_rays, S2));
+        w.delta = o; o += up4(nerf_delta_floats_dp(n_rays, S2, dp));
         w.partial = o; o += up4(nerf_wgrad_partial_floats(n_rays, S2));
         w.zero_rgb = o; o += up4(N * 3);
     }
@@ -104,7 +105,7 @@ extern "C" {
 
 size_t nerf_render_workspace_floats(const NerfRenderCfg* cfg, int n_rays, int training) {
     if (!cfg_ok(cfg) || n_rays <= 0) return 0;
-    return render_ws(n_rays, cfg->n_coarse, cfg->n_fine, training).total;
+    return render_ws(n_rays, cfg->n_coarse, cfg->n_fine, training, cfg->precision).total;
 }
 
 int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const float* packed_f, const float* rays, int ray_stride,
@@ -123,7 +124,7 @@ int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const 
             (reinterpret_cast<uintptr_t>(packed_c) & 15) == 0, "workspace / raw / packed must be 16-byte aligned");
     if (n_rays == 0) return 0;
     const float* pf = (fine && packed_f) ? packed_f : packed_c;          // network_fine == None: the coarse network (run_nerf.py:400)
-    const RenderWs w = render_ws(n_rays, Sc, Sf, training);
+    const RenderWs w = render_ws(n_rays, Sc, Sf, training, cfg->precision);
     hipStream_t st = (hipStream_t)stream;
     float* ws = workspace;
     hipLaunchKernelGGL(linspace01_kernel, dim3((Sc + 255) / 256), dim3(256), 0, st, ws + w.t_lin, Sc);
@@ -180,7 +181,7 @@ int nerf_render_rays_infer(const NerfRenderCfg* cfg, const float* packed_c, cons
     REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(packed_c) & 15) == 0, "workspace / raw / packed must be 16-byte aligned");
     if (n_rays == 0) return 0;
-    const RenderWs w = render_ws(n_rays, Sc, Sf, 0);
+    const RenderWs w = render_ws(n_rays, Sc, Sf, 0, cfg->precision);
     float* ws = workspace;
     const bool noisy = cfg->raw_noise_std > 0.0f;
     nerf::RenderInferArgs a{};
@@ -212,7 +213,7 @@ int nerf_render_rays_bwd(const NerfRenderCfg* cfg, const float* packed_c, const 
     const bool fine = Sf > 0;
     const bool same_net = !fine || !packed_f || packed_f == packed_c;
     REQUIRE(same_net || (grad_f && (cfg->precision == 0 || params_f)), "a separate fine network needs grad_f (and params_f)");
-    const RenderWs w = render_ws(n_rays, Sc, Sf, 1);
+    const RenderWs w = render_ws(n_rays, Sc, Sf, 1, cfg->precision);
     hipStream_t st = (hipStream_t)stream;
     float* ws = workspace;
     hipError_t e;

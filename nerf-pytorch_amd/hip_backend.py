@@ -15,7 +15,7 @@ from . import build as _build
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
-ABI_VERSION = 8        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
+ABI_VERSION = 9        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
 
 
 class NerfHipError(RuntimeError):
@@ -41,6 +41,9 @@ def _declare(lib):
         "nerf_debug_layout": (i, [i, i, i, i, ctypes.POINTER(ctypes.c_longlong)]),
         "nerf_act_floats": (sz, [i, i]),
         "nerf_workspace_floats": (sz, [i, i, i, i]),
+        "nerf_act_floats_dp": (sz, [i, i, i]),
+        "nerf_delta_floats_dp": (sz, [i, i, i]),
+        "nerf_workspace_floats_dp": (sz, [i, i, i, i, i]),
         "nerf_field_fwd": (i, [p, p, i, p, i, i, p, p, p]),
         "nerf_raw2outputs": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p, p]),
         "nerf_raw2outputs_bwd": (i, [p, p, p, i, i, i, p, f, i, p, p, p, p, p, p, p]),
@@ -83,7 +86,7 @@ def _declare(lib):
 
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
            "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_sample_ray_batch", "nerf_buffer_layout", "nerf_debug_layout", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
-           "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats",
+           "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats", "nerf_act_floats_dp", "nerf_delta_floats_dp", "nerf_workspace_floats_dp",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_debug_pack3_table",
            "nerf_field_wgrad_phase", "nerf_debug_pack16_table",
@@ -350,9 +353,26 @@ def sample_ray_batch(H, W, K, pose, image, n_rand, window, key, want_pixels=Fals
     return (rays, target, pix) if want_pixels else (rays, target)
 
 
-def act_floats(n_rays, n_samples, precision="fp32"):
-    """floats of a save buffer for this datapath (nerf_act_floats: the fp32 datapath's fp32 rows are the largest layout)"""
-    return lib().nerf_act_floats(n_rays, n_samples)
+def _dp(precision):
+    """datapath index of the *_dp size entry points: 0 = fp32 rows, 1 = 16-bit tiles of the split datapaths"""
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}")
+    return 0 if precision == "fp32" else 1
+
+
+def act_floats(n_rays, n_samples, precision=None):
+    """floats of a save buffer: for `precision`'s layout (fp32 rows: 10.6 KB / point; split datapaths' 16-bit tiles: 4.8 KB / point), or,
+    without a precision, the larger of the two (a buffer any datapath may write)"""
+    if precision is None:
+        return lib().nerf_act_floats(int(n_rays), int(n_samples))
+    return lib().nerf_act_floats_dp(int(n_rays), int(n_samples), _dp(precision))
+
+
+def delta_floats(n_rays, n_samples, precision=None):
+    """floats of the delta scratch of one backward pass (see act_floats)"""
+    if precision is None:
+        return lib().nerf_delta_floats(int(n_rays), int(n_samples))
+    return lib().nerf_delta_floats_dp(int(n_rays), int(n_samples), _dp(precision))
 
 
 class Workspace:
@@ -404,20 +424,23 @@ SAVE_BUDGET_BYTES = int(float(os.environ.get("NERF_SAVE_BUDGET_GB", "48")) * (1 
 SAVE_TOTAL_BYTES = int(float(os.environ.get("NERF_SAVE_TOTAL_GB", "160")) * (1 << 30))
 
 
-def workspace_floats(n_rays, n_coarse, n_fine, training=True):
-    """nerf_workspace_floats(): floats of scratch one training render_rays call needs (saved activations of both
-    passes + deltas + partial gradients of the larger pass); 0 for inference."""
-    return lib().nerf_workspace_floats(int(n_rays), int(n_coarse), int(n_fine), int(bool(training)))
+def workspace_floats(n_rays, n_coarse, n_fine, training=True, precision=None):
+    """nerf_workspace_floats[_dp](): floats of scratch one training render_rays call needs (saved activations of both
+    passes + deltas + partial gradients of the larger pass) on `precision`'s layouts (None: the larger of the two); 0 for inference."""
+    if precision is None:
+        return lib().nerf_workspace_floats(int(n_rays), int(n_coarse), int(n_fine), int(bool(training)))
+    return lib().nerf_workspace_floats_dp(int(n_rays), int(n_coarse), int(n_fine), int(bool(training)), _dp(precision))
 
 
-def max_saved_rays(n_coarse, n_fine):
+def max_saved_rays(n_coarse, n_fine, precision=None):
     """Largest ray count whose backward scratch fits SAVE_BUDGET_BYTES (multiple of 1024, at least 1024): larger ray
-    chunks are back-propagated in sub-chunks of this size with the forward recomputed (render._RenderRays)."""
-    per_1024 = 4 * workspace_floats(1024, n_coarse, n_fine, True)
+    chunks are back-propagated in sub-chunks of this size (render._RenderRays).  64 + 128 samples under the default 48 GiB:
+    10,240 rays on fp32 rows, 22,528 on the split datapaths' 16-bit tiles."""
+    per_1024 = 4 * workspace_floats(1024, n_coarse, n_fine, True, precision)
     return max(1, SAVE_BUDGET_BYTES // max(per_1024, 1)) * 1024
 
 
-def saved_bytes(n_rays, n_coarse, n_fine, precision="fp32"):
+def saved_bytes(n_rays, n_coarse, n_fine, precision=None):
     """bytes of saved activations (both passes) a training render_rays call over n_rays keeps until its backward"""
     return 4 * (act_floats(n_rays, n_coarse, precision) + (act_floats(n_rays, n_coarse + n_fine, precision) if n_fine > 0 else 0))
 
@@ -527,6 +550,9 @@ def delta_scale_word(buf, n_rays, n_samples):
 # chain of launches and as fast or faster for every ray count measured).  NERF_INFER_ONE_LAUNCH=0 keeps the chain:
 # sample_coarse -> field forward -> composite -> sample_fine -> field forward -> composite
 INFER_ONE_LAUNCH = os.environ.get("NERF_INFER_ONE_LAUNCH", "1") != "0"
+# the reduced inference class ("fp16_fp8c") evaluates the COARSE pass of a coarse + fine rendering on the three-term fp16 products
+# (render._field_pass); NERF_REDUCED_COARSE=reduced keeps round 4's all-reduced chain (with its two-pass last-sample guard)
+REDUCED_COARSE_THREE_TERM = os.environ.get("NERF_REDUCED_COARSE", "fp16x3") != "reduced"
 
 
 def render_cfg(n_coarse, n_fine, lindisp, white_bkgd, raw_noise_std, precision):
@@ -584,7 +610,7 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32", guard_pack
         raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
     elif tuple(raw.shape) != (n, S, 4) or raw.dtype != torch.float32 or not raw.is_contiguous():
         raise NerfHipError(f"field_fwd: raw= must be a contiguous float32 [{n}, {S}, 4] tensor")
-    act = WORKSPACE.take(act_floats(n, S), rays.device) if save_act else None
+    act = WORKSPACE.take(act_floats(n, S, precision), rays.device) if save_act else None
     nbytes = BYTES_ACT_PER_POINT * n * S if save_act else 16.0 * n * S
     if precision in SPLIT:
         nbytes = BYTES_ACT3_PER_POINT * n * S if save_act else 16.0 * n * S
@@ -682,7 +708,7 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32", params=Non
     n, S, _ = d_raw.shape
     L = lib()
     dev = d_raw.device
-    delta = WORKSPACE.take(L.nerf_delta_floats(n, S), dev)
+    delta = WORKSPACE.take(delta_floats(n, S, precision), dev)
     partial = WORKSPACE.take(L.nerf_wgrad_partial_floats(n, S), dev)
     try:
         return _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S, params)

@@ -137,14 +137,21 @@ def _field_pass(cfg, rays, rnd, model_c, model_f, save):
     std, wb, prec = cfg["raw_noise_std"], cfg["white_bkgd"], cfg.get("precision", "fp32")
     r = {}
     guard = (lambda m: m.packed_params("fp16x3")) if prec == "fp16_fp8c" else (lambda m: None)
-    r["packed_c"] = model_c.packed_params(prec)
     r["z_c"] = hb.sample_coarse(rays, _linspace01(n_c, dev), cfg["lindisp"], rnd.get("t_rand"))
     mf = model_c if (model_f is None or model_f is model_c) else model_f
     nxt = raw_f = None
-    if prec == "fp16_fp8c" and n_f > 0:     # the guard launch of the coarse pass also evaluates the fine pass's last sample (hb.field_fwd)
+    # The reduced inference class with a refining pass: hierarchical sampling divides by ~1e-5 in bins the coarse pass found empty
+    # (run_nerf_helpers.py:234-236), so a 2^-15 perturbation of the coarse weights moves single fine samples by whole bins -- measured
+    # on the reference's fixtures at BASELINE's batch sizes: no flipped ray, but images at 62-79 dB of the reference's instead of
+    # fp16x3's 89-120 dB (tools/EXPERIMENTS.md, round 5).  The coarse pass (a quarter of the points) therefore runs on the three-term
+    # products and only the refining pass (whose errors reach the image unamplified) on the reduced ones.
+    prec_c = "fp16x3" if (prec == "fp16_fp8c" and n_f > 0 and hb.REDUCED_COARSE_THREE_TERM) else prec
+    r["packed_c"] = model_c.packed_params(prec_c)
+    if prec_c == "fp16_fp8c" and n_f > 0:     # the guard launch of the coarse pass also evaluates the fine pass's last sample (hb.field_fwd)
         raw_f = torch.empty((rays.shape[0], n_c + n_f, 4), dtype=torch.float32, device=dev)
         nxt = (guard(mf), raw_f)
-    r["raw_c"], r["act_c"] = hb.field_fwd(r["packed_c"], rays, r["z_c"], save_act=save, precision=prec, guard_packed=guard(model_c), next_guard=nxt)
+    r["raw_c"], r["act_c"] = hb.field_fwd(r["packed_c"], rays, r["z_c"], save_act=save, precision=prec_c,
+                                          guard_packed=guard(model_c) if prec_c == "fp16_fp8c" else None, next_guard=nxt)
     r["rgb_c"], r["disp_c"], r["acc_c"], w_c, _ = hb.raw2outputs(r["raw_c"], r["z_c"], rays, rays.shape[1], rnd.get("noise_c"), std, wb,
                                                               want_weights=n_f > 0, want_depth=False, rays_d_offset=3)
     if n_f <= 0:
@@ -173,12 +180,13 @@ LAST_BACKWARD_PLAN = None
 class _RenderRays(torch.autograd.Function):
     """The whole of render_rays (run_nerf.py:308-418) as one autograd node.
 
-    Memory: the backward needs up to ~10.7 KB of saved activations per sample point (plus as much for the deltas).  Up to
-    hb.max_saved_rays(...) rays per call (default budget 48 GiB: ~10k rays at 64+128 samples, i.e. every N_rand of the
-    BASELINE configs) they are saved by the forward into buffers leased from hb.WORKSPACE (persistent across steps, no
-    per-step allocation).  Larger ray chunks (the reference's default chunk is 32768 rays) are rendered in equal
-    sub-chunks.  If the saved activations of ALL sub-chunks fit hb.SAVE_TOTAL_BYTES (default 160 GiB of the 288 GB: the
-    32768-ray batch of configs[3] needs ~90 GB) every sub-chunk keeps its own lease and the backward walks them: no
+    Memory: the backward needs 4.8 KB of saved activations per sample point on the split datapaths (16-bit tiles; 10.7 KB of fp32
+    rows on the fp32 datapath) plus as much for the deltas.  Up to hb.max_saved_rays(...) rays per call (default budget 48 GiB:
+    ~22k rays at 64+128 samples on the split datapaths, ~10k on fp32, i.e. every N_rand of the BASELINE configs) they are saved by
+    the forward into buffers leased from hb.WORKSPACE (persistent across steps, no per-step allocation).  Larger ray chunks (the
+    reference's default chunk is 32768 rays) are rendered in equal sub-chunks.  If the saved activations of ALL sub-chunks fit
+    hb.SAVE_TOTAL_BYTES (default 160 GiB of the 288 GB: the 32768-ray batch of configs[3] needs ~40 GB on the split datapaths,
+    ~90 GB on fp32) every sub-chunk keeps its own lease and the backward walks them: no
     recomputation, deltas and partial sums re-use one sub-chunk-sized scratch.  Beyond that the forward runs WITHOUT
     saving and the backward re-runs it, with saving, one sub-chunk at a time (the kernels are deterministic, so the
     recomputed pass is bit-identical to the first): bounded memory for +1 inference-speed forward."""
@@ -188,7 +196,7 @@ class _RenderRays(torch.autograd.Function):
         n_f = cfg["N_importance"]
         need = cfg["need_grad"]
         n = rays.shape[0]
-        sub = hb.max_saved_rays(cfg["N_samples"], n_f) if need else n
+        sub = hb.max_saved_rays(cfg["N_samples"], n_f, cfg.get("precision", "fp32")) if need else n
         ctx.checkpoint = bool(need and n > sub)
         ctx.tiles = None
         if ctx.checkpoint:

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/nerf_hip.h but not exported"
     assert declared == set(npa.hip_backend.EXPORTS), declared ^ set(npa.hip_backend.EXPORTS)
     L = npa.hip_backend.lib()
-    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 8 and L.nerf_param_count() == 595844
+    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 9 and L.nerf_param_count() == 595844
     assert L.nerf_packed_floats() % 4 == 0
 
 
@@ -34,9 +34,22 @@ def test_argument_errors_are_codes_not_crashes():
     assert L.nerf_act_floats(0, 64) == 0
     for n, S in ((4096, 192), (5, 3)):
         P = n * S
-        Pp = (P + 31) // 32 * 32       # the bf16x3 datapath saves 32-point tiles; the sizes cover both layouts
-        assert L.nerf_act_floats(n, S) == Pp * (9 * 256 + 128 + 64 + 32) + n * 32 + 9 * P * 8 + (-(Pp * 32 + n * 32) % 4) + 2048
-        assert L.nerf_delta_floats(n, S) == Pp * (9 * 256 + 128 + 4) + 2048 + 4        # + the fp16 split's scale words
+        Pp = (P + 31) // 32 * 32       # the split datapaths save 32-point tiles
+        # per-datapath sizes (ABI v9): fp32 rows [P][F] ...
+        a0 = P * (9 * 256 + 128 + 64 + 32) + n * 32
+        a0 = (a0 + 3) // 4 * 4 + 9 * P * 8
+        assert L.nerf_act_floats_dp(n, S, 0) == a0 and L.nerf_delta_floats_dp(n, S, 0) == P * (9 * 256 + 128)
+        # ... 16-bit tiles: 8 trunk regions + view branch + encoding + per-point direction tiles at 2 bytes per element, the dump
+        # region (8192 words), the per-ray fp32 direction encoding, bitmasks, 2048 words of staging slack
+        a1 = Pp * (8 * 256 + 128 + 64) // 2 + 8192 + n * 32 + max(Pp * 32 // 2, n * 32 * 4)
+        a1 = (a1 + 3) // 4 * 4 + 9 * P * 8 + 2048
+        assert L.nerf_act_floats_dp(n, S, 1) == a1
+        assert L.nerf_delta_floats_dp(n, S, 1) == Pp * (8 * 256 + 128 + 4) // 2 + 8192 + 2048 + 4      # + the fp16 split's scale words
+        # the two-argument forms: a buffer either datapath may write
+        assert L.nerf_act_floats(n, S) == max(a0, a1) and L.nerf_delta_floats(n, S) == max(L.nerf_delta_floats_dp(n, S, 0), L.nerf_delta_floats_dp(n, S, 1))
+        assert L.nerf_act_floats_dp(n, S, 2) == 0 and L.nerf_delta_floats_dp(n, S, -1) == 0
+    assert L.nerf_act_floats_dp(4096, 192, 1) < 0.5 * L.nerf_act_floats_dp(4096, 192, 0)            # 4.8 vs 10.6 KB / point
+    assert L.nerf_delta_floats_dp(4096, 192, 1) < 0.5 * L.nerf_delta_floats_dp(4096, 192, 0)
     assert (L.nerf_wgrad_partial_floats(n, S) - (128 * 256 + 128)) % 595844 == 0      # per-chunk partials + fold scratch (G | dbv)
 
 
@@ -365,6 +378,17 @@ def test_workspace_size_query_and_lease_pool():
         assert L.nerf_workspace_floats(n, sc, nf, 1) == want == npa.hip_backend.workspace_floats(n, sc, nf)
         assert L.nerf_workspace_floats(n, sc, nf, 0) == 0
     assert L.nerf_workspace_floats(0, 64, 128, 1) == 0
+    hb = npa.hip_backend
+    for dp, prec in ((0, "fp32"), (1, "fp16x3"), (1, "bf16x3"), (1, "fp16_fp8c")):
+        want = L.nerf_act_floats_dp(4096, 64, dp) + L.nerf_act_floats_dp(4096, 192, dp) + L.nerf_delta_floats_dp(4096, 192, dp) + L.nerf_wgrad_partial_floats(4096, 192)
+        assert L.nerf_workspace_floats_dp(4096, 64, 128, 1, dp) == want == hb.workspace_floats(4096, 64, 128, True, prec)
+        assert hb.act_floats(4096, 192, prec) == L.nerf_act_floats_dp(4096, 192, dp) and hb.delta_floats(4096, 192, prec) == L.nerf_delta_floats_dp(4096, 192, dp)
+    # the split datapaths keep twice the rays of the fp32 datapath per launch under the same budget, and the 32,768-ray batch of
+    # configs[3] stays under 50 GB of saved activations (fp32 rows: ~90 GB)
+    assert hb.max_saved_rays(64, 128, "fp16x3") >= 20480 and hb.max_saved_rays(64, 128, "fp32") >= 8192
+    assert hb.saved_bytes(32768, 64, 128, "fp16x3") <= 50e9 < hb.saved_bytes(32768, 64, 128, "fp32")
+    with pytest.raises(ValueError):
+        hb.act_floats(4, 4, "fp64")
     # the default budget (48 GiB) covers every N_rand of the BASELINE configs without recomputation
     assert npa.hip_backend.max_saved_rays(64, 128) >= 8192 and npa.hip_backend.max_saved_rays(64, 128) % 1024 == 0
     # ... and the 32,768-ray chunk of configs[3] keeps the saved activations of its four sub-chunks resident
