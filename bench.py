@@ -969,8 +969,10 @@ def main():
                    "kernels": {k: round(v["avg_ms"], 4) for k, v in kernel_table(kern_r).items()},
                    "what": "no_grad render() of the same 4096-ray batches under set_precision('fp16_fp8c'): every product of the 256-wide layers = "
                            "W_hi16 x_hi16 (fp16 MFMA) + W_hi8 x_lo8 + W_lo8 x_hi8 (fp8 e4m3 MFMAs, K = 128), ~2^-15 per product, 2 instead of 3 "
-                           "MFMA-equivalents; every ray's last sample evaluated with the three-term fp16 products (one guard launch for both "
-                           "passes); chain of 7 launches"}
+                           "MFMA-equivalents -- in the REFINING pass (three quarters of the points); the coarse pass runs on the three-term fp16 "
+                           "products (sample_pdf amplifies 2^-15 errors of the coarse weights: all-reduced images sit at 62-79 dB of the reference's "
+                           "on the 4096- / 32,768-ray fixtures, this form at 89-100 dB, tests/test_gpu_golden_cfg.py); every ray's last fine sample "
+                           "evaluated with the three-term products (guard launch); chain of 7 launches"}
             if default_run:     # BASELINE configs[4] on this class: 800x800 frames of the lego spiral
                 ef, _k = measure("fp16_fp8c", 2, 1, ses.frame_step, with_kernels=False)
                 out["render_only"] = {"rays_per_s": args.frame * args.frame * 2 / ef, "s_per_frame": ef / 2, "frame": args.frame, "chunk": args.chunk}
@@ -1033,12 +1035,15 @@ def main():
             big = Session("lego", args, rank, world, dev, N_RAND, True)
             try:
                 el, _ = measure(args.precision, 2, 1, big.train_step, with_kernels=False)
+                plan = sys.modules[npa.parallel.__name__.rsplit(".", 1)[0] + ".render"].LAST_BACKWARD_PLAN      # (npa.render is the function)
+                resident_gb = hb.saved_bytes(32768, N_SAMPLES, N_IMPORTANCE, args.precision) / 1e9
             finally:
                 big.close()
                 hb.WORKSPACE.clear()
                 torch.cuda.empty_cache()
-            return {"workload": "the 32,768-ray global batch of BASELINE configs[3] on ONE GPU (lego 64+128, training step; rendered in 4 "
-                                "sub-chunks of 8192 rays that all keep their saved activations: ~90 of the 288 GB)",
+            return {"workload": f"the 32,768-ray global batch of BASELINE configs[3] on ONE GPU (lego 64+128, training step; backward plan '{plan[0]}': "
+                                f"{-(-plan[1] // plan[2])} sub-chunk(s) of {plan[2]} rays that all keep their saved activations, {resident_gb:.1f} of the 288 GB)",
+                    "backward_plan": list(plan), "saved_activations_gb": resident_gb,
                     "value": 32768 * 2 / el, "unit": "rays/s", "steps": 2, "ms_per_step": 1e3 * el / 2, "precision_gate": lego_gate}
         def leg_coarse():
             # BASELINE configs[0] is the reference's CPU-plumbing configuration; its SHAPE on the GPU (no fine network: one pass, one

@@ -158,8 +158,8 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
  *   split = 0, T = bfloat16 ("bf16x3"): ~2^-17 per product, 8-bit saved operands; fp32's exponent range (no overflow possible).
  * Judged by the north-star PSNR criterion (measured: 4e-6 / 2.4e-4 dB) and by fp64 comparisons of the gradients (tests/).
  * Parameters are repacked into (hi, lo) fragment streams of nerf_packed3_floats() 32-bit words by nerf_pack_params_split
- * (streams = mask of 1: 16-point forward stream, 4: transposed streams of the delta chain -- 5 = everything these entry points read;
- * bits 2 / 8 write the streams of the superseded 32-point kernels, kept for the test-only reference library).  feature_linear is
+ * (streams = mask of 1: 16-point forward stream, 4: transposed streams of the delta chain -- 5 = everything these entry points
+ * read).  feature_linear is
  * FOLDED into the view branch: W' = Wv[:, :256] Wf, b' = Wv[:, :256] bf + bv are derived at pack time (helpers:111-115: no activation
  * between the two layers); `feature` and its delta are neither computed nor saved, and the weight-gradient entry point takes the
  * canonical parameter vector `params` (the one that was packed) to produce the gradients of Wf, bf and Wv[:, :256] from
@@ -177,6 +177,10 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
  * Replace run_nerf.py:37-51 + run_nerf_helpers.py:15-45, :96-119 and their autograd like nerf_field_fwd / nerf_field_bwd. */
 int nerf_packed3_floats(void);
 int nerf_pack_params_split(const float* params, float* packed3, int streams, int split, void* stream);
+/* the repack of TWO networks (a training step's coarse and fine network after the optimizer step) in the same two launches as one
+ * (ABI v9; split 0 / 1; results identical to two nerf_pack_params_split calls) */
+int nerf_pack_params_split_pair(const float* params_a, float* packed3_a, const float* params_b, float* packed3_b, int streams,
+                                int split, void* stream);
 int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                          int n_samples, float* raw, float* act /* nullable: inference */, int split, void* stream);
 int nerf_field_dgrad_split(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
@@ -238,8 +242,8 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
  * order the in-repo binding issues them, so the results are bit-identical to it.  What a host provides: the ray records, the
  * random draws in the reference's order (NULL where the reference draws nothing), the packed and canonical parameters, the
  * outputs, and ONE scratch buffer of nerf_render_workspace_floats() floats that lives from the forward to its backward
- * (depths, coarse raw, compositing weights; when training also the saved activations, deltas and partial gradients: ~23 KB
- * per sample point on the default datapath -- split larger ray batches, the reference's `chunk` argument does exactly that).
+ * (depths, coarse raw, compositing weights; when training also the saved activations, deltas and partial gradients: ~9.2 KB
+ * per sample point on the split datapaths, ~21 KB on fp32 -- split larger ray batches, the reference's `chunk` argument does exactly that).
  *   precision 0: exact fp32 datapath; 1: split-bf16; 3: split-fp16 (packed buffers from nerf_pack_params_split with the
  *   matching split; 16-bit operand storage of the weight-gradient GEMM either way).
  *   Backward with accumulate = 0: every gradient vector handed in is written -- a network whose pass received no upstream

@@ -413,6 +413,14 @@ int nerf_pack_params_split(const float* params, float* packed3, int streams, int
     return done(__func__, nerf::launch_pack3_sel(params, packed3, streams, (hipStream_t)stream, split));
 }
 
+int nerf_pack_params_split_pair(const float* params_a, float* packed3_a, const float* params_b, float* packed3_b, int streams, int split, void* stream) {
+    REQUIRE(params_a && packed3_a && params_b && packed3_b, "null pointer");
+    REQUIRE(packed3_a != packed3_b, "the two networks need their own packed buffers");
+    REQUIRE(streams >= 0 && (streams & ~5) == 0 && (split == 0 || split == 1), "streams is a mask of 1 (forward stream) and 4 (transposed streams); split 0 (bf16) or 1 (fp16)");
+    return done(__func__, nerf::launch_pack3_pair(params_a, packed3_a, params_b, packed3_b, streams, (hipStream_t)stream, split));
+}
+
+
 int nerf_mse_scratch_floats(void) { return nerf::MSE_SCRATCH_FLOATS; }
 int nerf_mse_fwd(const float* x, const float* y, long n, float* scratch, float* out, void* stream) {
     REQUIRE(x && y && scratch && out, "null pointer");

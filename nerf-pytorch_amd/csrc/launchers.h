@@ -88,6 +88,7 @@ void pack_table_host(int* out);
 void pack3_table_host(int* out);
 void pack16_table_host(int* out);
 hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream, int split = 0);
+hipError_t launch_pack3_pair(const float* params_a, float* packed_a, const float* params_b, float* packed_b, int streams, hipStream_t stream, int split);
 // largest launches of the 16-point forward: n_rays * S points in all, and with saving (4.8 KB per point: 2^26 points = 320 GB)
 constexpr long FWD16R_MAX_POINTS = (1L << 31) - 1, FWD16R_MAX_SAVED_POINTS = 1L << 26;
 // split (ring kernels, repack, streaming weight-gradient GEMM): 0 = bf16 three-term split, 1 = fp16 (csrc/split_types.h)

@@ -105,8 +105,12 @@ __device__ inline unsigned short bf16_rne(float x) {
 // W' = Wv[:, :256] Wf and b' = Wv[:, :256] bf + bv (nerf_common.h, folded feature layer): fp64 accumulation.  Eight lanes
 // share one output (contraction index i = part, part + 8, ...; fp64 shuffle reduction): 263 k threads with 32 dependent
 // loads each instead of 33 k threads with 256 (the kernel runs after every optimizer step: 21 -> ~4 us).
-__global__ void derive_folded_kernel(const float* __restrict__ p, float* __restrict__ derived) {
+// blockIdx.y selects the network: a training step repacks the coarse and the fine network in the same two launches (PackPair)
+struct PackPair { const float* params[2]; float* packed[2]; };
+__global__ void derive_folded_kernel(PackPair pp) {
     constexpr Canon c = canon();
+    const float* __restrict__ p = pp.params[blockIdx.y];
+    float* __restrict__ derived = pp.packed[blockIdx.y] + P3_DERIVED;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int part = tid & 7;
     const int idx = min(tid >> 3, N_DERIVED - 1);        // (every lane takes part in the shuffles)
@@ -177,8 +181,10 @@ void pack3_table_host(int* out) {
 // (bits 1 and 3 named streams of kernels that no longer exist).  The small fp32 parameters are always written.
 // SP (split_types.h): the 16-bit type the weights are split into -- the same buffer layout either way.
 template <typename SP>
-__global__ void pack3_all_kernel(const float* __restrict__ canon_params, const float* __restrict__ derived, float* __restrict__ packed,
-                                 int n16f, int n3b) {
+__global__ void pack3_all_kernel(PackPair pp, int n16f, int n3b) {
+    const float* __restrict__ canon_params = pp.params[blockIdx.y];
+    float* __restrict__ packed = pp.packed[blockIdx.y];
+    const float* __restrict__ derived = packed + P3_DERIVED;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned short* p16 = reinterpret_cast<unsigned short*>(packed);
     auto emit = [&](unsigned short* dst, int src, int is_lo) {
@@ -316,19 +322,29 @@ __global__ void pack8_kernel(const float* __restrict__ canon_params, const float
     }
 }
 
-hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream, int split) {
+// one or two networks (params_b == nullptr: one) in the same two launches: derive_folded, then every selected stream
+hipError_t launch_pack3_pair(const float* params_a, float* packed_a, const float* params_b, float* packed_b, int streams, hipStream_t stream, int split) {
     const int threads = 256;
-    float* derived = packed + P3_DERIVED;
-    hipLaunchKernelGGL(derive_folded_kernel, dim3((8 * N_DERIVED + threads - 1) / threads), dim3(threads), 0, stream, canon_params, derived);
+    const unsigned nets = params_b ? 2 : 1;
+    PackPair pp{{params_a, params_b ? params_b : params_a}, {packed_a, params_b ? packed_b : packed_a}};
+    hipLaunchKernelGGL(derive_folded_kernel, dim3((8 * N_DERIVED + threads - 1) / threads, nets), dim3(threads), 0, stream, pp);
     const int n16f = (streams & 1) ? 2 * P16F_WORDS : 0, n3b = (streams & 4) ? 2 * (P3B_END - P3B_VIEWS) : 0;
     const long total = (long)n16f + n3b + (PACKED_FLOATS - SM_BIAS);
-    const dim3 grid((unsigned)((total + threads - 1) / threads));
-    if (split) hipLaunchKernelGGL(pack3_all_kernel<SplitF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3b);
-    else hipLaunchKernelGGL(pack3_all_kernel<SplitBF16>, grid, dim3(threads), 0, stream, canon_params, (const float*)derived, packed, n16f, n3b);
+    const dim3 grid((unsigned)((total + threads - 1) / threads), nets);
+    if (split) hipLaunchKernelGGL(pack3_all_kernel<SplitF16>, grid, dim3(threads), 0, stream, pp, n16f, n3b);
+    else hipLaunchKernelGGL(pack3_all_kernel<SplitBF16>, grid, dim3(threads), 0, stream, pp, n16f, n3b);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack3_sel(const float* canon_params, float* packed, int streams, hipStream_t stream, int split) {
+    hipError_t e = launch_pack3_pair(canon_params, packed, nullptr, nullptr, streams, stream, split);
+    if (e != hipSuccess) return e;
     if (split == 2) {       // reduced inference stream on top of the fp16 three-term stream (its narrow units and small parameters stay)
-        hipLaunchKernelGGL(weight_scale_kernel, dim3(N_RED_MATRICES), dim3(1024), 0, stream, canon_params, (const float*)derived, packed);
+        const int threads = 256;
+        const float* derived = packed + P3_DERIVED;
+        hipLaunchKernelGGL(weight_scale_kernel, dim3(N_RED_MATRICES), dim3(1024), 0, stream, canon_params, derived, packed);
         const long n8 = 2L * P16F_WORDS + 1;
-        hipLaunchKernelGGL(pack8_kernel, dim3((unsigned)((n8 + threads - 1) / threads)), dim3(threads), 0, stream, canon_params, (const float*)derived, packed);
+        hipLaunchKernelGGL(pack8_kernel, dim3((unsigned)((n8 + threads - 1) / threads)), dim3(threads), 0, stream, canon_params, derived, packed);
     }
     return hipGetLastError();
 }

@@ -134,8 +134,8 @@ class NeRF(nn.Module):
             self._bind_flat()
         return self._flat
 
-    def packed_params(self, precision="fp32"):
-        """Fragment repack of the current parameters for the given datapath (cached on the parameters' versions)."""
+    def _refresh_packed_cache(self):
+        """drop the cached repacks if the parameters changed since they were made; returns the flat parameter vector"""
         flat = self.flat_params()
         # torch-side in-place updates advance the version counters of the parameters / of the flat vector; the fused
         # Adam kernel advances hb.param_epoch(flat).  Writers that do neither (c10d collectives such as the DP parameter
@@ -144,6 +144,11 @@ class NeRF(nn.Module):
         if self._packed is None or key != self._packed_key:
             self._packed = {}
             self._packed_key = key
+        return flat
+
+    def packed_params(self, precision="fp32"):
+        """Fragment repack of the current parameters for the given datapath (cached on the parameters' versions)."""
+        flat = self._refresh_packed_cache()
         if precision not in self._packed:
             # fresh tensor each time: a pending backward keeps a reference to the old one
             self._packed[precision] = hb.pack_params(flat, precision=precision)
@@ -182,6 +187,17 @@ class NeRF(nn.Module):
             put(self.views_linears[0], weights[2 * self.D + 2], weights[2 * self.D + 3])
             put(self.rgb_linear, weights[2 * self.D + 4], weights[2 * self.D + 5])
             put(self.alpha_linear, weights[2 * self.D + 6], weights[2 * self.D + 7])
+
+
+def packed_params_pair(model_a, model_b, precision):
+    """(model_a.packed_params(precision), model_b.packed_params(precision)); when BOTH repacks are stale -- every training step, after
+    the optimizer step -- the two networks are repacked in the two launches one takes (hb.pack_params_pair) instead of four."""
+    if model_a is model_b or precision not in ("fp16x3", "bf16x3") or not (isinstance(model_a, NeRF) and isinstance(model_b, NeRF)):
+        return model_a.packed_params(precision), model_b.packed_params(precision)
+    fa, fb = model_a._refresh_packed_cache(), model_b._refresh_packed_cache()
+    if precision not in model_a._packed and precision not in model_b._packed and fa.device == fb.device:
+        model_a._packed[precision], model_b._packed[precision] = hb.pack_params_pair(fa, fb, precision)
+    return model_a.packed_params(precision), model_b.packed_params(precision)
 
 
 _TABLE = None

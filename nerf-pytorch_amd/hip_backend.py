@@ -41,6 +41,7 @@ def _declare(lib):
         "nerf_debug_layout": (i, [i, i, i, i, ctypes.POINTER(ctypes.c_longlong)]),
         "nerf_act_floats": (sz, [i, i]),
         "nerf_workspace_floats": (sz, [i, i, i, i]),
+        "nerf_pack_params_split_pair": (i, [p, p, p, p, i, i, p]),
         "nerf_act_floats_dp": (sz, [i, i, i]),
         "nerf_delta_floats_dp": (sz, [i, i, i]),
         "nerf_workspace_floats_dp": (sz, [i, i, i, i, i]),
@@ -86,7 +87,7 @@ def _declare(lib):
 
 EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_param_offset", "nerf_packed_floats",
            "nerf_pack_params", "nerf_debug_pack_table", "nerf_embed", "nerf_make_rays", "nerf_assemble_rays", "nerf_sample_coarse", "nerf_sample_ray_batch", "nerf_buffer_layout", "nerf_debug_layout", "nerf_act_floats", "nerf_workspace_floats", "nerf_field_fwd",
-           "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats", "nerf_act_floats_dp", "nerf_delta_floats_dp", "nerf_workspace_floats_dp",
+           "nerf_raw2outputs", "nerf_raw2outputs_bwd", "nerf_sample_fine", "nerf_sample_pdf", "nerf_delta_floats", "nerf_pack_params_split_pair", "nerf_act_floats_dp", "nerf_delta_floats_dp", "nerf_workspace_floats_dp",
            "nerf_wgrad_partial_floats", "nerf_field_bwd", "nerf_field_dgrad", "nerf_field_wgrad",
            "nerf_packed3_floats", "nerf_debug_pack3_table",
            "nerf_field_wgrad_phase", "nerf_debug_pack16_table",
@@ -287,6 +288,17 @@ def pack_params(flat, out=None, precision="fp32"):
         out = torch.empty(L.nerf_packed_floats(), dtype=torch.float32, device=flat.device)
     _check(L.nerf_pack_params(_ptr(flat, "params"), _ptr(out, "packed"), _stream()), "nerf_pack_params")
     return out
+
+
+def pack_params_pair(flat_a, flat_b, precision):
+    """the (hi, lo) fragment repack of two networks in the two launches one takes (nerf_pack_params_split_pair; fp16x3 / bf16x3)"""
+    L = lib()
+    split = {"bf16x3": 0, "fp16x3": 1}[precision]
+    out_a = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat_a.device)
+    out_b = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat_a.device)
+    _check(L.nerf_pack_params_split_pair(_ptr(flat_a, "params"), _ptr(out_a, "packed"), _ptr(flat_b, "params"), _ptr(out_b, "packed"), 1 | 4, split,
+                                         _stream()), "nerf_pack_params_split_pair")
+    return out_a, out_b
 
 
 def embed(x, n_freqs):

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import hip_backend as hb
-from .field import NeRF
+from .field import NeRF, packed_params_pair
 
 _LINSPACE_CACHE = {}
 # The datapath a user gets without asking (round 5): the fp16 three-term split -- fp32-class products (~2^-22), the configuration
@@ -146,7 +146,10 @@ def _field_pass(cfg, rays, rnd, model_c, model_f, save):
     # fp16x3's 89-120 dB (tools/EXPERIMENTS.md, round 5).  The coarse pass (a quarter of the points) therefore runs on the three-term
     # products and only the refining pass (whose errors reach the image unamplified) on the reduced ones.
     prec_c = "fp16x3" if (prec == "fp16_fp8c" and n_f > 0 and hb.REDUCED_COARSE_THREE_TERM) else prec
-    r["packed_c"] = model_c.packed_params(prec_c)
+    if n_f > 0 and mf is not model_c and prec_c == prec:
+        r["packed_c"], packed_f = packed_params_pair(model_c, mf, prec)       # (both stale after an optimizer step: one pair of launches)
+    else:
+        r["packed_c"], packed_f = model_c.packed_params(prec_c), None
     if prec_c == "fp16_fp8c" and n_f > 0:     # the guard launch of the coarse pass also evaluates the fine pass's last sample (hb.field_fwd)
         raw_f = torch.empty((rays.shape[0], n_c + n_f, 4), dtype=torch.float32, device=dev)
         nxt = (guard(mf), raw_f)
@@ -158,7 +161,7 @@ def _field_pass(cfg, rays, rnd, model_c, model_f, save):
         return r
     u = rnd.get("u")
     r["z_f"], r["z_std"], _ = hb.sample_fine(r["z_c"], w_c, n_f, u, None if u is not None else _linspace01(n_f, dev))
-    r["packed_f"] = mf.packed_params(prec)
+    r["packed_f"] = packed_f if packed_f is not None else mf.packed_params(prec)
     r["raw_f"], r["act_f"] = hb.field_fwd(r["packed_f"], rays, r["z_f"], save_act=save, precision=prec,
                                           guard_packed="done" if raw_f is not None else guard(mf), raw=raw_f)
     r["rgb_f"], r["disp_f"], r["acc_f"], _, _ = hb.raw2outputs(r["raw_f"], r["z_f"], rays, rays.shape[1], rnd.get("noise_f"), std, wb,
