@@ -121,6 +121,7 @@ def parse_args(argv=None):
                          "(`precision_gate.training`): the training-equivalence evidence, ~1-2 min")
     ap.add_argument("--long-steps", type=int, default=2000)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
+    ap.add_argument("--bf16x3-leg", action="store_true", help="also measure the training step on the bf16 split (rounds 1-3's headline datapath)")
     ap.add_argument("--force-group", action="store_true",
                     help="build the process group even for ONE rank (NERF_FORCE_PROCESS_GROUP=1): a 1-GPU box then executes the RCCL branch as "
                          "written (ProcessGroupNCCL, async all-reduce work objects, broadcast, all-gather) and the line carries a multi_gpu block")
@@ -779,6 +780,7 @@ class Session:
 def _guarded(errors, name, fn):
     """Run a SECONDARY measurement (a `configs` leg, a baseline): the headline has been measured by then and must be printed
     whatever happens here; a failure is recorded in the line under `errors` instead of ending the run."""
+    t0 = time.perf_counter()
     try:
         return fn()
     except Exception as e:      # noqa: BLE001 (deliberately broad: out of memory, a missing fixture, a host without rocm tools ...)
@@ -791,9 +793,17 @@ def _guarded(errors, name, fn):
         except Exception:       # noqa: BLE001
             pass
         return None
+    finally:
+        LEG_SECONDS[name] = round(time.perf_counter() - t0, 2)
+
+
+T_START = time.perf_counter()
+LEG_SECONDS = {}        # wall time of every secondary leg of this run (reported in the line: the default command has a time budget)
 
 
 def main():
+    global T_START
+    T_START = time.perf_counter()
     args = parse_args()
     relaunch_if_needed(args)
     if args.dry_run:
@@ -891,7 +901,7 @@ def main():
             # the same batches through the chain of six launches, measured alternately with the one-launch kernel (the clock the
             # chip grants drifts over a run: whichever is measured first after the training steps looks ~1 % slower)
             el_c = None
-            for _ in range(2):
+            for _ in range(1):
                 hb.INFER_ONE_LAUNCH = False
                 try:
                     e, _ = measure(args.precision, k_inf, 2, ses.infer_step, with_kernels=False)
@@ -959,7 +969,7 @@ def main():
         def _red():
             k_inf = max(5, args.steps // 2)
             best = {"fp16x3": None, "fp16_fp8c": None}
-            for _ in range(2):
+            for _ in range(1):
                 for prec in ("fp16_fp8c", "fp16x3"):
                     e, _k = measure(prec, k_inf, 2, ses.infer_step, with_kernels=False)
                     best[prec] = e if best[prec] is None else min(best[prec], e)
@@ -984,7 +994,7 @@ def main():
         npa.set_precision(args.precision)
 
     bf16x3_leg = None
-    if not args.single_datapath and args.mode == "train" and args.precision == "fp16x3":
+    if args.bf16x3_leg and not args.single_datapath and args.mode == "train" and args.precision == "fp16x3":
         # rounds 1-3's headline datapath in the same run (bf16 parts: 2^-17 products, 8-bit weight-gradient operands)
         def _b3():
             kb = max(5, args.steps // 2)
@@ -1252,6 +1262,7 @@ def main():
             cb = _guarded(errors, "cpu_baseline", lambda: cpu_baseline(args.config))
             if cb is not None:
                 line["cpu_baseline"] = cb
+        line["leg_seconds"] = dict(LEG_SECONDS, total_since_start=round(time.perf_counter() - T_START, 2))
         if errors:
             line["errors"] = errors
         print(json.dumps(line))

@@ -315,7 +315,7 @@ def test_reduced_class_renders_without_gradients_and_trains_on_fp16x3(npa, dev, 
     # round 5: with a refining pass the COARSE pass of the reduced class runs on the three-term products (render._field_pass: sample_pdf
     # amplifies 2^-15 coarse errors) -- its outputs and the sampled depths are fp16x3's, bit for bit; the refining pass is the reduced one
     for k in ("rgb0", "acc0", "disp0", "z_std"):
-        assert torch.equal(out["fp16_fp8c"][k], out["fp16x3"][k]), k
+        assert torch.equal(out["fp16_fp8c"][k].view(torch.int32), out["fp16x3"][k].view(torch.int32)), k        # (bit patterns: disp is NaN on empty rays)
     d = maxdiff(out["fp16_fp8c"]["rgb_map"], out["fp16x3"]["rgb_map"])
     assert 0.0 < d <= 3e-4, d
     ref = orc.trace_rays(rays.cpu(), Pc, Pf, 64, 128, white_bkgd=True)
