@@ -109,17 +109,18 @@ def parse_args(argv=None):
     ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--no-gate", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other single-GPU configurations")
-    ap.add_argument("--sustained-s", type=float, default=10.0,
+    ap.add_argument("--sustained-s", type=float, default=6.0,
                     help="default run only: seconds of back-to-back training steps for `sustained` (rate over the whole interval and per "
                          "second, board power and shader clock sampled meanwhile); 0 = skip")
     ap.add_argument("--no-training-gate", action="store_true",
-                    help="skip `precision_gate.training` (default run: the converging teacher / student pair of --long, 500 Adam steps of 1024 "
+                    help="skip `precision_gate.training` (default run: the converging teacher / student pair of --long, 300 Adam steps of 1024 "
                          "rays on fp32, fp32 one ulp away and the headline datapath; ~25 s)")
     ap.add_argument("--long", action="store_true",
                     help="also fit a student to a teacher scene in every datapath (3 seeds x --long-steps Adam steps of 1024 rays, same "
                          "initialisation, batches and draws) and report the held-out PSNR per datapath as mean +- spread "
                          "(`precision_gate.training`): the training-equivalence evidence, ~1-2 min")
     ap.add_argument("--long-steps", type=int, default=2000)
+    ap.add_argument("--long-twins", type=int, default=4, help="--long: perturbed starts of the fp32 datapath per seed (the fp16x3 datapath gets two fewer)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
     ap.add_argument("--bf16x3-leg", action="store_true", help="also measure the training step on the bf16 split (rounds 1-3's headline datapath)")
     ap.add_argument("--force-group", action="store_true",
@@ -154,7 +155,7 @@ def relaunch_if_needed(args):
 
 
 # --------------------------------------------------------------------------------------------- baselines (reported beside)
-def cpu_baseline(cfg_name, n_rays=512):
+def cpu_baseline(cfg_name, n_rays=256):
     """The oracle (bit-identical restatement of the reference, CPU, fp32) timed on this box's host cores on a bounded
     sample of the same workload: training steps of n_rays rays x (64+128) samples."""
     import torch
@@ -184,7 +185,7 @@ def cpu_baseline(cfg_name, n_rays=512):
     step()
     t0 = time.perf_counter()
     reps = 0
-    while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 20):
+    while reps < 2 or (time.perf_counter() - t0 < 8.0 and reps < 20):
         step()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
@@ -258,7 +259,9 @@ def rocm_eager_baseline(cfg_name, dev, n_rays, steps=5, frame=0, chunk=32768, po
                 rays = orc.assemble_rays(ro, rd, cfg["near"], cfg["far"])
                 orc.trace_in_chunks(rays, chunk, P_coarse=Pc, P_fine=Pf, n_coarse=N_SAMPLES, n_fine=N_IMPORTANCE, perturb=0.0,
                                     white_bkgd=cfg["white_bkgd"])
-        one_frame()
+        with torch.no_grad():           # warm-up on the first chunk of the frame (allocator, kernel selection)
+            orc.trace_in_chunks(orc.assemble_rays(ro.reshape(-1, 3)[:chunk], rd.reshape(-1, 3)[:chunk], cfg["near"], cfg["far"]), chunk, P_coarse=Pc,
+                                P_fine=Pf, n_coarse=N_SAMPLES, n_fine=N_IMPORTANCE, perturb=0.0, white_bkgd=cfg["white_bkgd"])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         one_frame()
@@ -538,13 +541,15 @@ def dry_run(args):
 CONVERGING_PAIRS = (("scene", 5, 6), ("scene", 4, 6), ("scene", 2, 3))
 
 
-def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024, which=None, pairs=CONVERGING_PAIRS, checkpoints=None):
+def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024, which=None, pairs=CONVERGING_PAIRS, checkpoints=None, twins=1, twins16=0):
     """Training equivalence of the datapaths, measured instead of argued: the same student is fitted to a teacher scene's images
     with the fused Adam for `steps` steps of `n_batch` rays, once per datapath and seed, with identical initialisation, batch order
     and random draws; held-out PSNR (2048 rays, evaluated on the exact fp32 datapath) at every checkpoint and after the last step.
     Per datapath: mean and spread (max - min) over the seeds, and the largest per-seed difference to the fp32 datapath (over all
-    checkpoints: `max_abs_diff_to_fp32_db_any_checkpoint`).  `fp32_twin` is the fp32 datapath itself started one ulp away: training
-    is chaotic in the rounding, so a datapath is equivalent when it stays inside the twin's distance."""
+    checkpoints: `max_abs_diff_to_fp32_db_any_checkpoint`).  `fp32_twin`, `fp32_twin2` ... (`twins` of them) are the fp32 datapath
+    itself started one ulp away (each with its own perturbation): training is chaotic in the rounding, so a datapath is equivalent
+    when it stays inside the spread of the fp32 family.  `twins16` adds as many perturbed starts of the fp16x3 datapath, so that the
+    two FAMILIES can be compared (`families`: per seed the [min, max] of each family's final PSNR)."""
     import math
     import torch
     import nerf_pytorch_amd as npa
@@ -583,15 +588,17 @@ def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024, which=None, pai
                                        f"nan {int(torch.isnan(out).sum())}, target [{float(tgt_held.min())}, {float(tgt_held.max())}], "
                                        f"same storage {out.data_ptr() == tgt_held.data_ptr()}")
                 return -10 * math.log10(mse)
-            for name, prec in (("fp32", "fp32"), ("fp32_twin", "fp32"), ("fp16x3", "fp16x3"), ("bf16x3", "bf16x3")):
-                if which is not None and name not in which:
+            runs = [("fp32", "fp32", 0)] + [("fp32_twin" + (str(t) if t > 1 else ""), "fp32", t) for t in range(1, twins + 1)]
+            runs += [("fp16x3", "fp16x3", 0)] + [(f"fp16x3_twin{t}", "fp16x3", t) for t in range(1, twins16 + 1)] + [("bf16x3", "bf16x3", 0)]
+            for name, prec, twin in runs:
+                if which is not None and name not in which and not (twin > 1 and name.rstrip("0123456789") in which):
                     continue
                 torch.manual_seed(seed)
                 nc, nf = net(Sc), net(Sf)
-                if name == "fp32_twin":
-                    # the yardstick: the SAME fp32 datapath started 1e-7 (relative, ~1 ulp) away -- how far two runs of one
+                if twin:
+                    # the yardstick: the SAME datapath started 1e-7 (relative, ~1 ulp) away -- how far two runs of one
                     # datapath drift apart in this many steps
-                    gt = torch.Generator(device="cpu").manual_seed(5000 + seed)
+                    gt = torch.Generator(device="cpu").manual_seed(5000 * twin + seed)
                     with torch.no_grad():
                         for p in list(nc.parameters()) + list(nf.parameters()):
                             p.mul_((1.0 + 1e-7 * torch.randn(p.shape, generator=gt)).to(dev))
@@ -618,11 +625,21 @@ def convergence_table(dev, steps, seeds=(0, 1, 2), n_batch=1024, which=None, pai
                        "max_abs_diff_to_fp32_db_any_checkpoint": max(abs(x - y) for a, b in zip(vals, results["fp32"]) for x, y in zip(a, b))}
         if len(checkpoints) > 1:
             table[name]["psnr_db_per_seed_at_checkpoints"] = [[round(x, 3) for x in v] for v in vals]
+    families = None
+    if twins > 1 or twins16 > 0:
+        fam = lambda prefix: [[results[k][i][-1] for k in results if k == prefix or k.startswith(prefix + "_twin")] for i in range(len(seeds))]
+        f32, f16 = fam("fp32"), fam("fp16x3") if "fp16x3" in results else None
+        families = {"fp32_final_db_min_max_per_seed": [[round(min(v), 3), round(max(v), 3)] for v in f32],
+                    "fp32_family_spread_db_per_seed": [round(max(v) - min(v), 3) for v in f32], "runs_per_seed": {"fp32": len(f32[0])}}
+        if f16:
+            families.update({"fp16x3_final_db_min_max_per_seed": [[round(min(v), 3), round(max(v), 3)] for v in f16],
+                             "fp16x3_family_mean_minus_fp32_family_mean_db_per_seed": [round(sum(a) / len(a) - sum(b) / len(b), 3) for a, b in zip(f16, f32)]})
+            families["runs_per_seed"]["fp16x3"] = len(f16[0])
     return {"steps": steps, "checkpoints": checkpoints, "rays_per_step": n_batch, "seeds": list(seeds), "pairs": [list(pairs[s % len(pairs)]) for s in seeds],
             "what": "student fitted to a teacher scene ('scene': another scene's weights; 'near': the teacher's weights perturbed by a relative eps), fused "
                     "Adam lr 5e-4, same init / batches / draws per datapath; held-out PSNR (2048 rays, evaluated on the fp32 datapath) after the last step "
                     "and at the checkpoints; fp32_twin = the fp32 datapath with the initial parameters perturbed by 1e-7 relative",
-            "datapaths": table}
+            "datapaths": table, **({"families": families} if families else {})}
 
 
 class Session:
@@ -1012,10 +1029,10 @@ def main():
     if not args.no_gate and rank == 0:
         gate = ses.gate(args.precision)
         if args.long and gate is not None:
-            gate["training"] = convergence_table(dev, args.long_steps, checkpoints=(args.long_steps // 4, args.long_steps // 2))
+            gate["training"] = convergence_table(dev, args.long_steps, checkpoints=(args.long_steps // 4, args.long_steps // 2), twins=args.long_twins, twins16=max(0, args.long_twins - 2))
         elif default_run and gate is not None and not args.no_training_gate:
-            # the converging pair of --long (teacher 5 / student 6), 500 steps, fp32 / fp32 one ulp away / headline
-            tr = _guarded(errors, "precision_gate.training", lambda: convergence_table(dev, 500, seeds=(0,), which=("fp32", "fp32_twin", args.precision)))
+            # the converging pair of --long (teacher 5 / student 6), 300 steps, fp32 / fp32 one ulp away / headline
+            tr = _guarded(errors, "precision_gate.training", lambda: convergence_table(dev, 300, seeds=(0,), which=("fp32", "fp32_twin", args.precision)))
             if tr is not None:
                 gate["training"] = tr
 
