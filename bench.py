@@ -120,7 +120,7 @@ def parse_args(argv=None):
                          "initialisation, batches and draws) and report the held-out PSNR per datapath as mean +- spread "
                          "(`precision_gate.training`): the training-equivalence evidence, ~1-2 min")
     ap.add_argument("--long-steps", type=int, default=2000)
-    ap.add_argument("--long-twins", type=int, default=4, help="--long: perturbed starts of the fp32 datapath per seed (the fp16x3 datapath gets two fewer)")
+    ap.add_argument("--long-twins", type=int, default=4, help="--long: perturbed starts of the fp32 datapath and of the fp16x3 datapath per seed (families of 1 + N runs each)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
     ap.add_argument("--bf16x3-leg", action="store_true", help="also measure the training step on the bf16 split (rounds 1-3's headline datapath)")
     ap.add_argument("--force-group", action="store_true",
@@ -1029,7 +1029,7 @@ def main():
     if not args.no_gate and rank == 0:
         gate = ses.gate(args.precision)
         if args.long and gate is not None:
-            gate["training"] = convergence_table(dev, args.long_steps, checkpoints=(args.long_steps // 4, args.long_steps // 2), twins=args.long_twins, twins16=max(0, args.long_twins - 2))
+            gate["training"] = convergence_table(dev, args.long_steps, checkpoints=(args.long_steps // 4, args.long_steps // 2), twins=args.long_twins, twins16=args.long_twins)
         elif default_run and gate is not None and not args.no_training_gate:
             # the converging pair of --long (teacher 5 / student 6), 300 steps, fp32 / fp32 one ulp away / headline
             tr = _guarded(errors, "precision_gate.training", lambda: convergence_table(dev, 300, seeds=(0,), which=("fp32", "fp32_twin", args.precision)))

@@ -418,9 +418,11 @@ GOLD_TOL = {
     # 11 bits.  Coarse-pass quantities sit at fp32-class bounds; the fine pass keeps the p95 + worst-ray + image form because
     # sample_pdf's conditioning amplifies ANY perturbation of the coarse weights (the reference's own fp32-vs-fp64 distance is
     # the `10 x noise` term)
-    # round 5: gradient bound tightened to what is measured (worst sampled entry over the nine fixtures without the noise term: 1.3e-3 of
-    # max|g| on fern_ndc_train, 1.4e-4 .. 4.7e-4 elsewhere; lego_train's 3.9e-3 sits under ITS `10 x noise` term, the reference's own
-    # fp32-vs-fp64 distance on that fixture -- the fp32 datapath measures the same there)
+    # round 5: gradient bound tightened to what is measured.  Worst sampled gradient entry / max|g| per fixture, fp16x3 (fp32 datapath
+    # in brackets): cfg2 4.7e-4 (7.5e-4), cfg3 1.8e-4 (2.1e-4), lego_det 1.8e-4 (1.3e-4), fern_train 1.4e-4 (9e-5), coarse_only 1.4e-4
+    # (1.4e-4), fern_ndc_train 1.3e-3 (9e-5), lego_train / lego_render_train 3.9e-3 (9.3e-4).  The last two exceed this bound and are
+    # admitted by the fixture's own `10 x noise` term only (the reference's fp32-vs-fp64 distance of that entry is 4e-4 of max|g|:
+    # hierarchical samples that move under ANY rounding); everything else is held to 1.5e-3 (rounds 3-4: 3e-3)
     "fp16x3": dict(coarse=3e-5, fine_floor=3e-5, fine_stat="p95", fine_max=5e-3, disp_rel=1e-4, zstd_floor=3e-4, raw_floor=2e-3,
                    loss_floor=5e-6, grad=1.5e-3, grad_max=1.5e-3, img_psnr_db=85.0),
 }
