@@ -441,7 +441,7 @@ def pmc_traffic(kernel_name, precision):
     passes; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the
     process, so this is the profile of the same command committed under profiles/ (None if absent)."""
     tag = {"bf16x3": "bf16x3_", "fp16x3": "fp16x3_"}.get(precision, "")
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}pmc_summary.csv")
         if os.path.exists(path):
             break

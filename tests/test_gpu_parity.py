@@ -1034,6 +1034,49 @@ def test_fused_adam_step_reaches_the_kernels(npa, dev):
         assert torch.equal(after, fresh)
 
 
+@pytest.mark.parametrize("mode", ["frozen_first_layer", "heads_only", "first_grad_none"])
+def test_fused_adam_on_a_subset_of_the_network_reaches_the_kernels(npa, dev, mode):
+    """FlatAdam hands the kernel the run of parameters that HAVE gradients, which starts anywhere inside the network's
+    flat vector (first layer frozen, heads-only fine-tuning, an optimizer over a subset, a parameter whose grad is None).  The
+    repack cache's epoch is keyed on the STORAGE of the vector (hip_backend._epoch_key), so such a step must still invalidate the
+    fragment repack: the next forward equals a fresh module that loads the updated weights, and differs from the one before."""
+    Pc, Pf = orc.scene_params(seed=4)
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    rays = orc.synthetic_rays(64, seed=12).to(dev)
+    target = torch.rand(64, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    for prec in ("fp16x3", "fp32"):
+        nc = npa.NeRF(**kw).to(dev)
+        nc.load_state_dict(Pc)
+        if mode == "frozen_first_layer":
+            for p_ in nc.pts_linears[0].parameters():
+                p_.requires_grad_(False)
+            trained = [p_ for p_ in nc.parameters() if p_.requires_grad]
+        elif mode == "heads_only":
+            trained = list(nc.rgb_linear.parameters()) + list(nc.alpha_linear.parameters())
+        else:
+            trained = list(nc.parameters())
+        opt = npa.FlatAdam(trained, lr=1e-2)
+        npa.set_precision(prec)
+        try:
+            render = lambda m: npa.render_rays(rays, m, None, 64, N_importance=0, white_bkgd=True)
+            before = render(nc)
+            npa.img2mse(before["rgb_map"], target).backward()
+            if mode == "first_grad_none":
+                nc.pts_linears[0].weight.grad = None
+            w0 = nc.pts_linears[0].weight.detach().clone()
+            opt.step()
+            with torch.no_grad():
+                after = render(nc)["rgb_map"]
+                nc2 = npa.NeRF(**kw).to(dev)
+                nc2.load_state_dict(nc.state_dict())
+                fresh = render(nc2)["rgb_map"]
+        finally:
+            npa.set_precision("fp32")
+        assert torch.equal(nc.pts_linears[0].weight.detach(), w0), "a parameter outside the optimizer's run moved"
+        assert float((after - before["rgb_map"].detach()).abs().max()) > 1e-4, (mode, prec, "the step did not reach the kernels")
+        assert torch.equal(after, fresh), (mode, prec)
+
+
 def test_training_reaches_the_same_psnr_in_every_datapath(npa, dev):
     """End-to-end training equivalence: a student field is fitted to a teacher scene with the fused optimizer for 150
     steps in each datapath (same init, same batches); held-out PSNR rises from 12 dB to > 38 dB and the three
@@ -1135,10 +1178,10 @@ def test_large_chunks_backpropagate_in_subchunks(npa, dev, nets, precision, monk
         return {k: v.detach().clone() for k, v in out.items()}, nc.last_flat_grad.clone(), nf.last_flat_grad.clone()
     npa.set_precision(precision)
     try:
-        assert hb.max_saved_rays(64, 128) >= n
+        assert hb.max_saved_rays(64, 128, precision) >= n
         out_a, gc_a, gf_a = run()
-        monkeypatch.setattr(hb, "SAVE_BUDGET_BYTES", 4 * hb.workspace_floats(1024, 64, 128) + 1)      # -> 1024-ray sub-chunks
-        assert hb.max_saved_rays(64, 128) == 1024
+        monkeypatch.setattr(hb, "SAVE_BUDGET_BYTES", 4 * hb.workspace_floats(1024, 64, 128, True, precision) + 1)      # -> 1024-ray sub-chunks
+        assert hb.max_saved_rays(64, 128, precision) == 1024       # (sized for THIS datapath's layouts: 16-bit tiles on the split ones)
         # (a) the sub-chunks' saved activations fit SAVE_TOTAL_BYTES: each keeps its lease, the forward runs ONCE per sub-chunk
         calls = []
         real_fwd = hb.field_fwd
