@@ -151,7 +151,7 @@ int nerf_field_dgrad(const float* packed, const float* act, const float* d_raw, 
 int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                      float* partial, float* grad, int accumulate, void* stream);
 
-/* ---- the three-term SPLIT datapaths of the same functions (ABI v7; csrc/split_types.h): every product W x of the MLP is evaluated
+/* ---- the three-term SPLIT datapaths of the same functions (csrc/split_types.h): every product W x of the MLP is evaluated
  * as  W_hi x_hi + W_hi x_lo + W_lo x_hi  on 16-bit MFMAs with fp32 accumulation, hi = T(v), lo = T(v - hi):
  *   split = 1, T = IEEE half ("fp16x3", the host code's default): v_mfma_f32_16x16x32_f16 / 32x32x16_f16, ~2^-22 per product --
  *              fp32-class; the rows / deltas saved for the weight-gradient GEMM are the hi words (11 significant bits);

@@ -1,12 +1,12 @@
 // field_dgrad3r_kernel: the delta chain of the split datapaths (d_raw -> dL/d(pre-activation) of every layer; the autograd of
 // run_nerf_helpers.py:96-119) on the weight RING of field_ring.h.  32 points per wave on v_mfma_f32_32x32x16_{bf16,f16}, 4 waves,
 // one per SIMD.  A wave alone on its SIMD has nobody to cover what it does between MFMAs (the double-buffered kernel of round 2,
-// csrc/ref/field_bwd_bf16.hip, spends that time after every 64 KiB chunk: barrier, 16 DMA pieces per wave back to back, LDS latency
+// deleted in round 5, spent that time after every 64 KiB chunk: barrier, 16 DMA pieces per wave back to back, LDS latency
 // of the first fragments, 32 row stores in a burst: MFMA-busy 0.53).  Here every MFMA (32 cycles of pipe) carries its own share of
 // that work in its shadow: one fragment request 8 MFMAs ahead of its use, a piece of the next k-step's operand split, one row
 // store, and behind each of four units per chunk a 4 KiB DMA part (field_ring.h: unit_pipelined, WeightRingT<4>).
 // Same transposed fragment stream (P3B), same MFMA order per accumulator, same masks as that kernel: with SP = SplitBF16 every
-// delta written is BIT-IDENTICAL to it (tests/test_gpu_round3.py::test_ring_dgrad_bit_identical).  Deltas leave as 16-bit elements
+// delta written was BIT-IDENTICAL to it while both existed (the digests of tests/golden/kernel_digests.json were recorded then).  Deltas leave as 16-bit elements
 // of the split's type SP (split_types.h; operands of wgrad1_kernel).  SP = SplitF16: the chain runs on s * d_raw, s a power of
 // two per launch (delta_amax_kernel).
 #include <type_traits>

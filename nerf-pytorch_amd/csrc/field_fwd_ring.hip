@@ -1,9 +1,9 @@
 // field_fwd16r_kernel: the 16-point-per-wave three-term-split forward (encode + 8x256 trunk + density head + folded view
 // branch -> raw[P,4]; run_nerf.py:37-51, run_nerf_helpers.py:15-45, :96-119) on the weight RING of field_ring.h.  Same fragment
-// stream (P16F), same MFMA order per accumulator, same encodings and heads as round 2's double-buffered kernel
-// (csrc/ref/field_fwd_bf16.hip, test-only library): with SP = SplitBF16 `raw`, the saved rows, encodings and ReLU bitmasks are
-// BIT-IDENTICAL to it (tests/test_gpu_parity.py::test_ring_forward_bit_identical); what changed is when the weights arrive and
-// when the fragments are requested.  SAVE: 0 = inference, 2 = 16-bit rows of the split's type (operands of the weight-gradient
+// stream (P16F), same MFMA order per accumulator, same encodings and heads as round 2's double-buffered kernel (deleted in round 5):
+// with SP = SplitBF16 `raw`, the saved rows, encodings and ReLU bitmasks were BIT-IDENTICAL to it while both existed -- the digests
+// of tests/golden/kernel_digests.json were recorded in that state and pin every later change; what changed against that kernel
+// is when the weights arrive and when the fragments are requested.  SAVE: 0 = inference, 2 = 16-bit rows of the split's type (operands of the weight-gradient
 // GEMM).  SP (split_types.h): bf16 split or fp16 split (fp32-class products, 11-bit saved rows); RED: the reduced inference class
 // (field_ring8.h).
 #include "field_fwd_ring_body.h"

@@ -447,7 +447,7 @@ def workspace_floats(n_rays, n_coarse, n_fine, training=True, precision=None):
 def max_saved_rays(n_coarse, n_fine, precision=None):
     """Largest ray count whose backward scratch fits SAVE_BUDGET_BYTES (multiple of 1024, at least 1024): larger ray
     chunks are back-propagated in sub-chunks of this size (render._RenderRays).  64 + 128 samples under the default 48 GiB:
-    10,240 rays on fp32 rows, 22,528 on the split datapaths' 16-bit tiles."""
+    10,240 rays on fp32 rows, 21,504 on the split datapaths' 16-bit tiles."""
     per_1024 = 4 * workspace_floats(1024, n_coarse, n_fine, True, precision)
     return max(1, SAVE_BUDGET_BYTES // max(per_1024, 1)) * 1024
 

@@ -5,7 +5,7 @@ are used only by loaders / image writers), runs the reference functions and the
 oracle restatement on identical inputs on CPU, and asserts bit-identical fp32
 results function by function.  /root/reference does not exist on the GPU box,
 so this script is run here (``python oracle/pin_against_reference.py``) and by
-``tests/test_oracle_pin.py`` when the reference is present.
+``tests/test_oracle_golden.py`` when the reference is present.
 """
 import os
 import sys

@@ -34,7 +34,7 @@ def test_golden_cfg3_fern_ndc_4096_ray_training_step(npa, dev, nets, precision):
 @pytest.mark.parametrize("precision", PARITY_DATAPATHS)
 def test_golden_cfg4_32768_rays_in_one_chunk(npa, dev, nets, precision):
     """BASELINE.json configs[3]'s batch on ONE GPU: render(chunk = 32768) with gradients enabled renders the chunk in sub-chunks
-    whose saved activations stay resident (render._RenderRays, ~90 GB) -- maps and loss against the REFERENCE's forward of the
+    whose saved activations stay resident (render._RenderRays: 87 GB of fp32 rows, 40.5 GB on the split datapaths) -- maps and loss against the REFERENCE's forward of the
     same 32,768 rays in one chunk (the reference's draw order: t_rand [32768, 64] then u [32768, 128]); then the backward
     through all sub-chunks against the sum of the gradients of eight independent 4096-ray render() calls."""
     nc, nf, Pc, Pf = nets
