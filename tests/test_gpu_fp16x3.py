@@ -290,6 +290,30 @@ def test_reduced_forward_against_fp64_and_the_last_sample_guard(npa, dev, nets, 
         hb.field_fwd(nf.packed_params("fp16_fp8c"), rays.to(dev), z.to(dev), save_act=True, precision="fp16_fp8c", guard_packed=nf.packed_params("fp16x3"))
 
 
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16x3"])
+def test_pair_repack_equals_two_repacks(npa, dev, nets, precision):
+    """nerf_pack_params_split_pair (both networks in the two launches one takes, blockIdx.y = network) writes, word for word, what two
+    nerf_pack_params_split calls write; field.packed_params_pair uses it exactly when both cached repacks are stale."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    fa, fb = nc.flat_params(), nf.flat_params()
+    one_a, one_b = hb.pack_params(fa, precision=precision), hb.pack_params(fb, precision=precision)
+    pair_a, pair_b = hb.pack_params_pair(fa, fb, precision)
+    assert torch.equal(one_a.view(torch.int32), pair_a.view(torch.int32)) and torch.equal(one_b.view(torch.int32), pair_b.view(torch.int32))
+    assert not torch.equal(pair_a.view(torch.int32), pair_b.view(torch.int32))
+    from nerf_pytorch_amd.field import packed_params_pair
+    for m in (nc, nf):
+        m.invalidate_packed()
+    pa, pb = packed_params_pair(nc, nf, precision)
+    assert torch.equal(pa.view(torch.int32), one_a.view(torch.int32)) and torch.equal(pb.view(torch.int32), one_b.view(torch.int32))
+    assert packed_params_pair(nc, nf, precision)[0] is pa and nc.packed_params(precision) is pa and nf.packed_params(precision) is pb      # cached
+    nf.invalidate_packed()                                     # only one of the two stale: the single repack
+    pa2, pb2 = packed_params_pair(nc, nf, precision)
+    assert pa2 is pa and pb2 is not pb and torch.equal(pb2.view(torch.int32), one_b.view(torch.int32))
+    same = packed_params_pair(nc, nc, precision)
+    assert same[0] is same[1] is pa
+
+
 def test_reduced_class_renders_without_gradients_and_trains_on_fp16x3(npa, dev, nets):
     """render_rays under set_precision("fp16_fp8c"): no_grad -> the reduced products (close to, not equal to, fp16x3's image);
     with gradients enabled -> the fp16x3 datapath itself: outputs and both networks' gradients bit-identical to fp16x3's."""

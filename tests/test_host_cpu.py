@@ -31,6 +31,12 @@ def test_argument_errors_are_codes_not_crashes():
     assert L.nerf_pack_params(None, None, None) == -1
     assert b"null pointer" in L.nerf_last_error()
     assert L.nerf_field_fwd(None, None, 11, None, 4, 4, None, None, None) == -1
+    # the pair repack: null pointers, one packed buffer for both networks, an unknown stream bit, the reduced split (its two extra
+    # launches are per network: nerf_pack_params_split(split = 2))
+    assert L.nerf_pack_params_split_pair(None, None, None, None, 5, 1, None) == -1 and b"null pointer" in L.nerf_last_error()
+    assert L.nerf_pack_params_split_pair(0x1000, 0x2000, 0x3000, 0x2000, 5, 1, None) == -1 and b"own packed buffers" in L.nerf_last_error()
+    assert L.nerf_pack_params_split_pair(0x1000, 0x2000, 0x3000, 0x4000, 2, 1, None) == -1
+    assert L.nerf_pack_params_split_pair(0x1000, 0x2000, 0x3000, 0x4000, 5, 2, None) == -1
     assert L.nerf_act_floats(0, 64) == 0
     for n, S in ((4096, 192), (5, 3)):
         P = n * S
