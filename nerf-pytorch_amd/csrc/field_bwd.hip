@@ -664,13 +664,19 @@ __global__ void wgrad_fold_kernel(const float* __restrict__ params, const float*
 }
 
 // ------------------------------------------------------------------ host side
+#ifndef NERF_WG_CHUNKS           // tuning knob of tools/build_variant.sh (A/B timing on one box); the shipped value: tools/EXPERIMENTS.md, round 5
+#define NERF_WG_CHUNKS 19
+#endif
 static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
     // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU).  fp32: 14 jobs x
-    // 128 = 7 x 256 (the 8 full-width jobs x 128 = 4 x 256).  Split datapaths (13 jobs, 16-bit operands): 13 x 39 = 507 =
-    // 2 x 256 - 5 (59 chunks = 3 rounds: GEMM +1 %, reduction 0.055 instead of 0.043 ms); launches below 400 k points -- the coarse
-    // pass: 19 chunks = 247 workgroups = ONE round (the GEMM takes the same time, the deterministic reduction reads half the
-    // partial sums: 0.044 -> 0.032 ms).  Small inputs get >= 256-point chunks.
-    long n = n_jobs == 14 ? 128 : (P < 400000 ? 19 : 39);
+    // 128 = 7 x 256 (the 8 full-width jobs x 128 = 4 x 256).  Split datapaths (13 jobs, 16-bit operands, wgrad1_kernel): 13 x 19 = 247
+    // workgroups = ONE round for every launch size.  Rounds 2-4 gave launches above 400 k points 39 chunks (507 workgroups = two
+    // rounds); measured in round 5 on one box, alternating builds, fine launch (786,432 points): 39 chunks GEMM 1.312 ms + reduction
+    // 0.037 ms; 26 chunks (1.3 rounds) 1.726 + 0.030; 19 chunks 1.281 + 0.026 -- a workgroup streaming twice the points keeps its
+    // 96 KiB of DMA in flight just the same, and the deterministic reduction reads half the partial sums.  (Pairing the narrow jobs
+    // into one workgroup so that all workgroups stream equal bytes -- 11 "virtual jobs" x 23 chunks -- measured 1.84 ms: the job loop
+    // costs the kernel its schedule, 192 -> 255 VGPRs; not kept.)  Small inputs get >= 256-point chunks.
+    long n = n_jobs == 14 ? 128 : NERF_WG_CHUNKS;
     const long cap = (P + 255) / 256;
     if (n > cap) n = cap;
     if (n < 1) n = 1;
