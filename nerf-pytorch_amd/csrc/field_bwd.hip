@@ -164,6 +164,12 @@ struct WgradJob {
     int b_tile16;                   // split datapaths: B is stored in 16-point tiles, row16h row order (the forward's saved rows)
     int b_ray_tiles;                // wgrad1_kernel: > 0 = B is constant along a ray (the direction encoding) and stored ONCE per
                                     // ray as [ray][feature][8 copies] bf16 (512 B per ray); value = 32-point tiles per ray
+    // wgrad1_kernel: the LAST row of A (row a2_row = nA - 1 > 0) comes from a second region of the same buffer -- the alpha head's
+    // d_sigma next to the view layer's 128 delta rows: both contract against h7, which is then read once instead of twice.
+    int a2_row;                     // 0: none
+    unsigned a2_off;                // bytes from A (tile 0) to that row in tile 0 of the second region
+    int a2_tile_bytes;              // bytes per 32-point tile of the second region
+    int c_off2, bias_off2;          // where that row's gradient goes: out[c_off2 + k], out[bias_off2]
 };
 struct WgradArgs {
     WgradJob job[WG_MAX_JOBS];
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     // B constant along a ray: every 8-point group of feature f of a tile is the ray's 16-byte record of f (8 copies of the
     // value); the stage's source is the record block of the ray its tile belongs to
     const int ray_tiles = sop == 1 ? jb.b_ray_tiles : 0;
-    unsigned doff[4];
+    unsigned doff[4], dstep[4];     // source offset of the lane's piece in stage 0 of this chunk, and what it moves by per stage on top of the tile pitch
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int q = 64 * (4 * (wave & 3) + u) + lane;
@@ -473,6 +479,13 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
         const unsigned fc = (unsigned)min(f, swidth - 1), g = (unsigned)(jj ^ ((f >> 2) & 3));
         doff[u] = ray_tiles > 0 ? 16u * fc
                 : t16 ? (g >> 1) * 32u * (unsigned)sld + 32u * (unsigned)row16h((int)fc) + 16u * (g & 1u) : 64u * fc + 16u * g;
+        dstep[u] = 0u;
+        if (sop == 0 && jb.a2_row > 0 && f >= jb.a2_row) {
+            // rows from a2_row on (the pad rows repeat it): second region, whose tiles are a2_tile_bytes apart.  Unsigned wrap-around
+            // arithmetic: the sums below are the true (non-negative, < 4 GiB) offsets from this chunk's first tile of A
+            dstep[u] = (unsigned)jb.a2_tile_bytes - tile_bytes;
+            doff[u] = jb.a2_off + (unsigned)(p_begin >> 5) * dstep[u] + 16u * g;
+        }
     }
     const char* rbase = reinterpret_cast<const char*>(jb.B);
     const long tile0 = p_begin >> 5;
@@ -481,7 +494,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
         const char* src = ray_tiles > 0 ? rbase + (size_t)((tile0 + st) / ray_tiles) * (size_t)(16 * sld) : cbase + (size_t)st * tile_bytes;
         const unsigned dst = lds0 + (unsigned)(st & 3) * WG1_STAGE_BYTES;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dma_1k_s(src, doff[u], dst + 1024u * u);
+        for (int u = 0; u < 4; ++u) dma_1k_s(src, doff[u] + (unsigned)st * dstep[u], dst + 1024u * u);
     };
 
     f32x16 acc[4][2];
@@ -584,7 +597,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int n = wave_n * 128 + 32 * i + d32row(r, hf);
             if (n < jb.nA) {
-                float* orow = out + jb.c_off + (size_t)n * jb.ldc;
+                float* orow = (jb.a2_row > 0 && n == jb.a2_row) ? out + jb.c_off2 : out + jb.c_off + (size_t)n * jb.ldc;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int k = wave_k * 64 + 32 * j + row;
@@ -597,7 +610,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
         for (int i = 0; i < 4; ++i) {
             const float t = rowsum[i] + __shfl_xor(rowsum[i], 32);
             const int n = wave_n * 128 + 32 * i + row;
-            if (hf == 0 && n < jb.nA) out[jb.bias_off + n] = t;
+            if (hf == 0 && n < jb.nA) out[(jb.a2_row > 0 && n == jb.a2_row) ? jb.bias_off2 : jb.bias_off + n] = t;
         }
     }
 }
@@ -664,8 +677,12 @@ __global__ void wgrad_fold_kernel(const float* __restrict__ params, const float*
 }
 
 // ------------------------------------------------------------------ host side
-#ifndef NERF_WG_CHUNKS           // tuning knob of tools/build_variant.sh (A/B timing on one box); the shipped value: tools/EXPERIMENTS.md, round 5
-#define NERF_WG_CHUNKS 19
+// tuning knobs of tools/build_variant.sh (A/B timing on one box); the shipped values: tools/EXPERIMENTS.md, round 5
+#ifndef NERF_WG_MERGE_ALPHA
+#define NERF_WG_MERGE_ALPHA 1
+#endif
+#ifndef NERF_WG_CHUNKS
+#define NERF_WG_CHUNKS (NERF_WG_MERGE_ALPHA ? 21 : 19)
 #endif
 static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
     // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU).  fp32: 14 jobs x
@@ -837,15 +854,26 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         }
     }
     if (!fold) add(d_feat, W, W, x_h[D - 1], W, W, 1, cn.wf, W, cn.bf);
-    add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);           // alpha_linear (A = d_sigma, one row)
+    if (!(split16 && NERF_WG_MERGE_ALPHA)) add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);           // alpha_linear (A = d_sigma, one row)
     // fold: G = delta_hv^T h7 lands in the slot of Wv[:, :256]; wgrad_fold_kernel turns it into dWv[:, :256], dWf, dbf
     if (fold) {
         add(d_hv, WV, WV, x_h[D - 1], W, W, 1, cn.wv, W + IN_DIR, cn.bv);
+        if (split16 && NERF_WG_MERGE_ALPHA) {
+            // the alpha head's one row rides on the view layer's job (both contract against h7: 512 B per point read once instead of
+            // twice): row 128 of A = d_sigma = feature 3 of the 4-wide graw tiles of the same delta buffer
+            WgradJob& j = wa.job[nj - 1];
+            j.nA = WV + 1;
+            j.a2_row = WV;
+            j.a2_off = (unsigned)((reinterpret_cast<const char*>(d_sigma) - reinterpret_cast<const char*>(d_hv)));
+            j.a2_tile_bytes = 64 * ld_graw;
+            j.c_off2 = cn.wa;
+            j.bias_off2 = cn.ba;
+        }
     } else add(d_hv, WV, WV, x_feat, W, W, 1, cn.wv, W + IN_DIR, cn.bv);
     add(d_hv, WV, WV, x_dir, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
     if (split16 && S % 32 == 0 && nj <= WG_MAX_JOBS) wa.job[nj - 1].b_ray_tiles = S / 32;       // direction encoding: one record per ray
     add(d_rgb, ld_graw, 3, x_hv, WV, WV, 1, cn.wr, WV, cn.br);
-    if (nj != WG_MAX_JOBS - (fold ? 1 : 0)) return hipErrorInvalidValue;
+    if (nj != WG_MAX_JOBS - (fold ? 1 : 0) - (split16 && NERF_WG_MERGE_ALPHA ? 1 : 0)) return hipErrorInvalidValue;
     // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
     WgradArgs big{}, small{};
     int small_tiles = 0;
