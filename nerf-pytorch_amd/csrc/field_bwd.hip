@@ -18,6 +18,17 @@
 
 #include "launchers.h"
 
+// tuning knobs of tools/build_variant.sh (A/B timing on one box); the shipped values: tools/EXPERIMENTS.md, round 5
+#ifndef NERF_WG_MERGE_ALPHA
+#define NERF_WG_MERGE_ALPHA 1
+#endif
+#ifndef NERF_WG_CHUNKS
+#define NERF_WG_CHUNKS (NERF_WG_MERGE_ALPHA ? 21 : 19)
+#endif
+#ifndef NERF_WG_REDUCE_BATCH
+#define NERF_WG_REDUCE_BATCH 1
+#endif
+
 namespace nerf {
 
 // ------------------------------------------------------------------ dgrad chain
@@ -627,8 +638,20 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chu
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N_PARAMS) return;
     if (fold && i >= cn.wf && i < cn.bf + W) return;                    // produced by wgrad_fold_kernel (no partials exist)
+    // loads in batches of 8 (all issued before the first is added: the loop is latency-bound otherwise), sums in chunk order
     float s = 0.0f;
-    for (int cix = 0; cix < n_chunks; ++cix) s += partial[(size_t)cix * N_PARAMS + i];
+    const float* src = partial + i;
+    int cix = 0;
+#if NERF_WG_REDUCE_BATCH
+    for (; cix + 8 <= n_chunks; cix += 8) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = src[(size_t)(cix + t) * N_PARAMS];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s += v[t];
+    }
+#endif
+    for (; cix < n_chunks; ++cix) s += src[(size_t)cix * N_PARAMS];
     if (amax) s *= __uint_as_float(delta_scale_bits(amax[0], true));
     if (fold) {
         if (i >= cn.wv && i < cn.bv) {
@@ -644,7 +667,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int n_chu
 // Gradients of the two layers the split datapaths evaluate as one (nerf_common.h, folded feature layer), from
 // G = delta_hv^T h7 [128][256] and dbv [128]:   dWv[:, :256] = G Wf^T + dbv bf^T,  dWf = Wv[:, :256]^T G,
 // dbf = Wv[:, :256]^T dbv.   Plain fp32 FMA loops (K = 256 / 128): 16.8 MFLOP, one thread per output
-// (eight lanes per output with a shuffle reduction, as derive_folded_kernel does, measured slower: 17.7 vs 14.2 us per launch).
+// (eight lanes per output with a shuffle reduction, as derive_folded_kernel does, measured slower: 17.7 vs 14.2 us per launch; four
+// interleaved partial sums per output instead of one 256-long FMA chain: no change, round 5).
 __global__ void wgrad_fold_kernel(const float* __restrict__ params, const float* __restrict__ scratch, float* __restrict__ grad,
                                   int accumulate) {
     constexpr Canon cn = canon();
@@ -677,13 +701,6 @@ __global__ void wgrad_fold_kernel(const float* __restrict__ params, const float*
 }
 
 // ------------------------------------------------------------------ host side
-// tuning knobs of tools/build_variant.sh (A/B timing on one box); the shipped values: tools/EXPERIMENTS.md, round 5
-#ifndef NERF_WG_MERGE_ALPHA
-#define NERF_WG_MERGE_ALPHA 1
-#endif
-#ifndef NERF_WG_CHUNKS
-#define NERF_WG_CHUNKS (NERF_WG_MERGE_ALPHA ? 21 : 19)
-#endif
 static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
     // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU).  fp32: 14 jobs x
     // 128 = 7 x 256 (the 8 full-width jobs x 128 = 4 x 256).  Split datapaths (13 jobs, 16-bit operands, wgrad1_kernel): 13 x 19 = 247

@@ -1,0 +1,8 @@
+mkdir -p gpurun_out
+V=nerf-pytorch_amd/build/variants
+for i in 1 2 3; do
+  for lib in nerf-pytorch_amd/libnerf_hip.so $V/libnerf_hip_nobatch.so $V/libnerf_hip_fold4.so; do
+    NERF_HIP_LIB=$lib python tools/time_kernels.py --only wgrad_reduce --reps 50 2>/dev/null | tail -1
+  done
+done > gpurun_out/r05q_reduce.log
+cat gpurun_out/r05q_reduce.log
