@@ -28,6 +28,9 @@
 #ifndef NERF_WG_REDUCE_BATCH
 #define NERF_WG_REDUCE_BATCH 1
 #endif
+#ifndef NERF_WG1_STAGES
+#define NERF_WG1_STAGES 4
+#endif
 
 namespace nerf {
 
@@ -438,8 +441,8 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(WgradArgs a) {
 constexpr int WG1_STAGE_PTS = 32;
 constexpr int WG1_OP_BYTES = 256 * 64;                           // 16 KiB: [256 features][32 points] bf16
 constexpr int WG1_STAGE_BYTES = 2 * WG1_OP_BYTES;
-constexpr int WG1_STAGES = 4;
-constexpr int WG1_LDS_BYTES = WG1_STAGES * WG1_STAGE_BYTES;      // 128 KiB
+constexpr int WG1_STAGES = NERF_WG1_STAGES;                      // 4: 128 KiB of LDS, three stages (96 KiB) in flight; 5: all 160 KiB, four in flight
+constexpr int WG1_LDS_BYTES = WG1_STAGES * WG1_STAGE_BYTES;
 
 __device__ inline void dma_1k_s(const void* sbase, unsigned voff, unsigned lds_dst_uniform) {
     unsigned keep;
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     const unsigned lds0 = lds_addr(sm1) + (unsigned)(sop * WG1_OP_BYTES + (wave & 3) * 4096);
     auto issue = [&](int st) {
         const char* src = ray_tiles > 0 ? rbase + (size_t)((tile0 + st) / ray_tiles) * (size_t)(16 * sld) : cbase + (size_t)st * tile_bytes;
-        const unsigned dst = lds0 + (unsigned)(st & 3) * WG1_STAGE_BYTES;
+        const unsigned dst = lds0 + (unsigned)(st % WG1_STAGES) * WG1_STAGE_BYTES;
 #pragma unroll
         for (int u = 0; u < 4; ++u) dma_1k_s(src, doff[u] + (unsigned)st * dstep[u], dst + 1024u * u);
     };
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     };
     auto compute = [&](int st) {
         if (!wave_has_work) return;
-        const unsigned char* stage = sm1 + (st & 3) * WG1_STAGE_BYTES;
+        const unsigned char* stage = sm1 + (st % WG1_STAGES) * WG1_STAGE_BYTES;
         const unsigned char* sa = stage + (wave_n * 128) * 64;
         const unsigned char* sb = stage + WG1_OP_BYTES + (wave_k * 64) * 64;
         const int left = nrows - st * WG1_STAGE_PTS;
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     // fragment whether its rows exist, whether the stage is ragged and whether bias sums are wanted: a branch, i.e. a
     // scheduling barrier, between every pair of MFMAs, each pair waiting for its own ds_read_b128.)
     auto compute_full = [&](int st, auto with_bias) {
-        const unsigned char* stage = sm1 + (st & 3) * WG1_STAGE_BYTES;
+        const unsigned char* stage = sm1 + (st % WG1_STAGES) * WG1_STAGE_BYTES;
         const unsigned char* sa = stage + (wave_n * 128) * 64;
         const unsigned char* sb = stage + WG1_OP_BYTES + (wave_k * 64) * 64;
 #pragma unroll
@@ -588,7 +591,8 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     for (int st = 0; st < WG1_STAGES - 1; ++st)
         if (st < n_st) issue(st);
     auto enter = [&](int st) {
-        if (st + 2 < n_st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (WG1_STAGES >= 5 && st + 3 < n_st) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (st + 2 < n_st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (st + 1 < n_st) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();        // every wave's pieces landed; everybody is done with stage st-1, whose slot is reused now
