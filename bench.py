@@ -31,8 +31,8 @@ table (`kernels`, `roofline`) comes from a separate pass over the same steps.  P
 `roofline`: `achieved` = ALGORITHMIC FLOP of the reference's layer stack (1,186,816 per point and forward
 evaluation: run_nerf_helpers.py:96-119) processed by one launch of the dominant kernel / its average launch time, `frac` =
 achieved / the dense MFMA peak of the arithmetic type the datapath computes in (bf16: 2.5 PFLOP/s; f32: 157.3 TFLOP/s).
-The split-bf16 datapath issues three bf16 MFMAs per product and executes one folded layer less than the reference; the
-fraction of the MFMA pipe its instructions occupy is reported next to it as `mfma_busy_frac` and is NOT the roofline
+The split datapaths issue three 16-bit MFMAs per product and execute one folded layer less than the reference; the
+fraction of the MFMA pipe their instructions occupy is reported next to it as `mfma_busy_frac` and is NOT the roofline
 fraction.
 """
 import argparse

@@ -228,7 +228,7 @@ int nerf_buffer_layout(const float* buf, int* is_delta, int* n_rays, int* n_samp
 int nerf_debug_layout(int n_rays, int n_samples, int family, int is_delta, long long* out_host);
 /* The weight gradients dW = delta^T x, db = sum delta of one evaluation (the second half of nerf_field_bwd; the only form on the
  * split datapaths), split into launches a profiler can bracket: phases bit 0 = the GEMM jobs (fp32: the eight full-width 256x256
- * jobs; split datapaths: all 13 jobs on the streaming 16-bit GEMM), bit 1 = the six narrow jobs (fp32 datapath only), bit 2 =
+ * jobs; split datapaths: all jobs on the streaming 16-bit GEMM), bit 1 = the six narrow jobs (fp32 datapath only), bit 2 =
  * reduction of the per-chunk partial gradients into grad (deterministic, no atomics; + the folded feature layer's gradients).
  * Calling it with phases 1, 2, 4 in that order equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(WgradArgs a) {
 }
 
 // ------------------------------------------------------------------ streaming weight gradients of the split datapaths (16-bit operands)
-// 13 jobs, operands saved as 16-bit elements (bf16 or fp16: SP) in 32-point feature-major tiles (64-byte rows): a lane's MFMA
+// 12 jobs (13 before the alpha head's row joined the view layer's job), operands saved as 16-bit elements (bf16 or fp16: SP) in 32-point feature-major tiles (64-byte rows): a lane's MFMA
 // fragment (8 consecutive points of one feature = 16 B) is in memory as is, so the kernel is pure streaming:
 // HBM -> LDS by DMA into a ring of 4 stages (one stage = one 32-point tile of both operands = 32 KiB = 32
 // wave-instructions of global_load_lds_dwordx4, three stages = 96 KiB per CU in flight), ds_read_b128, one bf16 MFMA
@@ -707,8 +707,8 @@ __global__ void wgrad_fold_kernel(const float* __restrict__ params, const float*
 // ------------------------------------------------------------------ host side
 static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
     // point chunks such that jobs x chunks fills whole rounds of 256 workgroups (one workgroup per CU).  fp32: 14 jobs x
-    // 128 = 7 x 256 (the 8 full-width jobs x 128 = 4 x 256).  Split datapaths (13 jobs, 16-bit operands, wgrad1_kernel): 13 x 19 = 247
-    // workgroups = ONE round for every launch size.  Rounds 2-4 gave launches above 400 k points 39 chunks (507 workgroups = two
+    // 128 = 7 x 256 (the 8 full-width jobs x 128 = 4 x 256).  Split datapaths (12 jobs, 16-bit operands, wgrad1_kernel): 12 x 21 = 252
+    // workgroups (13 jobs: 13 x 19 = 247) = ONE round for every launch size.  Rounds 2-4 gave launches above 400 k points 39 chunks (507 workgroups = two
     // rounds); measured in round 5 on one box, alternating builds, fine launch (786,432 points): 39 chunks GEMM 1.312 ms + reduction
     // 0.037 ms; 26 chunks (1.3 rounds) 1.726 + 0.030; 19 chunks 1.281 + 0.026 -- a workgroup streaming twice the points keeps its
     // 96 KiB of DMA in flight just the same, and the deterministic reduction reads half the partial sums.  (Pairing the narrow jobs

@@ -192,9 +192,9 @@ BYTES_ACT3_PER_POINT = BYTES_ACT_PER_POINT - 4 * 256
 BYTES_DELTA3_PER_POINT = BYTES_DELTA_PER_POINT - 4 * 256
 BYTES_ACT3_BF16_PER_POINT = 2 * (8 * 256 + 128 + 64) + 32 * 9 + 16  # bf16 rows + encodings, ReLU bitmasks, raw
 BYTES_DELTA3_BF16_PER_POINT = 2 * (8 * 256 + 128 + 4)
-BYTES_WGRAD_MIXED_PER_POINT = 0.5 * (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256))   # 13 jobs, bf16 operands
-# bf16x3: the alpha_linear gradient rides on the staging of the (delta_hv, h7) job — h7 is not re-read for it (12 jobs)
-BYTES_WGRAD3_PER_POINT = BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256) - 4 * 256
+# 12 jobs on 16-bit operands (round 5: the alpha head's row rides on the (delta_hv, h7) job -- h7 is not re-read for it): 9,808 B per
+# point (PMC: 9.83 KB)
+BYTES_WGRAD_MIXED_PER_POINT = 0.5 * (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256)) - 2 * 256
 
 
 N_PARAMS = 595844
@@ -754,7 +754,7 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
     if TIMER is None:
         _check(L.nerf_field_wgrad_phase(*args, 7, *tail), "nerf_field_wgrad_phase")
         return grad
-    if gemm16:      # all 13 jobs stream 16-bit operands straight into the MFMA
+    if gemm16:      # all 12 jobs stream 16-bit operands straight into the MFMA
         with _timed("wgrad1_kernel<fp16>" if split else "wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD_MIXED_PER_POINT * P):
             _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
     else:

@@ -6,7 +6,11 @@ proven bit-identical, word for word of every buffer, to the double-buffered kern
 `test_ring_forward_bit_identical` / `test_ring_dgrad_bit_identical` against the test-only libnerf_hip_ref.so, green in the same GPU
 run; that library and csrc/ref were deleted afterwards).  They are NOT parity evidence -- parity is the oracle / golden tests --
 they pin the arithmetic: a refactor of a kernel (register allocation, scratch layout, launch merging) must reproduce every
-digest, and a deliberate change of arithmetic must re-record them and say so in its commit.
+digest, and a deliberate change of arithmetic must re-record them and say so in its commit.  Re-recorded since (round 5): the
+no_grad outputs of the reduced class on coarse + fine renderings (its coarse pass moved to the three-term products), and the
+GRADIENT digests of the split datapaths (`grad*`, `params_c`, `after_step.*`) when the weight-gradient GEMM went from 13 jobs x 19
+point chunks to 12 x 21 -- the same products summed over other chunk boundaries; forward, save-buffer and delta digests stand as first
+recorded.
 
 Digests are taken over LOGICAL views (hip_backend.saved_rows / delta_rows / saved_masks: point-major [P, F] tensors), so the
 physical layout of the scratch buffers may change without touching the fixture.
