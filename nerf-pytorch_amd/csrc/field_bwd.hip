@@ -22,9 +22,6 @@
 #ifndef NERF_WG_MERGE_ALPHA
 #define NERF_WG_MERGE_ALPHA 1
 #endif
-#ifndef NERF_WG_CHUNKS
-#define NERF_WG_CHUNKS (NERF_WG_MERGE_ALPHA ? 21 : 19)
-#endif
 #ifndef NERF_WG_REDUCE_BATCH
 #define NERF_WG_REDUCE_BATCH 1
 #endif
@@ -714,7 +711,7 @@ static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
     // 96 KiB of DMA in flight just the same, and the deterministic reduction reads half the partial sums.  (Pairing the narrow jobs
     // into one workgroup so that all workgroups stream equal bytes -- 11 "virtual jobs" x 23 chunks -- measured 1.84 ms: the job loop
     // costs the kernel its schedule, 192 -> 255 VGPRs; not kept.)  Small inputs get >= 256-point chunks.
-    long n = n_jobs == 14 ? 128 : NERF_WG_CHUNKS;
+    long n = n_jobs == 14 ? 128 : 256 / n_jobs;       // 12 jobs: 21 chunks, 13 jobs: 19
     const long cap = (P + 255) / 256;
     if (n > cap) n = cap;
     if (n < 1) n = 1;
@@ -727,7 +724,7 @@ static int wgrad_chunks(long P, int* chunk_pts, int n_jobs = 14) {
 size_t wgrad_partial_floats(long P) {
     // sized for either job count, plus the scratch of the folded feature layer (G | dbv) behind the partial sums
     int pts;
-    const int n14 = wgrad_chunks(P, &pts, 14), n13 = wgrad_chunks(P, &pts, 13);
+    const int n14 = wgrad_chunks(P, &pts, 14), n13 = wgrad_chunks(P, &pts, 12);      // (12 jobs: the most chunks a split launch uses)
     return (size_t)(n14 > n13 ? n14 : n13) * N_PARAMS + N_DERIVED;
 }
 
@@ -875,11 +872,15 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         }
     }
     if (!fold) add(d_feat, W, W, x_h[D - 1], W, W, 1, cn.wf, W, cn.bf);
-    if (!(split16 && NERF_WG_MERGE_ALPHA)) add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);           // alpha_linear (A = d_sigma, one row)
+    // (the merged job addresses d_sigma through a 32-bit lane offset from d_hv: kept below 2 GiB -- launches beyond ~9 M points keep
+    // the alpha head as a job of its own)
+    const bool merge_alpha = split16 && NERF_WG_MERGE_ALPHA &&
+                             reinterpret_cast<const char*>(d_sigma) - reinterpret_cast<const char*>(d_hv) < (1L << 31);
+    if (!merge_alpha) add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);           // alpha_linear (A = d_sigma, one row)
     // fold: G = delta_hv^T h7 lands in the slot of Wv[:, :256]; wgrad_fold_kernel turns it into dWv[:, :256], dWf, dbf
     if (fold) {
         add(d_hv, WV, WV, x_h[D - 1], W, W, 1, cn.wv, W + IN_DIR, cn.bv);
-        if (split16 && NERF_WG_MERGE_ALPHA) {
+        if (merge_alpha) {
             // the alpha head's one row rides on the view layer's job (both contract against h7: 512 B per point read once instead of
             // twice): row 128 of A = d_sigma = feature 3 of the 4-wide graw tiles of the same delta buffer
             WgradJob& j = wa.job[nj - 1];
@@ -894,7 +895,7 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     add(d_hv, WV, WV, x_dir, 32, IN_DIR, 1, cn.wv + W, W + IN_DIR, -1);
     if (split16 && S % 32 == 0 && nj <= WG_MAX_JOBS) wa.job[nj - 1].b_ray_tiles = S / 32;       // direction encoding: one record per ray
     add(d_rgb, ld_graw, 3, x_hv, WV, WV, 1, cn.wr, WV, cn.br);
-    if (nj != WG_MAX_JOBS - (fold ? 1 : 0) - (split16 && NERF_WG_MERGE_ALPHA ? 1 : 0)) return hipErrorInvalidValue;
+    if (nj != WG_MAX_JOBS - (fold ? 1 : 0) - (merge_alpha ? 1 : 0)) return hipErrorInvalidValue;
     // full-width jobs -> wgrad256_kernel (whole 256x256 output per workgroup); the rest -> 128x128 tiles
     WgradArgs big{}, small{};
     int small_tiles = 0;
