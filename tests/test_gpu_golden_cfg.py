@@ -125,3 +125,44 @@ def test_golden_cfg4_32768_rays_reduced_inference_class(npa, dev, nets):
         _check_golden_forward_reduced(npa, dev, nets, "lego_cfg4_forward", dict(perturb=1.0), 2024, render=(orc.LEGO, orc.lego_batch(n, seed=19)), n=n)
     finally:
         tp._golden_randoms = keep
+
+
+def test_largest_single_launch_matches_two_half_launches(npa, dev, nets):
+    """Round 5 sized the split datapaths' scratch for 16-bit elements: ONE launch now takes hb.max_saved_rays(64, 128, "fp16x3") =
+    21,504 rays x 192 samples = 4.1 M points -- 256-wide regions of 2.1 GB (just under 2^31 bytes), twice what any launch of rounds
+    1-4 addressed.  The same rays as two launches of half the size: outputs bit-identical (rays are independent), gradients equal
+    up to the summation order of the weight-gradient chunks."""
+    import sys
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    render_mod = sys.modules[npa.parallel.__name__.rsplit(".", 1)[0] + ".render"]
+    npa.set_precision("fp16x3")
+    try:
+        n = hb.max_saved_rays(64, 128, "fp16x3")
+        assert n >= 20480 and n * 192 * 512 > 2 ** 30
+        rays = orc.synthetic_rays(n, seed=5).to(dev)
+        g = torch.Generator().manual_seed(9)
+        rnd = {"t_rand": torch.rand(n, 64, generator=g).to(dev), "u": torch.rand(n, 128, generator=g).to(dev)}
+        target = torch.rand(n, 3, generator=g).to(dev)
+        kw = dict(N_samples=64, N_importance=128, network_fine=nf, white_bkgd=True, perturb=1.0, retraw=False)
+
+        def run(lo, hi):
+            for m in (nc, nf):
+                m.zero_grad()
+            out = npa.render_rays(rays[lo:hi], nc, None, randoms={k: v[lo:hi] for k, v in rnd.items()}, **kw)
+            plan = render_mod.LAST_BACKWARD_PLAN
+            (((out["rgb_map"] - target[lo:hi]) ** 2).sum() + ((out["rgb0"] - target[lo:hi]) ** 2).sum()).backward()
+            return out["rgb_map"].detach().clone(), out["acc0"].detach().clone(), torch.cat([nc.last_flat_grad, nf.last_flat_grad]).double(), plan
+        rgb, acc0, g_all, plan = run(0, n)
+        assert plan[0] == "one launch", plan
+        r1, a1, g1, _ = run(0, n // 2)
+        r2, a2, g2, _ = run(n // 2, n)
+    finally:
+        npa.set_precision("fp32")
+        hb.WORKSPACE.clear()
+        torch.cuda.empty_cache()
+    assert torch.equal(rgb, torch.cat([r1, r2])) and torch.equal(acc0, torch.cat([a1, a2]))
+    assert bool(torch.isfinite(g_all).all()) and float(g_all.abs().max()) > 0
+    rel = float((g_all - (g1 + g2)).norm() / (g1 + g2).norm())
+    print("largest single launch:", n, "rays; gradient vs two half launches (rel L2):", rel)
+    assert rel <= 1e-4, rel
