@@ -133,15 +133,15 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     // one paired 16-bit store: rows (r, r + 1) of 32-feature block ob of a F-wide region (32-point feature-major tiles,
     // nerf_common.h), `own` = the two values of this lane's point
     auto store_pair16 = [&](size_t region_off, int F, int ob, int r, unsigned own) __attribute__((always_inline)) {
-        const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
         unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.delta + (tile_ok ? region_off : dl.feat))
                                                      + (tile_ok ? tile * (size_t)(F * 32) : (size_t)0)) + pair_off;
-        nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, __builtin_amdgcn_perm(nbr, own, pair_sel));
+        paired_store(own, pair_sel, [&](unsigned word) __attribute__((always_inline)) { nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word); });
     };
     // the deltas in `v` (value 16 ob + r) leave while the next contraction consumes them: unit i of NU writes its share
     // (NV / NU values as 16-bit pairs)
     size_t store_region = 0;
-    constexpr int NP = 8;       // row stores guaranteed behind the last fetch part (two per unit, positions 3..6)
+    // row stores guaranteed behind the last fetch part (two per unit, positions 3..6); none under the store-less timing ablations
+    constexpr int NP = (NERF_ABL_SAVE == 1 || NERF_ABL_SAVE == 3) ? 0 : 8;
 
     // ---- view branch folded with feature_linear (nerf_common.h): delta of the trunk output =
     //      (alpha_linear^T d_sigma + W'^T d_hv) * relu'(h7); the feature_linear^T units of the stream are skipped

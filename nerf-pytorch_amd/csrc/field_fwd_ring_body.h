@@ -82,11 +82,9 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     // rows (r0, r0 + 1) of block nb of this lane's point, paired with the neighbour point: one dword store (unconditional;
     // a wave whose tile lies beyond the padded range writes to the unused `feat` region)
     auto store_word = [&](size_t region, int F, int nb, int r0, unsigned own) __attribute__((always_inline)) {
-        const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
-        const unsigned word = __builtin_amdgcn_perm(nbr, own, pair_sel);
         char* tile_base = act_bytes + 4 * (tile_ok ? region : al.feat) + (tile_ok ? (size_t)tile16 * (size_t)(F * 32) : (size_t)0)
                           + (size_t)((16 * nb + 4 * r0) * 32);
-        nt_store_saddr(tile_base, lane_pair_bytes, word);
+        paired_store(own, pair_sel, [&](unsigned word) __attribute__((always_inline)) { nt_store_saddr(tile_base, lane_pair_bytes, word); });
     };
     if (SAVE) {
         al = act_layout3((size_t)P, (size_t)a.n_rays);
@@ -111,7 +109,8 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[4 * nb + r] = relu(acc[nb][r]);
     };
-    constexpr int NP = SAVE ? 4 : 0;        // row stores guaranteed behind the last fetch part (one per unit, positions 3..6)
+    // row stores guaranteed behind the last fetch part (one per unit, positions 3..6); none under the store-less timing ablations
+    constexpr int NP = (SAVE && NERF_ABL_SAVE != 1 && NERF_ABL_SAVE != 3) ? 4 : 0;
     auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
         store_word(region, F, nb, r0, SP::cvt_pk(v0, v1));
     };

@@ -15,7 +15,26 @@
 #pragma once
 #include "field_device.h"
 
+// TIMING-ONLY ablations of the paired 16-bit stores (tools/exp_save_ablation.sh, round 6; results are wrong for every value but 0):
+//   0 = product; 1 = pack + DPP swap + v_perm, no store; 2 = store of the lane's own word, no DPP / v_perm; 3 = neither
+#ifndef NERF_ABL_SAVE
+#define NERF_ABL_SAVE 0
+#endif
+
 namespace nerf {
+
+// one paired store under the ablation switch: `own` = this lane's packed word, sel = its v_perm selector
+template <typename Store>
+__device__ __forceinline__ void paired_store(unsigned own, unsigned sel, Store store) {
+    if constexpr (NERF_ABL_SAVE == 3) { asm volatile("" ::"v"(own)); return; }
+    unsigned word = own;
+    if constexpr (NERF_ABL_SAVE != 2) {
+        const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
+        word = __builtin_amdgcn_perm(nbr, own, sel);
+    }
+    if constexpr (NERF_ABL_SAVE == 1) { asm volatile("" ::"v"(word)); return; }
+    store(word);
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -111,8 +130,7 @@ __device__ __forceinline__ void store_tile16_pair(unsigned short* tile_base, int
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const unsigned own = SP::cvt_pk(v[16 * ob + r], v[16 * ob + r + 1]);
-            const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
-            nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, __builtin_amdgcn_perm(nbr, own, sel));
+            paired_store(own, sel, [&](unsigned word) __attribute__((always_inline)) { nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word); });
         }
 }
 

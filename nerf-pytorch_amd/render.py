@@ -470,10 +470,55 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
     return out.reshape(lead + [N_samples])
 
 
+def builtin_query_fn(fn):
+    """Mark `fn` as the stock network_query_fn (run_network with the stock embedders, run_nerf.py:201-204): render_rays then takes the
+    fused path, in which encoding, network and netchunk tiling happen inside one kernel.  create_nerf marks the lambda it builds."""
+    fn._nerf_amd_builtin = True
+    return fn
+
+
+def _is_builtin_query(network_query_fn):
+    return network_query_fn is None or getattr(network_query_fn, "_nerf_amd_builtin", False)
+
+
+def _render_rays_hooked(rays, rnd, network_fn, network_query_fn, N_samples, n_f, network_fine, lindisp, white_bkgd, std, retraw):
+    """render_rays with a USER-SUPPLIED network_query_fn (run_nerf.py:385, :401 call it for every pass): the hook sees the reference's
+    arguments -- pts [N, S, 3], viewdirs [N, 3], the network module -- and whatever it returns is composited, exactly as in the
+    reference (a density regulariser, a clamp, a different network call all work).  Stage by stage through the C ABI: coarse depths
+    (nerf_sample_coarse), the hook (stock run_network -> nerf_field_fwd / dgrad / wgrad per point), raw2outputs with its adjoint
+    (nerf_raw2outputs[_bwd]), hierarchical depths (nerf_sample_fine: sample_pdf + sort, a constant as in run_nerf.py:394)."""
+    dev = rays.device
+    rays_o, rays_d, viewdirs = rays[:, 0:3], rays[:, 3:6].contiguous(), rays[:, 8:11]
+
+    def one_pass(z_vals, net, noise):
+        pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]       # run_nerf.py:381 / :397
+        raw = network_query_fn(pts, viewdirs, net)
+        return raw, _Composite.apply(raw.to(torch.float32).contiguous(), z_vals, rays_d, noise, std, bool(white_bkgd))
+
+    z_c = hb.sample_coarse(rays, _linspace01(N_samples, dev), lindisp, rnd.get("t_rand"))
+    raw, (rgb, disp, acc, weights, _) = one_pass(z_c, network_fn, rnd.get("noise_c"))
+    ret = {}
+    if n_f > 0:
+        ret.update(rgb0=rgb, disp0=disp, acc0=acc)
+        u = rnd.get("u")
+        z_f, z_std, _ = hb.sample_fine(z_c, weights.detach().contiguous(), n_f, u, None if u is not None else _linspace01(n_f, dev))
+        raw, (rgb, disp, acc, _, _) = one_pass(z_f, network_fn if network_fine is None else network_fine, rnd.get("noise_f"))
+        ret["z_std"] = z_std
+    ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc)
+    if retraw:
+        ret["raw"] = raw
+    return ret
+
+
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
                 *, randoms=None):
     """run_nerf.py:308-418.  Same arguments, same returned dict.
+
+    ``network_query_fn``: None or the function create_nerf built (builtin_query_fn) -> the fused path; ANY other callable is called
+    for every pass with (pts, viewdirs, network) like the reference does (_render_rays_hooked).  ``verbose`` is accepted and prints
+    nothing (run_nerf.py:414-416's DEBUG-gated NaN check: see render.check_range()); the reference's ``netchunk`` has no counterpart
+    (the kernels tile the points themselves).
 
     ``randoms`` (keyword-only, not in the reference) injects the random tensors
     {t_rand [N,N_samples], noise_c [N,N_samples], u [N,N_importance], noise_f [N,N_samples+N_importance]}
@@ -532,14 +577,20 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             if pytest:
                 np.random.seed(0)
                 rnd["u"] = torch.Tensor(np.random.rand(n, n_f)).to(dev)
-        elif pytest:
-            pass        # det + pytest: np.linspace == torch.linspace to fp32 rounding; kernel uses torch.linspace
+        elif pytest and randoms is None:
+            # det + pytest: the reference builds u with np.linspace in float64 and casts it (helpers:213-215), which is NOT
+            # torch.linspace's fp32 sequence (one ulp apart in 30 of 64 / 8 of 128 entries: tests/test_host_cpu.py) -- hand the
+            # kernel the reference's numbers as explicit draws
+            rnd["u"] = torch.Tensor(np.broadcast_to(np.linspace(0., 1., n_f), (n, n_f)).copy()).to(dev)
         if raw_noise_std > 0. and randoms is None:
             rnd["noise_f"] = draw_noise(N_samples + n_f)
     if pytest and raw_noise_std > 0. and randoms is None:
         std = 1.0       # pytest noise is pre-scaled in float64 like the reference (run_nerf.py:290)
     cfg = dict(N_samples=int(N_samples), N_importance=n_f, lindisp=bool(lindisp), white_bkgd=bool(white_bkgd),
                raw_noise_std=std, precision=_PRECISION)
+    if not _is_builtin_query(network_query_fn):
+        return _render_rays_hooked(rays, rnd, network_fn, network_query_fn, int(N_samples), n_f, network_fine if n_f > 0 else None,
+                                   bool(lindisp), white_bkgd, std, retraw)
     if dense:
         from .dense import render_rays_dense
         ret = render_rays_dense(cfg, rays, rnd, network_fn, network_fine if n_f > 0 else None)

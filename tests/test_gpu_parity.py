@@ -43,6 +43,21 @@ def nets(npa, dev):
     return nc, nf, Pc, Pf
 
 
+# The datapath of a boundary test: "fp32" = the exact anchor (the suite's default, tests/conftest.py), "fp16x3" = what a user gets
+# without asking (render.DEFAULT_PRECISION).  BOUNDARY_TOL: per-ray / per-entry bounds of those tests on each (GOLD_TOL's classes).
+BOUNDARY_DATAPATHS = ["fp32", "fp16x3"]
+BOUNDARY_TOL = {"fp32": dict(coarse=1e-5, fine=1e-5, field=2e-4, grad=2e-3, loss=2e-4),
+                "fp16x3": dict(coarse=3e-5, fine=3e-5, field=2e-4, grad=4e-3, loss=2e-4)}
+
+
+@pytest.fixture
+def datapath(npa, request):
+    prev = npa.get_precision()
+    npa.set_precision(request.param)
+    yield request.param
+    npa.set_precision(prev)
+
+
 def maxdiff(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     both_nan = torch.isnan(a) & torch.isnan(b)
@@ -330,7 +345,8 @@ def test_raw2outputs_weight_and_depth_gradients(npa, dev):
     assert maxdiff(rawg2.grad, raw64b.grad) <= 2e-5 * max(1.0, float(raw64b.grad.abs().max()))
 
 
-def test_render_rays_raw_output_carries_gradients(npa, dev):
+@pytest.mark.parametrize("datapath", BOUNDARY_DATAPATHS, indirect=True)
+def test_render_rays_raw_output_carries_gradients(npa, dev, datapath):
     """extras['raw'] is differentiable in the reference (a sigma regulariser on raw[..., 3] trains the networks)."""
     Pc, Pf = orc.scene_params(seed=3)
     kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
@@ -349,11 +365,12 @@ def test_render_rays_raw_output_carries_gradients(npa, dev):
     assert stable.all(), "pick another seed: this test wants no endpoint-unstable ray"
     for k, p in nf.named_parameters():
         r = Pf_g[k].grad
-        assert maxdiff(p.grad, r) <= 2e-3 * float(r.abs().max()) + 1e-9, (k, maxdiff(p.grad, r), float(r.abs().max()))
+        assert maxdiff(p.grad, r) <= BOUNDARY_TOL[datapath]["grad"] * float(r.abs().max()) + 1e-9, (k, maxdiff(p.grad, r), float(r.abs().max()))
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in nc.parameters())   # coarse net: rgb0 not in this loss
 
 
-def test_second_backward_fails_loudly(npa, dev, nets):
+@pytest.mark.parametrize("datapath", BOUNDARY_DATAPATHS, indirect=True)
+def test_second_backward_fails_loudly(npa, dev, nets, datapath):
     nc, nf, Pc, Pf = nets
     rays = orc.synthetic_rays(8, seed=1).to(dev)
     out = npa.render_rays(rays, nc, None, 64, N_importance=128, network_fine=nf, white_bkgd=True)
@@ -1203,7 +1220,8 @@ def test_large_chunks_backpropagate_in_subchunks(npa, dev, nets, precision, monk
     assert torch.equal(gc_t, gc_b) and torch.equal(gf_t, gf_b)      # same sub-chunks, same kernels: the two modes agree bit for bit
 
 
-def test_training_steps_reuse_the_same_workspace_buffers(npa, dev, nets):
+@pytest.mark.parametrize("datapath", BOUNDARY_DATAPATHS, indirect=True)
+def test_training_steps_reuse_the_same_workspace_buffers(npa, dev, nets, datapath):
     """No per-step allocation of the backward scratch: consecutive steps lease the same device buffers (hb.WORKSPACE)."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
@@ -1230,7 +1248,9 @@ def test_training_steps_reuse_the_same_workspace_buffers(npa, dev, nets):
 
 
 # ---------------------------------------------------------------- boundary: render() / run_network / NeRF.forward
-def test_render_boundary_and_chunking(npa, dev, nets):
+@pytest.mark.parametrize("datapath", BOUNDARY_DATAPATHS, indirect=True)
+def test_render_boundary_and_chunking(npa, dev, nets, datapath):
+    tol = BOUNDARY_TOL[datapath]
     nc, nf, Pc, Pf = nets
     H, W, focal = 12, 16, 20.0
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
@@ -1249,11 +1269,15 @@ def test_render_boundary_and_chunking(npa, dev, nets):
     flat = orc.assemble_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 2., 6.)
     ref = orc.trace_rays(flat, Pc, Pf, 64, 128, perturb=0., white_bkgd=True)
     stable = ~orc.endpoint_unstable(ref["_weights0"])
-    assert maxdiff(extras["rgb0"].reshape(-1, 3), ref["rgb0"]) <= 1e-5
+    assert maxdiff(extras["rgb0"].reshape(-1, 3), ref["rgb0"]) <= tol["coarse"]
     ref64 = orc.trace_rays(flat.double(), {k: v.double() for k, v in Pc.items()}, {k: v.double() for k, v in Pf.items()},
                            64, 128, perturb=0., white_bkgd=True)
     floor = maxdiff(ref["rgb_map"][stable], ref64["rgb_map"][stable])
-    assert maxdiff(rgb.reshape(-1, 3)[stable], ref["rgb_map"][stable]) <= max(1e-5, 10 * floor)
+    if datapath == "fp32":
+        assert maxdiff(rgb.reshape(-1, 3)[stable], ref["rgb_map"][stable]) <= max(tol["fine"], 10 * floor)
+    else:   # the split datapaths' fine pass: p95 + worst ray, as the goldens hold it (GOLD_TOL: sample_pdf amplifies any coarse rounding)
+        err = (rgb.reshape(-1, 3).cpu() - ref["rgb_map"]).abs().max(-1)[0][stable]
+        assert float(err.quantile(0.95)) <= max(tol["fine"], 10 * floor) and float(err.max()) <= 5e-3, (float(err.quantile(0.95)), float(err.max()))
     # run_network / NeRF.forward on explicit points
     pts = torch.randn(7, 5, 3)
     vd = torch.nn.functional.normalize(torch.randn(7, 3), dim=-1)
@@ -1262,8 +1286,8 @@ def test_render_boundary_and_chunking(npa, dev, nets):
         emb = torch.cat([orc.posenc(pts.reshape(-1, 3), 10), orc.posenc(vd[:, None].expand(7, 5, 3).reshape(-1, 3), 4)], -1)
         got2 = nf(emb.to(dev))
     ref = orc.query_field(Pf, pts, vd)
-    assert maxdiff(got, ref) <= 2e-4 * max(1.0, float(ref.abs().max()) / 10)
-    assert maxdiff(got2.reshape(7, 5, 4), ref) <= 2e-4 * max(1.0, float(ref.abs().max()) / 10)
+    assert maxdiff(got, ref) <= tol["field"] * max(1.0, float(ref.abs().max()) / 10)
+    assert maxdiff(got2.reshape(7, 5, 4), ref) <= tol["field"] * max(1.0, float(ref.abs().max()) / 10)
 
 
 @pytest.mark.parametrize("ndc", [False, True])
@@ -1314,7 +1338,8 @@ def test_assemble_rays_matches_reference_ray_assembly(npa, dev, ndc):
     assert float(((got - ref).abs() / scale).max()) <= 2e-6
 
 
-def test_render_path_overlapped_output(npa, dev, nets, tmp_path):
+@pytest.mark.parametrize("datapath", BOUNDARY_DATAPATHS, indirect=True)
+def test_render_path_overlapped_output(npa, dev, nets, tmp_path, datapath):
     """render_path (run_nerf.py:137-175): frames rendered from poses, device-side to8b, asynchronous copies and PNG
     encoding on worker threads -- arrays and files equal to the synchronous formulation."""
     nc, nf, Pc, Pf = nets
@@ -1342,7 +1367,8 @@ def test_render_path_overlapped_output(npa, dev, nets, tmp_path):
         assert np.array_equal(rows[:, 1:].reshape(H, W, 3), npa.to8b(rgbs[i]))
 
 
-def test_training_step_moves_parameters_like_the_oracle(npa, dev):
+@pytest.mark.parametrize("datapath", BOUNDARY_DATAPATHS, indirect=True)
+def test_training_step_moves_parameters_like_the_oracle(npa, dev, datapath):
     """Two Adam steps through the drop-in surface == two Adam steps of the oracle."""
     Pc, Pf = orc.scene_params(seed=1)
     kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
@@ -1365,5 +1391,54 @@ def test_training_step_moves_parameters_like_the_oracle(npa, dev):
         lo = orc.mse(ref["rgb_map"], target) + orc.mse(ref["rgb0"], target)
         lo.backward()
         opt_o.step()
-        assert abs(loss.item() - lo.item()) <= 2e-4, (step, loss.item(), lo.item())
+        assert abs(loss.item() - lo.item()) <= BOUNDARY_TOL[datapath]["loss"], (step, loss.item(), lo.item())
     assert nc._is_bound() and nf._is_bound()
+
+
+# ---------------------------------------------------------------- network_query_fn as a live hook (run_nerf.py:385, :401)
+@pytest.mark.gpu
+@pytest.mark.parametrize("datapath", BOUNDARY_DATAPATHS, indirect=True)
+def test_user_network_query_fn_is_called_for_every_pass(npa, dev, nets, datapath):
+    """A user's own network_query_fn in render_kwargs is CALLED (with the reference's arguments) for the coarse and the fine pass and
+    what it returns is what gets composited; None / the function create_nerf builds select the fused kernels.  The stock body behind
+    a user's wrapper reproduces the fused path (same kernels per stage, same arithmetic), values and gradients."""
+    nc, nf, Pc, Pf = nets
+    n = 48
+    rays = orc.synthetic_rays(n, seed=12).to(dev)
+    target = torch.rand(n, 3, device=dev)
+    rnd = {k: v.to(dev) for k, v in orc.synthetic_randoms(n, 64, 128, seed=5).items()}
+    kw = dict(N_samples=64, N_importance=128, network_fine=nf, white_bkgd=True, perturb=1.0, raw_noise_std=1.0, retraw=True, randoms=rnd)
+    calls = []
+
+    def hook(pts, viewdirs, net):
+        calls.append((tuple(pts.shape), tuple(viewdirs.shape), net))
+        return npa.run_network(pts, viewdirs, net, None, None)
+
+    def grads(query_fn):
+        for m in (nc, nf):
+            m.zero_grad()
+        out = npa.render_rays(rays, nc, query_fn, **kw)
+        (npa.img2mse(out["rgb_map"], target) + npa.img2mse(out["rgb0"], target)).backward()
+        return out, [p.grad.clone() for m in (nc, nf) for p in m.parameters()]
+    fused, g_fused = grads(None)
+    assert calls == []
+    hooked, g_hook = grads(hook)
+    assert calls == [((n, 64, 3), (n, 3), nc), ((n, 192, 3), (n, 3), nf)]
+    assert set(hooked) == set(fused)
+    for k in fused:        # the points o + d z are formed by torch here and inside the kernel there: the same fp32 operations
+        assert maxdiff(hooked[k], fused[k]) <= 1e-6 * max(1.0, float(fused[k].abs().nan_to_num().max())), k
+    for a, b in zip(g_hook, g_fused):
+        assert maxdiff(a, b) <= 1e-4 * float(b.abs().max()) + 1e-12
+    # ... and it is live: a hook that changes raw changes the image (here: a density floor on raw[..., 3])
+    denser = npa.render_rays(rays, nc, lambda p, v, m: torch.cat([hook(p, v, m)[..., :3], hook(p, v, m)[..., 3:] + 5.0], -1), **kw)
+    assert float((denser["acc_map"] - fused["acc_map"]).abs().max()) > 1e-3
+    # create_nerf's own function is recognised as the stock one
+    import types
+    args = npa.config_parser().parse_args([])
+    tr = npa.create_nerf(types.SimpleNamespace(**dict(vars(args), basedir=None, expname=None)), device=dev)[0]
+    calls.clear()
+    with torch.no_grad():
+        stock = npa.render_rays(rays, tr["network_fn"], tr["network_query_fn"], N_samples=64, N_importance=128, network_fine=tr["network_fine"])
+    assert calls == [] and stock["rgb_map"].shape == (n, 3)
+    for m in (nc, nf):
+        m.zero_grad()

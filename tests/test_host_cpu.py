@@ -508,3 +508,55 @@ def test_no_heavy_kernel_spills():
                 assert v["occupancy_waves_per_simd"] >= 2, (k, v)
     spilling = sorted(k for k, v in table.items() if v.get("scratch_bytes_per_lane", 0))
     assert not spilling, spilling
+
+
+def test_pytest_det_samples_are_the_references_numpy_linspace(monkeypatch):
+    """render_rays(pytest=True, perturb=0): the reference builds the deterministic CDF samples with np.linspace in float64 and casts
+    them (run_nerf_helpers.py:213-215).  That is NOT torch.linspace's fp32 sequence (round 5 assumed it was): they differ by one ulp
+    in some entries for most sample counts -- so the pytest + det branch hands the kernel the reference's numbers explicitly, and the
+    plain det branch (pytest=False: helpers:205 is torch.linspace in the reference too) keeps torch.linspace."""
+    differing = {}
+    for n in (2, 3, 64, 128):
+        ours = torch.linspace(0.0, 1.0, steps=n, dtype=torch.float32)
+        theirs = torch.Tensor(np.linspace(0.0, 1.0, n))            # float64 -> float32, as torch.Tensor(ndarray) does in the reference
+        differing[n] = int((ours != theirs).sum())
+        assert float((ours - theirs).abs().max()) <= 2.0 ** -24
+        assert torch.equal(ours, torch.linspace(0., 1., steps=n))   # t_vals / det u of the reference (run_nerf.py:357, helpers:205)
+    assert differing[2] == 0 and differing[3] == 0 and differing[64] > 0 and differing[128] > 0, differing
+    import sys
+    render = sys.modules["nerf_pytorch_amd.render"]
+    seen = {}
+
+    class _Stop(Exception):
+        pass
+
+    def spy(cfg, rays, rnd, *rest):
+        seen.update(rnd)
+        raise _Stop()
+    monkeypatch.setattr(render._RenderRays, "apply", staticmethod(spy))
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    net = npa.NeRF(**kw)
+    for pytest_flag, expect_u in ((True, True), (False, False)):
+        seen.clear()
+        with pytest.raises(_Stop):
+            render.render_rays(torch.zeros(5, 11), net, None, 64, N_importance=128, perturb=0., pytest=pytest_flag)
+        assert ("u" in seen) == expect_u
+        if expect_u:
+            assert torch.equal(seen["u"], torch.Tensor(np.linspace(0., 1., 128)).expand(5, 128))
+
+
+def test_network_query_fn_selects_the_fused_or_the_hooked_path(monkeypatch):
+    """None and create_nerf's own function are the stock query (fused kernels); any other callable is a user hook that render_rays
+    calls per pass (run_nerf.py:385, :401) -- never silently ignored."""
+    import sys
+    render = sys.modules["nerf_pytorch_amd.render"]
+    a = npa.config_parser().parse_args(["--use_viewdirs", "--N_importance", "128"])
+    a.basedir = a.expname = None
+    tr = npa.create_nerf(a, device=torch.device("cpu"))[0]
+    assert render._is_builtin_query(None) and render._is_builtin_query(tr["network_query_fn"])
+    mine = lambda pts, viewdirs, net: None
+    assert not render._is_builtin_query(mine)
+    went = []
+    monkeypatch.setattr(render, "_render_rays_hooked", lambda *a_, **k_: went.append(a_[3]) or {"rgb_map": None})
+    rays = torch.zeros(4, 11)
+    assert render.render_rays(rays, tr["network_fn"], mine, 8) == {"rgb_map": None} and went == [mine]
