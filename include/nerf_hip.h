@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 9
+#define NERF_ABI_VERSION 10
 #define NERF_E_BADARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define NERF_E_UNSUPPORTED (-2) /* configuration outside the fixed architecture */
 
@@ -101,8 +101,8 @@ size_t nerf_act_floats(int n_rays, int n_samples);
  * = nerf_act_floats(coarse) + nerf_act_floats(fine) + nerf_delta_floats(larger) + nerf_wgrad_partial_floats(larger). */
 size_t nerf_workspace_floats(int n_rays, int n_coarse, int n_fine, int training);
 /* The same three sizes for ONE datapath (ABI v9).  datapath: 0 = exact fp32 (fp32 rows, 10.6 KB / point each way), 1 = the split
- * datapaths (16-bit tiles of either type, 4.8 / 4.4 KB / point); the two-argument forms above return the larger of the two, i.e. a
- * buffer any datapath may write.  A caller that knows its datapath keeps ~2.2x more rays resident per GB of HBM with these:
+ * datapaths (16-bit tiles of either type, 4.8 / 4.4 KB / point), 2 (ABI v10) = the fp16 split with TWO-WORD saves (hi and lo words:
+ * twice datapath 1); the two-argument forms above return the larger of datapaths 0 and 1, i.e. a buffer either of those may write.  A caller that knows its datapath keeps ~2.2x more rays resident per GB of HBM with these:
  * the 32,768-ray batch of BASELINE configs[3] holds ~40 GB of saved activations on the split datapaths instead of ~90 GB. */
 size_t nerf_act_floats_dp(int n_rays, int n_samples, int datapath);
 size_t nerf_delta_floats_dp(int n_rays, int n_samples, int datapath);
@@ -174,6 +174,12 @@ int nerf_field_wgrad(const float* act, const float* delta, const float* d_raw, i
  * = 1) first reduces max|d_raw| on the device and runs the chain on s * d_raw with s the power of two that puts that maximum in
  * [16, 32) (the chain is linear; the maximum lives in the delta buffer), every stored delta and partial weight gradient carries s, and
  * the reduction phase of nerf_field_wgrad_phase multiplies by 1/s -- exact.  A non-finite d_raw propagates to the gradient.
+ *   split = 5 (ABI v10, "fp16x3w"; nerf_field_fwd_split with act, nerf_field_dgrad_split): the fp16 split with TWO-WORD saves -- the
+ * forward and the delta chain store the lo words (T(v - hi)) next to the hi words (mirror regions at ActLayout3::lo /
+ * DeltaLayout3::lo; buffers of nerf_act_floats_dp / nerf_delta_floats_dp(datapath = 2) floats), and the weight-gradient GEMM
+ * (nerf_field_wgrad_phase datapath 6) contracts  d_hi^T X_hi + d_hi^T X_lo + d_lo^T X_hi : the products of the forward's class
+ * (~2^-22) instead of 11-bit operands, at twice the saved bytes and three times the GEMM's MFMAs.  Same packed3 as split = 1.  Not
+ * the default: it prices and bounds what the one-word operand storage costs the gradients.
  * Replace run_nerf.py:37-51 + run_nerf_helpers.py:15-45, :96-119 and their autograd like nerf_field_fwd / nerf_field_bwd. */
 int nerf_packed3_floats(void);
 int nerf_pack_params_split(const float* params, float* packed3, int streams, int split, void* stream);
@@ -215,11 +221,12 @@ int nerf_field_fwd_last_sample(const float* packed3, const float* rays, int ray_
  *   - nerf_field_wgrad_phase(datapath = -1) takes the datapath from the record.
  * Buffers the library has not written (copies, foreign producers) are not checked.
  * nerf_buffer_layout: the recorded kind, or -1 for an unknown buffer.  act: 0 fp32 point-major rows (nerf_field_fwd), 4 / 5 = rows
- * in 16-point tiles of bf16 / fp16 (nerf_field_fwd_split(split = 0 / 1)); delta (*is_delta = 1): 0 fp32 rows, 2 / 3 = 32-point
- * tiles of bf16 / fp16. */
+ * in 16-point tiles of bf16 / fp16 (nerf_field_fwd_split(split = 0 / 1)), 6 = fp16 hi + lo rows (split = 5); delta (*is_delta = 1):
+ * 0 fp32 rows, 2 / 3 = 32-point tiles of bf16 / fp16, 4 = fp16 hi + lo tiles (split = 5). */
 int nerf_buffer_layout(const float* buf, int* is_delta, int* n_rays, int* n_samples);
 /* test hook (host only): where the regions of such a buffer start, in floats from its base, for n_rays x n_samples points.
- * family 0 = fp32 point-major rows, 1 = the split datapaths' tiles of 16-bit elements.  out_host[16]:
+ * family 0 = fp32 point-major rows, 1 = the split datapaths' tiles of 16-bit elements, 2 = the same with two-word saves (the offsets
+ * of family 1 plus [15] = offset of the mirror that holds the lo words; [14] total = twice family 1's).  out_host[16]:
  *   save buffer  (is_delta = 0): [0..7] post-ReLU rows of trunk layers 0..7, [8] feature (fp32 rows only; the split datapaths fold
  *                that layer and use the slot as the dump tile of out-of-range waves), [9] view branch, [10] xyz encoding,
  *                [11] direction encoding per ray, [12] its per-point / per-ray-record expansion, [13] ReLU bitmasks, [14] total;
@@ -233,7 +240,8 @@ int nerf_debug_layout(int n_rays, int n_samples, int family, int is_delta, long 
  * Calling it with phases 1, 2, 4 in that order equals one call with 7. */
 int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_raw, int n_rays, int n_samples,
                            float* partial, float* grad, int accumulate,
-                           int datapath /* -1 as recorded for act / delta (above); 0 fp32; 4 bf16 operands; 5 fp16 operands */,
+                           int datapath /* -1 as recorded for act / delta (above); 0 fp32; 4 bf16 operands; 5 fp16 operands;
+                                           6 fp16 two-word operands (split = 5 buffers) */,
                            int phases, const float* params /* canonical parameters; may be NULL for datapath 0 */,
                            void* stream);
 /* ---- render_rays in one call (run_nerf.py:308-418 and its autograd): the whole of a ray batch's forward, and the whole of
@@ -245,7 +253,8 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
  * (depths, coarse raw, compositing weights; when training also the saved activations, deltas and partial gradients: ~9.2 KB
  * per sample point on the split datapaths, ~21 KB on fp32 -- split larger ray batches, the reference's `chunk` argument does exactly that).
  *   precision 0: exact fp32 datapath; 1: split-bf16; 3: split-fp16 (packed buffers from nerf_pack_params_split with the
- *   matching split; 16-bit operand storage of the weight-gradient GEMM either way).
+ *   matching split; 16-bit operand storage of the weight-gradient GEMM either way); 5: split-fp16 with two-word saves and the
+ *   three-term weight-gradient GEMM (packed buffers of split 1; workspace of nerf_render_workspace_floats for THIS cfg).
  *   Backward with accumulate = 0: every gradient vector handed in is written -- a network whose pass received no upstream
  *   gradient gets zeros; d_disp / d_acc may be given without d_rgb.
  *   packed_f / params_f / grad_f NULL (or packed_f == packed_c): the fine pass uses the coarse network (network_fine None).
@@ -257,7 +266,7 @@ typedef struct NerfRenderCfg {
     int n_coarse, n_fine;          /* N_samples, N_importance */
     int lindisp, white_bkgd;
     float raw_noise_std;
-    int precision;                 /* 0 fp32, 1 split-bf16, 3 split-fp16 */
+    int precision;                 /* 0 fp32, 1 split-bf16, 3 split-fp16, 5 split-fp16 with two-word saves */
     int reserved;                  /* (round 3: operand storage switch; ignored) */
 } NerfRenderCfg;
 size_t nerf_render_workspace_floats(const NerfRenderCfg* cfg, int n_rays, int training);

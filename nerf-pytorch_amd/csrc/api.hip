@@ -42,15 +42,19 @@ int datapath_of(int act_kind, int delta_kind) {
     if (act_kind == ACT_ROWS_F32 && delta_kind == DELTA_ROWS_F32) return 0;
     if (act_kind == ACT_TILE16_BF16 && delta_kind == DELTA_TILE32_BF16) return 4;
     if (act_kind == ACT_TILE16_F16 && delta_kind == DELTA_TILE32_F16) return 5;
+    if (act_kind == ACT_TILE16_F16X2 && delta_kind == DELTA_TILE32_F16X2) return 6;
     return -1;
 }
 
 // the save buffer a dgrad is about to read: written by a forward of the same family (fp32 rows vs split-bf16 tiles: the
 // ReLU bitmasks differ) for the same point count?  0 = fine / unknown buffer
-static int check_act_for_dgrad(const char* fn, const void* act, bool split_bf16, int n_rays, int n_samples) {
+static int check_act_for_dgrad(const char* fn, const void* act, bool split_bf16, int n_rays, int n_samples, int two_word = -1) {
     BufTag t;
     if (!tag_lookup(act, &t)) return 0;
     if (t.is_delta) return fail_arg(fn, "`act` is a buffer this library last wrote DELTAS into");
+    if (two_word >= 0 && (t.kind == ACT_TILE16_F16X2) != (two_word == 1))
+        return fail_arg(fn, "`act` and this dgrad disagree about two-word saves (split = 5 on both the forward and the dgrad, or on neither): "
+                            "the three-term weight-gradient GEMM contracts the lo deltas with the lo rows only a split = 5 forward saved");
     if ((t.kind != ACT_ROWS_F32) != split_bf16)
         return fail_arg(fn, split_bf16 ? "`act` was saved by the exact-fp32 forward (point-major rows, fp32 bitmask order): not readable by a split datapath's dgrad"
                                        : "`act` was saved by a split datapath's forward (tiles, its bitmask order): not readable by the fp32 dgrad");
@@ -150,14 +154,14 @@ int nerf_sample_coarse(const float* rays, int ray_stride, int n_rays, const floa
 }
 
 size_t nerf_act_floats_dp(int n_rays, int n_samples, int datapath) {
-    if (n_rays <= 0 || n_samples <= 0 || datapath < 0 || datapath > 1) return 0;
+    if (n_rays <= 0 || n_samples <= 0 || datapath < 0 || datapath > 2) return 0;
     const size_t P = (size_t)n_rays * n_samples;
-    return datapath == 0 ? nerf::act_layout(P, (size_t)n_rays).total : nerf::act_layout3(P, (size_t)n_rays).total;
+    return datapath == 0 ? nerf::act_layout(P, (size_t)n_rays).total : nerf::act_layout3(P, (size_t)n_rays, datapath == 2).total;
 }
 size_t nerf_delta_floats_dp(int n_rays, int n_samples, int datapath) {
-    if (n_rays <= 0 || n_samples <= 0 || datapath < 0 || datapath > 1) return 0;
+    if (n_rays <= 0 || n_samples <= 0 || datapath < 0 || datapath > 2) return 0;
     const size_t P = (size_t)n_rays * n_samples;
-    return datapath == 0 ? nerf::delta_layout(P).total : nerf::delta_layout3(P).total;
+    return datapath == 0 ? nerf::delta_layout(P).total : nerf::delta_layout3(P, datapath == 2).total;
 }
 size_t nerf_act_floats(int n_rays, int n_samples) {       // a buffer either datapath may write
     const size_t a = nerf_act_floats_dp(n_rays, n_samples, 0), b = nerf_act_floats_dp(n_rays, n_samples, 1);
@@ -179,7 +183,7 @@ size_t nerf_workspace_floats(int n_rays, int n_coarse, int n_fine, int training)
            nerf_delta_floats(n_rays, s_big) + nerf_wgrad_partial_floats(n_rays, s_big);
 }
 size_t nerf_workspace_floats_dp(int n_rays, int n_coarse, int n_fine, int training, int datapath) {
-    if (!training || n_rays <= 0 || n_coarse <= 0 || n_fine < 0 || datapath < 0 || datapath > 1) return 0;
+    if (!training || n_rays <= 0 || n_coarse <= 0 || n_fine < 0 || datapath < 0 || datapath > 2) return 0;
     const int s_big = n_coarse + n_fine;
     return nerf_act_floats_dp(n_rays, n_coarse, datapath) + (n_fine > 0 ? nerf_act_floats_dp(n_rays, s_big, datapath) : 0) +
            nerf_delta_floats_dp(n_rays, s_big, datapath) + nerf_wgrad_partial_floats(n_rays, s_big);
@@ -187,7 +191,7 @@ size_t nerf_workspace_floats_dp(int n_rays, int n_coarse, int n_fine, int traini
 
 int nerf_debug_layout(int n_rays, int n_samples, int family, int is_delta, long long* out_host) {
     REQUIRE(out_host, "null pointer");
-    REQUIRE(n_rays > 0 && n_samples > 0 && (family == 0 || family == 1), "bad size / family (0 fp32 rows, 1 split tiles)");
+    REQUIRE(n_rays > 0 && n_samples > 0 && family >= 0 && family <= 2, "bad size / family (0 fp32 rows, 1 split tiles, 2 split tiles with two-word saves)");
     const size_t P = (size_t)n_rays * n_samples;
     for (int i = 0; i < 16; ++i) out_host[i] = -1;
     auto put = [&](int i, size_t v) { out_host[i] = (long long)v; };
@@ -196,17 +200,19 @@ int nerf_debug_layout(int n_rays, int n_samples, int family, int is_delta, long 
         for (int l = 0; l < nerf::D; ++l) put(l, a.h[l]);
         put(8, a.feat); put(9, a.hv); put(10, a.enc); put(11, a.dir); put(12, a.dir_pt); put(13, a.mask); put(14, a.total);
     } else if (!is_delta) {
-        const nerf::ActLayout3 a = nerf::act_layout3(P, (size_t)n_rays);
+        const nerf::ActLayout3 a = nerf::act_layout3(P, (size_t)n_rays, family == 2);
         for (int l = 0; l < nerf::D; ++l) put(l, a.h[l]);
         put(8, a.feat); put(9, a.hv); put(10, a.enc); put(11, a.dir); put(12, a.dir_pt); put(13, a.mask); put(14, a.total);
+        if (family == 2) put(15, a.lo);
     } else if (family == 0) {
         const nerf::DeltaLayout a = nerf::delta_layout(P);
         for (int l = 0; l < nerf::D; ++l) put(l, a.h[l]);
         put(8, a.feat); put(9, a.hv); put(14, a.total);
     } else {
-        const nerf::DeltaLayout3 a = nerf::delta_layout3(P);
+        const nerf::DeltaLayout3 a = nerf::delta_layout3(P, family == 2);
         for (int l = 0; l < nerf::D; ++l) put(l, a.h[l]);
         put(8, a.feat); put(9, a.hv); put(10, a.graw); put(11, a.scale); put(14, a.total);
+        if (family == 2) put(15, a.lo);
     }
     return 0;
 }
@@ -335,7 +341,7 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
                            float* partial, float* grad, int accumulate, int datapath, int phases, const float* params,
                            void* stream) {
     REQUIRE(act && delta && d_raw && partial && grad, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && (datapath == -1 || datapath == 0 || datapath == 4 || datapath == 5), "bad size / datapath (-1, 0, 4, 5)");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && phases >= 1 && phases <= 7 && (datapath == -1 || datapath == 0 || (datapath >= 4 && datapath <= 6)), "bad size / datapath (-1, 0, 4, 5, 6)");
     int rc;
     const int recorded = datapath_from_tags(__func__, act, delta, n_rays, n_samples, &rc);
     if (rc) return rc;
@@ -355,12 +361,12 @@ int nerf_field_wgrad_phase(const float* act, const float* delta, const float* d_
 int nerf_field_dgrad_split(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
                            float* delta, int split, void* stream) {
     REQUIRE(packed3 && act && d_raw && delta, "null pointer");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && (split == 0 || split == 1), "bad size");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && (split == 0 || split == 1 || split == 5), "bad size / split (0 bf16, 1 fp16, 5 fp16 with two-word saves)");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(act) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0,
             "packed/act/d_raw/delta must be 16-byte aligned");
-    if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples)) return rc;
-    tag_record(delta, 1, split ? DELTA_TILE32_F16 : DELTA_TILE32_BF16, n_rays, n_samples);
+    if (int rc = check_act_for_dgrad(__func__, act, true, n_rays, n_samples, split == 5 ? 1 : 0)) return rc;
+    tag_record(delta, 1, split == 5 ? DELTA_TILE32_F16X2 : split ? DELTA_TILE32_F16 : DELTA_TILE32_BF16, n_rays, n_samples);
     return done(__func__, nerf::launch_field_dgrad3r(packed3, act, d_raw, n_rays, n_samples, delta, split, (hipStream_t)stream));
 }
 
@@ -383,13 +389,13 @@ int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride
                          int n_samples, float* raw, float* act, int split, void* stream) {
     REQUIRE(packed3 && rays && z_vals && raw, "null pointer");
     REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
-    REQUIRE(n_rays >= 0 && n_samples >= 1 && split >= 0 && split <= 3, "bad size");
-    REQUIRE(split < 2 || !act, "split = 2 / 3 (fp16 main term + fp8 corrections) is an inference form: act must be NULL");
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && ((split >= 0 && split <= 3) || split == 5), "bad size / split (0, 1, 2, 3, 5)");
+    REQUIRE(split < 2 || split == 5 || !act, "split = 2 / 3 (fp16 main term + fp8 corrections) is an inference form: act must be NULL");
     REQUIRE((long)n_rays * n_samples <= nerf::FWD16R_MAX_POINTS && (!act || (long)n_rays * n_samples <= nerf::FWD16R_MAX_SAVED_POINTS),
             "too many points for one launch (2^31 - 1; 2^26 when saving): split the ray batch");
     REQUIRE((reinterpret_cast<uintptr_t>(packed3) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(act) & 15) == 0, "packed/raw/act must be 16-byte aligned");
-    if (act) tag_record(act, 0, split ? ACT_TILE16_F16 : ACT_TILE16_BF16, n_rays, n_samples);
+    if (act) tag_record(act, 0, split == 5 ? ACT_TILE16_F16X2 : split ? ACT_TILE16_F16 : ACT_TILE16_BF16, n_rays, n_samples);
     return done(__func__, nerf::launch_field_fwd16r(packed3, rays, ray_stride, z_vals, n_rays, n_samples, raw, act, split,
                                                     (hipStream_t)stream));
 }

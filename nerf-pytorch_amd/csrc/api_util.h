@@ -25,8 +25,9 @@ inline int done(const char* fn, hipError_t e) {
 // a small table, nothing on the device, no pointer is ever dereferenced) so that a mismatched pairing is refused with
 // NERF_E_BADARG instead of computing garbage, and so that nerf_field_wgrad_phase(datapath = -1) can pick the datapath
 // itself.  Buffers the library has not seen (copied, produced elsewhere) are not checked.
-enum ActLayoutKind { ACT_ROWS_F32 = 0, ACT_TILE32_F32 = 1, ACT_TILE32_BF16 = 2, ACT_TILE16_F32 = 3, ACT_TILE16_BF16 = 4, ACT_TILE16_F16 = 5 };
-enum DeltaKind { DELTA_ROWS_F32 = 0, DELTA_TILE32_F32 = 1, DELTA_TILE32_BF16 = 2, DELTA_TILE32_F16 = 3 };
+enum ActLayoutKind { ACT_ROWS_F32 = 0, ACT_TILE32_F32 = 1, ACT_TILE32_BF16 = 2, ACT_TILE16_F32 = 3, ACT_TILE16_BF16 = 4, ACT_TILE16_F16 = 5,
+                     ACT_TILE16_F16X2 = 6 /* hi + lo words (two-word saves) */ };
+enum DeltaKind { DELTA_ROWS_F32 = 0, DELTA_TILE32_F32 = 1, DELTA_TILE32_BF16 = 2, DELTA_TILE32_F16 = 3, DELTA_TILE32_F16X2 = 4 };
 struct BufTag { int is_delta, kind, n_rays, n_samples; unsigned long seq; };
 
 void tag_record(const void* buf, int is_delta, int kind, int n_rays, int n_samples);

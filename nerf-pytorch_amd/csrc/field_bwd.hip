@@ -188,6 +188,9 @@ struct WgradArgs {
     long P;
     int chunk_pts, n_chunks;
     float* partial;                 // [n_chunks][N_PARAMS]
+    // wgrad1_kernel<SP, 3> (two-word operands, round 6): bytes from any A / B operand pointer to the LO words of the same operand
+    // (the mirrors of the delta / save layouts: DeltaLayout3::lo, ActLayout3::lo)
+    long a_lo_bytes, b_lo_bytes;
 };
 
 __device__ inline f32x4 load_row4(const float* base, int ld, long row, bool row_ok, int col, int ncols, int vec) {
@@ -455,7 +458,12 @@ __device__ inline void dma_1k_s(const void* sbase, unsigned voff, unsigned lds_d
 }
 // SP: element type of the stored operands (split_types.h: bf16, or fp16 = the hi words of the fp16 split -- then every delta
 // carries the launch's power-of-two scale, which wgrad_reduce_kernel removes)
-template <typename SP>
+// TERMS = 1: the operands are the stored hi words (11 / 8 significant bits).  TERMS = 3 (round 6, "fp16x3w"): TWO-WORD operands --
+// dW = d_hi^T X_hi + d_hi^T X_lo + d_lo^T X_hi, the same three-term product as the forward's, as a contraction over 3 x the points:
+// the stage sequence of a chunk is (tile 0: hi.hi, hi.lo, lo.hi), (tile 1: ...), ...; only the DMA source of a stage changes (the lo
+// words live at a_lo_bytes / b_lo_bytes from the hi words), the ring, the fragment reads and the MFMAs are the one-word kernel's.
+// An operand's hi tile is fetched for two consecutive (A) / alternate (B) stages: the second fetch comes out of L2.
+template <typename SP, int TERMS = 1>
 __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm1[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -466,7 +474,8 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     const long p_begin = (long)chunk * a.chunk_pts;              // multiple of 32: chunks start on a tile
     const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
     const int nrows = (int)(p_end - p_begin);
-    const int n_st = (nrows + WG1_STAGE_PTS - 1) / WG1_STAGE_PTS;
+    const int n_tiles = (nrows + WG1_STAGE_PTS - 1) / WG1_STAGE_PTS;
+    const int n_st = n_tiles * TERMS;                            // stages: TERMS per 32-point tile
 
     // DMA role: waves 0-3 copy delta (A), waves 4-7 the input (B); instruction u of a wave copies LDS pieces
     // [64*m, 64*m + 64) of its operand, m = 4*(wave&3) + u; LDS piece 4*f + jj holds points 8*(jj ^ swz(f))..+7 of
@@ -501,11 +510,15 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     const char* rbase = reinterpret_cast<const char*>(jb.B);
     const long tile0 = p_begin >> 5;
     const unsigned lds0 = lds_addr(sm1) + (unsigned)(sop * WG1_OP_BYTES + (wave & 3) * 4096);
+    const long lo_bytes = TERMS == 3 ? (sop == 0 ? a.a_lo_bytes : a.b_lo_bytes) : 0;     // this wave's operand: hi -> lo words
     auto issue = [&](int st) {
-        const char* src = ray_tiles > 0 ? rbase + (size_t)((tile0 + st) / ray_tiles) * (size_t)(16 * sld) : cbase + (size_t)st * tile_bytes;
+        const int tl = TERMS == 3 ? st / 3 : st;                                 // 32-point tile of this stage
+        const int term = TERMS == 3 ? st - 3 * tl : 0;                          // 0: hi.hi, 1: d_hi.X_lo, 2: d_lo.X_hi
+        const long part = (TERMS == 3 && term == (sop == 0 ? 2 : 1)) ? lo_bytes : 0;
+        const char* src = (ray_tiles > 0 ? rbase + (size_t)((tile0 + tl) / ray_tiles) * (size_t)(16 * sld) : cbase + (size_t)tl * tile_bytes) + part;
         const unsigned dst = lds0 + (unsigned)(st % WG1_STAGES) * WG1_STAGE_BYTES;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dma_1k_s(src, doff[u] + (unsigned)st * dstep[u], dst + 1024u * u);
+        for (int u = 0; u < 4; ++u) dma_1k_s(src, doff[u] + (unsigned)tl * dstep[u], dst + 1024u * u);
     };
 
     f32x16 acc[4][2];
@@ -539,7 +552,8 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
         const unsigned char* stage = sm1 + (st % WG1_STAGES) * WG1_STAGE_BYTES;
         const unsigned char* sa = stage + (wave_n * 128) * 64;
         const unsigned char* sb = stage + WG1_OP_BYTES + (wave_k * 64) * 64;
-        const int left = nrows - st * WG1_STAGE_PTS;
+        const int left = nrows - (st / TERMS) * WG1_STAGE_PTS;
+        const bool bias_stage = want_bias && (TERMS == 1 || st % TERMS != 1);     // db = sum (d_hi + d_lo): the hi words count once
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             u32x4 bf[2];
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
             for (int i = 0; i < 4; ++i) {
                 if (i >= ni) break;
                 const u32x4 af = fragment(sa + i * 32 * 64, t, left);
-                if (want_bias) rowsum[i] += SP::sum8(af);
+                if (bias_stage) rowsum[i] += SP::sum8(af);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(af, bf[j], acc[i][j]);
             }
@@ -564,6 +578,9 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
         const unsigned char* stage = sm1 + (st % WG1_STAGES) * WG1_STAGE_BYTES;
         const unsigned char* sa = stage + (wave_n * 128) * 64;
         const unsigned char* sb = stage + WG1_OP_BYTES + (wave_k * 64) * 64;
+        // two-word operands: the delta hi words of a tile pass twice (stages 3 t and 3 t + 1); db = sum (d_hi + d_lo) counts them once
+        // (a multiplication by exactly 1 or 0 instead of a branch between the MFMAs)
+        const float bias_w = (TERMS == 3 && st % 3 == 1) ? 0.0f : 1.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {           // six reads, then eight MFMAs, per k-step (all twelve reads up front spill)
             u32x4 bf[2], af[4];
@@ -573,14 +590,14 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(sa + i * 32 * 64 + frag[t]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (decltype(with_bias)::value) rowsum[i] += SP::sum8(af[i]);
+                if (decltype(with_bias)::value) rowsum[i] += TERMS == 3 ? bias_w * SP::sum8(af[i]) : SP::sum8(af[i]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(af[i], bf[j], acc[i][j]);
             }
         }
     };
     const bool full_tile = wave_has_work && ni == 4 && nj == 2;                 // wave-uniform
-    const int n_full = (nrows % WG1_STAGE_PTS == 0) ? n_st : n_st - 1;          // stages whose 32 points all exist
+    const int n_full = ((nrows % WG1_STAGE_PTS == 0) ? n_tiles : n_tiles - 1) * TERMS;     // stages whose 32 points all exist
 
     // ring: stages st+1 .. st+3 are in flight while st is consumed.  vmcnt retires in order: "at most 4 * (younger
     // stages in flight) outstanding" = this wave's pieces of st have landed
@@ -756,7 +773,14 @@ template <typename SP>
 __device__ inline u32x4 pack8_sp(const float* v) {
     return u32x4{SP::cvt_pk(v[0], v[1]), SP::cvt_pk(v[2], v[3]), SP::cvt_pk(v[4], v[5]), SP::cvt_pk(v[6], v[7])};
 }
+// LO: the remainders T(v - hi) instead of the hi words (two-word operands)
 template <typename SP>
+__device__ inline float split_rem(float x) {
+    const unsigned short h = SP::cvt1(x);
+    if constexpr (SP::F16) return x - (float)__builtin_bit_cast(_Float16, h);
+    else return x - __uint_as_float((unsigned)h << 16);
+}
+template <typename SP, bool LO = false>
 __global__ void expand_dir_tiles_bf16_kernel(const float* __restrict__ dir_ray, u32x4* __restrict__ dir_pt, long P, int S) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n_tiles = (P + 31) >> 5;
@@ -768,6 +792,7 @@ __global__ void expand_dir_tiles_bf16_kernel(const float* __restrict__ dir_ray, 
     for (int e = 0; e < 8; ++e) {
         const long p = min(tile * 32 + 8 * g + e, P - 1);
         v[e] = dir_ray[(p / S) * 32 + f];
+        if (LO) v[e] = split_rem<SP>(v[e]);
     }
     dir_pt[i] = pack8_sp<SP>(v);
 }
@@ -775,13 +800,13 @@ __global__ void expand_dir_tiles_bf16_kernel(const float* __restrict__ dir_ray, 
 // ... or, when a ray's samples fill whole 32-point tiles, ONCE per ray: [ray][feature][8 copies] bf16 -- 16 bytes per (ray,
 // feature), which is the fragment wgrad1_kernel's DMA fetches for every 8-point group of that ray (2 MB instead of 50 MB for
 // 4096 x 192 points, and no per-point kernel)
-template <typename SP>
+template <typename SP, bool LO = false>
 __global__ void replicate_dir_bf16_kernel(const float* __restrict__ dir_ray, u32x4* __restrict__ dir_rep, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // (ray, feature)
     if (i >= n) return;
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = dir_ray[i];
+    for (int e = 0; e < 8; ++e) v[e] = LO ? split_rem<SP>(dir_ray[i]) : dir_ray[i];
     dir_rep[i] = pack8_sp<SP>(v);
 }
 
@@ -790,9 +815,11 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
                               float* partial, float* grad, int accumulate, int datapath, int phases, hipStream_t stream,
                               const float* params) {
     // datapath: 0 = fp32 (point-major rows); 4 = bf16 operands, rows saved by the 16-point forward (16-point tiles, row16h order),
-    // deltas in 32-point tiles; 5 = the same with fp16 elements (deltas scaled by the launch's power of two, removed in the reduction)
-    if (datapath != 0 && datapath != 4 && datapath != 5) return hipErrorInvalidValue;
-    const bool f16 = datapath == 5;
+    // deltas in 32-point tiles; 5 = the same with fp16 elements (deltas scaled by the launch's power of two, removed in the reduction);
+    // 6 = fp16 TWO-WORD operands (hi and lo words saved by the SAVE = 3 forward and the TWO dgrad: three MFMAs per product)
+    if (datapath != 0 && datapath != 4 && datapath != 5 && datapath != 6) return hipErrorInvalidValue;
+    const bool two = datapath == 6;
+    const bool f16 = datapath == 5 || two;
     const bool split16 = datapath != 0;      // split datapaths: 16-bit operands streamed by wgrad1_kernel,
     const bool fold = split16;               //   feature layer folded into the view branch (nerf_common.h)
     if (fold && !params) return hipErrorInvalidValue;
@@ -805,9 +832,12 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     const float *d_h[D], *d_feat, *d_hv, *d_rgb, *d_sigma, *x_h[D], *x_feat, *x_hv, *x_enc, *x_dir;
     const unsigned* amax = nullptr;
     int ld_graw;
+    long lo_a = 0, lo_b = 0;        // two-word operands: bytes from the hi words of a delta / save region to its lo words
     if (split16) {
-        const ActLayout3 al = act_layout3((size_t)P, (size_t)n_rays);
-        const DeltaLayout3 dl = delta_layout3((size_t)P);
+        const ActLayout3 al = act_layout3((size_t)P, (size_t)n_rays, two);
+        const DeltaLayout3 dl = delta_layout3((size_t)P, two);
+        lo_a = 4 * (long)dl.lo;
+        lo_b = 4 * (long)al.lo;
         if (f16) amax = reinterpret_cast<const unsigned*>(delta + dl.scale);
         for (int l = 0; l < D; ++l) { d_h[l] = delta + dl.h[l]; x_h[l] = act + al.h[l]; }
         d_feat = delta + dl.feat; d_hv = delta + dl.hv; d_rgb = delta + dl.graw;
@@ -821,12 +851,16 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
                 u32x4* dst = reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt);
                 if (f16) hipLaunchKernelGGL(replicate_dir_bf16_kernel<SplitF16>, grid, dim3(256), 0, stream, act + al.dir, dst, (long)n_rays * 32);
                 else hipLaunchKernelGGL(replicate_dir_bf16_kernel<SplitBF16>, grid, dim3(256), 0, stream, act + al.dir, dst, (long)n_rays * 32);
+                if (two) hipLaunchKernelGGL((replicate_dir_bf16_kernel<SplitF16, true>), grid, dim3(256), 0, stream, act + al.dir,
+                                            reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.lo + al.dir_pt), (long)n_rays * 32);
             } else {
                 const long n_thr = ((P + 31) >> 5) * 128;
                 const dim3 grid((unsigned)((n_thr + 255) / 256));
                 u32x4* dst = reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.dir_pt);
                 if (f16) hipLaunchKernelGGL(expand_dir_tiles_bf16_kernel<SplitF16>, grid, dim3(256), 0, stream, act + al.dir, dst, P, S);
                 else hipLaunchKernelGGL(expand_dir_tiles_bf16_kernel<SplitBF16>, grid, dim3(256), 0, stream, act + al.dir, dst, P, S);
+                if (two) hipLaunchKernelGGL((expand_dir_tiles_bf16_kernel<SplitF16, true>), grid, dim3(256), 0, stream, act + al.dir,
+                                            reinterpret_cast<u32x4*>(const_cast<float*>(act) + al.lo + al.dir_pt), P, S);
             }
             e = hipGetLastError();
             if (e != hipSuccess) return e;
@@ -874,7 +908,9 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     if (!fold) add(d_feat, W, W, x_h[D - 1], W, W, 1, cn.wf, W, cn.bf);
     // (the merged job addresses d_sigma through a 32-bit lane offset from d_hv: kept below 2 GiB -- launches beyond ~9 M points keep
     // the alpha head as a job of its own)
-    const bool merge_alpha = split16 && NERF_WG_MERGE_ALPHA &&
+    // ... and the kernel's wrap-around arithmetic (a2_off + tile * (a2_tile_bytes - tile_bytes)) wants the graw region BEHIND hv, as
+    // delta_layout3 lays them out: a reordered layout falls back to 13 jobs instead of reading the wrong rows
+    const bool merge_alpha = split16 && NERF_WG_MERGE_ALPHA && d_sigma > d_hv &&
                              reinterpret_cast<const char*>(d_sigma) - reinterpret_cast<const char*>(d_hv) < (1L << 31);
     if (!merge_alpha) add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);           // alpha_linear (A = d_sigma, one row)
     // fold: G = delta_hv^T h7 lands in the slot of Wv[:, :256]; wgrad_fold_kernel turns it into dWv[:, :256], dWf, dbf
@@ -916,6 +952,8 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     big.chunk_pts = small.chunk_pts = chunk_pts;
     big.n_chunks = small.n_chunks = n_chunks;
     big.partial = small.partial = partial;
+    big.a_lo_bytes = lo_a;
+    big.b_lo_bytes = lo_b;
     small.total_tiles = small_tiles;
     static bool attr_set = false;
     if (!attr_set) {
@@ -929,10 +967,13 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)wgrad1_kernel<SplitF16>, hipFuncAttributeMaxDynamicSharedMemorySize, WG1_LDS_BYTES);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)wgrad1_kernel<SplitF16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, WG1_LDS_BYTES);
+        if (e != hipSuccess) return e;
         attr1_set = true;
     }
     if (big.n_jobs > 0 && split16 && (phases & 1)) {
-        if (f16) hipLaunchKernelGGL(wgrad1_kernel<SplitF16>, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
+        if (two) hipLaunchKernelGGL((wgrad1_kernel<SplitF16, 3>), dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
+        else if (f16) hipLaunchKernelGGL(wgrad1_kernel<SplitF16>, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
         else hipLaunchKernelGGL(wgrad1_kernel<SplitBF16>, dim3((unsigned)(big.n_jobs * n_chunks)), dim3(512), WG1_LDS_BYTES, stream, big);
         e = hipGetLastError();
         if (e != hipSuccess) return e;

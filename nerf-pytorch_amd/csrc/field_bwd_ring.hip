@@ -64,7 +64,9 @@ __global__ __launch_bounds__(1024) void delta_amax_kernel(const f32x4* __restric
     }
 }
 
-template <typename SP>
+// TWO (round 6, "fp16x3w"): every delta leaves as TWO 16-bit words, hi = T(v) and lo = T(v - hi) -- the lo words go to the mirror of
+// the layout at DeltaLayout3::lo (delta_layout3(P, true)); the save buffer it reads was written by the two-word forward (SAVE = 3).
+template <typename SP, bool TWO = false>
 __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldBwdRingArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     ring.start(a.packed3 + P3B_VIEWS, lds, wave, lane, BWD3_UNITS_VIEWS, BWD3_UNITS_SKIP, BWD3_UNITS);
     stage_small_ring(a.packed3 + P3_SMALL, lds, FIELD3_WAVES * 64);
 
-    const ActLayout3 al = act_layout3(P, (size_t)a.n_rays);
-    const DeltaLayout3 dl = delta_layout3(P);
+    const ActLayout3 al = act_layout3(P, (size_t)a.n_rays, TWO);
+    const DeltaLayout3 dl = delta_layout3(P, TWO);
     const size_t tile = (size_t)blockIdx.x * FIELD3_WAVES + wave;          // this wave's tile of every delta region
     f32x4 g = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);             // (d_rgb3, d_sigma)
     if (SP::F16) {      // the whole chain is linear in d_raw: run it on s * d_raw (s = 2^k, exact), see DeltaLayout3::scale
@@ -92,6 +94,10 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
         unsigned short* gt = reinterpret_cast<unsigned short*>(a.delta + dl.graw) + goff;
         nt_store(gt, SP::cvt1(half ? g[2] : g[0]));
         nt_store(gt + 32, SP::cvt1(half ? g[3] : g[1]));
+        if (TWO) {
+            nt_store(gt + 2 * dl.lo, split_lo<SP>(half ? g[2] : g[0]));
+            nt_store(gt + 2 * dl.lo + 32, split_lo<SP>(half ? g[3] : g[1]));
+        }
     }
     u32x4 msk[D + 1];
     {
@@ -132,8 +138,8 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     const int pair_off = ((lane >> 5) * 4 + (int)odd) * 16 + ((lane & 31) >> 1);      // dwords inside the tile
     // one paired 16-bit store: rows (r, r + 1) of 32-feature block ob of a F-wide region (32-point feature-major tiles,
     // nerf_common.h), `own` = the two values of this lane's point
-    auto store_pair16 = [&](size_t region_off, int F, int ob, int r, unsigned own) __attribute__((always_inline)) {
-        unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.delta + (tile_ok ? region_off : dl.feat))
+    auto store_pair16 = [&](size_t region_off, int F, int ob, int r, unsigned own, bool lo_part = false) __attribute__((always_inline)) {
+        unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.delta + (tile_ok ? region_off : dl.feat) + (lo_part ? dl.lo : (size_t)0))
                                                      + (tile_ok ? tile * (size_t)(F * 32) : (size_t)0)) + pair_off;
         paired_store(own, pair_sel, [&](unsigned word) __attribute__((always_inline)) { nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word); });
     };
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     // (NV / NU values as 16-bit pairs)
     size_t store_region = 0;
     // row stores guaranteed behind the last fetch part (two per unit, positions 3..6); none under the store-less timing ablations
-    constexpr int NP = (NERF_ABL_SAVE == 1 || NERF_ABL_SAVE == 3) ? 0 : 8;
+    constexpr int NP = (NERF_ABL_SAVE == 1 || NERF_ABL_SAVE == 3) ? 0 : (TWO ? 16 : 8);
 
     // ---- view branch folded with feature_linear (nerf_common.h): delta of the trunk output =
     //      (alpha_linear^T d_sigma + W'^T d_hv) * relu'(h7); the feature_linear^T units of the stream are skipped
@@ -161,12 +167,13 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     store_region = dl.hv;
     // unit (k-step kk, group gg) writes values 8 kk + 4 gg .. + 3: as bf16 pairs they ARE words 2 gg, 2 gg + 1 of the k-step's
     // hi fragment (value 2 q, 2 q + 1 = rows r = 2 (q % 8), r + 1 of block q / 8)
-    ring_units<SP, 16, 2, 0, true, 0>(ring, fa, fb, fl, acc, dhv, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
+    ring_units<SP, 16, 2, 0, true, 0>(ring, fa, fb, fl, acc, dhv, [&](auto kk, auto gg, const u32x4& bhi, const u32x4& blo) __attribute__((always_inline)) {
         constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;            // unit 0..15: 64 values -> 4 per unit
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int q = 2 * i + t;
             store_pair16(store_region, WV, q / 8, 2 * (q % 8), bhi[2 * decltype(gg)::value + t]);
+            if constexpr (TWO) store_pair16(store_region, WV, q / 8, 2 * (q % 8), blo[2 * decltype(gg)::value + t], true);
         }
     });
     apply_mask3r<128>(d, acc, msk[D - 1]);
@@ -179,12 +186,13 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
         store_region = (size_t)l * region_words3(pad32(P), W);              // dl.h[l]: delta of layer l = input of this step
-        ring_units<SP, 32, 2, 0, false, NP>(ring, fa, fb, fl, acc, d, [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
+        ring_units<SP, 32, 2, 0, false, NP>(ring, fa, fb, fl, acc, d, [&](auto kk, auto gg, const u32x4& bhi, const u32x4& blo) __attribute__((always_inline)) {
             constexpr int i = 2 * decltype(kk)::value + decltype(gg)::value;        // unit 0..31: 128 values -> 4 per unit
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int q = 2 * i + t;
                 store_pair16(store_region, W, q / 8, 2 * (q % 8), bhi[2 * decltype(gg)::value + t]);
+                if constexpr (TWO) store_pair16(store_region, W, q / 8, 2 * (q % 8), blo[2 * decltype(gg)::value + t], true);
             }
         });
         u32x4 m = msk[0];                   // ReLU bitmask of h_{l-1} (static indices only: msk stays in registers)
@@ -194,21 +202,23 @@ __global__ __launch_bounds__(FIELD3_WAVES * 64) void field_dgrad3r_kernel(FieldB
     }
     // dl.h[0]
     store_tile16_pair<SP, 0, 8>(reinterpret_cast<unsigned short*>(a.delta + (tile_ok ? (size_t)0 : dl.feat)) + (tile_ok ? tile * (size_t)(W * 32) : (size_t)0), lane, d);
+    if constexpr (TWO)
+        store_tile16_pair<SP, 0, 8, 128, true>(reinterpret_cast<unsigned short*>(a.delta + dl.lo + (tile_ok ? (size_t)0 : dl.feat)) + (tile_ok ? tile * (size_t)(W * 32) : (size_t)0), lane, d);
 }
 
-template <typename SP>
+template <typename SP, bool TWO = false>
 static hipError_t launch_dgrad_one(const FieldBwdRingArgs& ba, unsigned blocks, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3r_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)field_dgrad3r_kernel<SP, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((field_dgrad3r_kernel<SP>), dim3(blocks), dim3(FIELD3_WAVES * 64), RING_LDS_FLOATS * 4, stream, ba);
+    hipLaunchKernelGGL((field_dgrad3r_kernel<SP, TWO>), dim3(blocks), dim3(FIELD3_WAVES * 64), RING_LDS_FLOATS * 4, stream, ba);
     return hipGetLastError();
 }
 
-// split: 0 bf16, 1 fp16 parts (of the products and of the stored deltas)
+// split: 0 bf16, 1 fp16 parts (of the products and of the stored deltas); 5 = fp16 with two-word deltas (and a two-word save buffer)
 hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const float* d_raw, int n_rays, int S,
                                 float* delta, int split, hipStream_t stream) {
     const long P = (long)n_rays * S;
@@ -216,12 +226,13 @@ hipError_t launch_field_dgrad3r(const float* packed3, const float* act, const fl
     FieldBwdRingArgs ba{packed3, act, d_raw, delta, n_rays, S};
     const unsigned blocks = (unsigned)((P + PTS_PER_WG3 - 1) / PTS_PER_WG3);
     if (split) {
+        // (the scale word sits in the hi part of the layout: at the same offset in the one- and the two-word layout)
         unsigned* slot = reinterpret_cast<unsigned*>(delta + delta_layout3((size_t)P).scale);
         hipError_t e = hipMemsetAsync(slot, 0, 16, stream);
         if (e != hipSuccess) return e;
         const unsigned sb = (unsigned)min((long)1024, (P + 1023) / 1024);      // one 16-byte load per thread: the launch is latency, not bytes
         hipLaunchKernelGGL(delta_amax_kernel, dim3(sb), dim3(1024), 0, stream, reinterpret_cast<const f32x4*>(d_raw), P, slot);
-        return launch_dgrad_one<SplitF16>(ba, blocks, stream);
+        return split == 5 ? launch_dgrad_one<SplitF16, true>(ba, blocks, stream) : launch_dgrad_one<SplitF16>(ba, blocks, stream);
     }
     return launch_dgrad_one<SplitBF16>(ba, blocks, stream);
 }

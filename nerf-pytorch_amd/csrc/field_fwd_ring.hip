@@ -30,7 +30,8 @@ static hipError_t launch_one(const FieldFwdRingArgs& a, unsigned blocks, hipStre
 
 // split: 0 = bf16 (packed3 from the bf16 repack), 1 = fp16 (packed3 from the fp16 repack); split_types.h
 // 2 = fp16 main term + fp8 correction terms (field_ring8.h; inference only: act must be null; packed3 from the reduced repack);
-// 3 = the same, every ray's last sample left unwritten (launch_field_fwd16r_last evaluates it)
+// 3 = the same, every ray's last sample left unwritten (launch_field_fwd16r_last evaluates it);
+// 5 = fp16 with TWO-WORD saves (hi and lo rows: act laid out by act_layout3(P, N, true)); without act it is split 1
 hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_stride, const float* z_vals,
                                int n_rays, int S, float* raw, float* act, int split, hipStream_t stream) {
     FieldFwdRingArgs a{packed3, rays, z_vals, raw, act, ray_stride, n_rays, S, S, 0, S, 0, split == 3 ? 1 : 0};
@@ -39,6 +40,7 @@ hipError_t launch_field_fwd16r(const float* packed3, const float* rays, int ray_
     // the kernel's point arithmetic is 32-bit, and a saving launch addresses its rows with 32-bit lane offsets (field_fwd_ring_body.h)
     if (P > FWD16R_MAX_POINTS || (act && P > FWD16R_MAX_SAVED_POINTS)) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((P + PTS_PER_WG - 1) / PTS_PER_WG);
+    if (split == 5) return act ? launch_one<3, SplitF16>(a, blocks, stream) : launch_one<0, SplitF16>(a, blocks, stream);
     if (split >= 2) return act ? hipErrorInvalidValue : launch_one<0, SplitF16, true>(a, blocks, stream);
     if (split) return act ? launch_one<2, SplitF16>(a, blocks, stream) : launch_one<0, SplitF16>(a, blocks, stream);
     return act ? launch_one<2, SplitBF16>(a, blocks, stream) : launch_one<0, SplitBF16>(a, blocks, stream);

@@ -41,7 +41,11 @@ static_assert((FWD16_UNITS_TRUNK + FWD16_UNITS_SKIP) * UNIT_WORDS == P16F_VIEWS,
 // packed buffer made by the reduced repack (nerf_pack_params_split(split = 2)).
 template <int SAVE, typename SP, bool RED = false>
 __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, float* lds, long wg) {
-    static_assert(SAVE == 0 || SAVE == 2, "inference or 16-bit rows");
+    // SAVE: 0 = inference; 2 = 16-bit rows (the hi words: 11 / 8 significant bits); 3 = hi AND lo words ("fp16x3w", round 6: the
+    // weight-gradient GEMM then contracts two-word operands, X_hi d_hi + X_lo d_hi + X_hi d_lo) -- the lo words go to the mirror
+    // of the layout at ActLayout3::lo
+    static_assert(SAVE == 0 || SAVE == 2 || SAVE == 3, "inference, 16-bit rows, or (hi, lo) rows");
+    constexpr bool TWO = SAVE == 3;
     static_assert(!RED || (SAVE == 0 && SP::F16), "the reduced products are an inference form of the fp16 split");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -81,20 +85,23 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     char* const act_bytes = reinterpret_cast<char*>(a.act);
     // rows (r0, r0 + 1) of block nb of this lane's point, paired with the neighbour point: one dword store (unconditional;
     // a wave whose tile lies beyond the padded range writes to the unused `feat` region)
-    auto store_word = [&](size_t region, int F, int nb, int r0, unsigned own) __attribute__((always_inline)) {
-        char* tile_base = act_bytes + 4 * (tile_ok ? region : al.feat) + (tile_ok ? (size_t)tile16 * (size_t)(F * 32) : (size_t)0)
-                          + (size_t)((16 * nb + 4 * r0) * 32);
+    auto store_word = [&](size_t region, int F, int nb, int r0, unsigned own, bool lo_part = false) __attribute__((always_inline)) {
+        char* tile_base = act_bytes + 4 * ((tile_ok ? region : al.feat) + (lo_part ? al.lo : (size_t)0))
+                          + (tile_ok ? (size_t)tile16 * (size_t)(F * 32) : (size_t)0) + (size_t)((16 * nb + 4 * r0) * 32);
         paired_store(own, pair_sel, [&](unsigned word) __attribute__((always_inline)) { nt_store_saddr(tile_base, lane_pair_bytes, word); });
     };
     if (SAVE) {
-        al = act_layout3((size_t)P, (size_t)a.n_rays);
+        al = act_layout3((size_t)P, (size_t)a.n_rays, TWO);
         if (valid) {
             char* enc_tile = act_bytes + 4 * al.enc + (size_t)(tile16 >> 1) * (size_t)(64 * 32 * 2);     // the wave's 32-point tile (uniform)
             const unsigned pp2 = 2u * (p_raw & 31u);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int col = encslot(s, q);
-                if (col >= 0) nt_store(reinterpret_cast<unsigned short*>(enc_tile + ((unsigned)col * 64u + pp2)), SP::cvt1(e[s]));
+                if (col >= 0) {
+                    nt_store(reinterpret_cast<unsigned short*>(enc_tile + ((unsigned)col * 64u + pp2)), SP::cvt1(e[s]));
+                    if (TWO) nt_store(reinterpret_cast<unsigned short*>(enc_tile + 4 * al.lo + ((unsigned)col * 64u + pp2)), split_lo<SP>(e[s]));
+                }
             }
         }
     }
@@ -110,11 +117,16 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
             for (int r = 0; r < 4; ++r) h[4 * nb + r] = relu(acc[nb][r]);
     };
     // row stores guaranteed behind the last fetch part (one per unit, positions 3..6); none under the store-less timing ablations
-    constexpr int NP = (SAVE && NERF_ABL_SAVE != 1 && NERF_ABL_SAVE != 3) ? 4 : 0;
+    constexpr int NP = (SAVE && NERF_ABL_SAVE != 1 && NERF_ABL_SAVE != 3) ? (TWO ? 8 : 4) : 0;
     auto store_pair = [&](size_t region, int F, int nb, int r0, float v0, float v1) __attribute__((always_inline)) {
-        store_word(region, F, nb, r0, SP::cvt_pk(v0, v1));
+        if constexpr (TWO) {
+            unsigned hi, lo;
+            SP::split_pair(v0, v1, hi, lo);
+            store_word(region, F, nb, r0, hi);
+            store_word(region, F, nb, r0, lo, true);
+        } else store_word(region, F, nb, r0, SP::cvt_pk(v0, v1));
     };
-    auto no_store = [](auto, auto, const u32x4&) __attribute__((always_inline)) {};
+    auto no_store = [](auto, auto, const u32x4&, const u32x4&) __attribute__((always_inline)) {};
     // rows of the layer in h[] leave while the next contraction consumes them: unit (k-step kk, group gg) covers
     // block 2 kk + (gg >> 1), rows 2 (gg & 1), 2 (gg & 1) + 1 (row16h order)
     size_t row_region = 0;
@@ -131,11 +143,12 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
         asm volatile("" : "+v"(b));
         mw[(nb >> 2) & 1] |= b;
     };
-    auto store_rows = [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
+    auto store_rows = [&](auto kk, auto gg, const u32x4& bhi, const u32x4& blo) __attribute__((always_inline)) {
         if (!SAVE) return;
         constexpr int nb = 2 * decltype(kk)::value + (decltype(gg)::value >> 1);
         constexpr int r0 = 2 * (decltype(gg)::value & 1);
         store_word(row_region, W, nb, r0, bhi[decltype(gg)::value]);
+        if constexpr (TWO) store_word(row_region, W, nb, r0, blo[decltype(gg)::value], true);
         mask_bits(std::integral_constant<int, nb>{}, std::integral_constant<int, r0>{});
         mask_bits(std::integral_constant<int, nb>{}, std::integral_constant<int, r0 + 1>{});
     };
@@ -219,11 +232,15 @@ __device__ __forceinline__ void field_fwd16r_tile(const FieldFwdRingArgs& a, flo
     load_bias<8>(av, ring_small_ptr(lds, SM_BVIEWS), q_l);
     {   // layer 7's rows leave under the 16 units of the trunk part: k-step kk = blocks 2 kk, 2 kk + 1, half of them per unit
         row_region = (size_t)(D - 1) * layer_floats;
-        auto store_rows_v = [&](auto kk, auto gg, const u32x4& bhi) __attribute__((always_inline)) {
+        auto store_rows_v = [&](auto kk, auto gg, const u32x4& bhi, const u32x4& blo) __attribute__((always_inline)) {
             if (!SAVE) return;
             constexpr int nb = 2 * decltype(kk)::value + decltype(gg)::value;
             store_word(row_region, W, nb, 0, bhi[2 * decltype(gg)::value]);
             store_word(row_region, W, nb, 2, bhi[2 * decltype(gg)::value + 1]);
+            if constexpr (TWO) {
+                store_word(row_region, W, nb, 0, blo[2 * decltype(gg)::value], true);
+                store_word(row_region, W, nb, 2, blo[2 * decltype(gg)::value + 1], true);
+            }
             static_for<0, 4>([&](auto rc) __attribute__((always_inline)) { mask_bits(std::integral_constant<int, nb>{}, rc); });
         };
         if constexpr (RED) ring_units8<16>(ring, fa, fb, fl, av, h, red_scale(7, 0), red_scale(7, 1));

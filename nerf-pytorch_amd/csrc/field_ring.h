@@ -193,8 +193,9 @@ __device__ __forceinline__ void unit_pipelined(Acc (&acc)[NB], int g4, const Fra
 
 // NU units of one contraction: G groups (units) per k-step, B operand of k-step s = v[VOFF + 8 s ..+7].  The first
 // unit is at position 0 of its chunk (every contraction starts on a chunk boundary); FIRST = the very first units of
-// the kernel (no fetch in progress at positions 0..2).  `after(k-step, group, bhi)` runs behind the 10th MFMA of each
-// unit (row stores; bhi = the hi words of the k-step in progress, which ARE the 16-bit values of its rows).  NPEND: see WeightRing::barrier (the row stores of positions 3..6 follow the last part of a fetch: 4 when
+// the kernel (no fetch in progress at positions 0..2).  `after(k-step, group, bhi, blo)` runs behind the 10th MFMA of each
+// unit (row stores; bhi = the hi words of the k-step in progress, which ARE the 16-bit values of its rows; blo = their remainders,
+// stored as well by the two-word save forms).  NPEND: see WeightRing::barrier (the row stores of positions 3..6 follow the last part of a fetch: 4 when
 // one per unit).  fa holds the hi fragments of the first unit on entry and of the unit after the last one on exit (NU is
 // even); fb is the second hi set, fl the lo set of the unit in progress.
 template <typename SP, int NU, int G, int VOFF, bool FIRST, int NPEND, int NW, typename Acc, int NB, int NV, typename After>
@@ -230,7 +231,7 @@ __device__ __forceinline__ void ring_units(WeightRingT<NW>& ring, Frag& fa, Frag
                 nhi[j] = wh;
                 nlo[j] = wl;
             }
-            if constexpr (t == 2) after(std::integral_constant<int, s>{}, std::integral_constant<int, g>{}, bhi);
+            if constexpr (t == 2) after(std::integral_constant<int, s>{}, std::integral_constant<int, g>{}, bhi, blo);
         });
         if constexpr (!(FIRST && i < 3)) ring.template fetch_after_unit<pos>();
     });

@@ -254,9 +254,11 @@ struct ActLayout3 {
     size_t dir_pt;      // 16-bit tiles of 32: the same per point (or [N][32][8 copies] when a ray's samples fill whole tiles), expanded
     //                    right before the weight-gradient GEMM
     size_t mask;        // [9][P][2] x 128 ReLU sign bits in the lane order of the split kernels (9th = view branch)
+    size_t lo;          // two-word saves (round 6, "fp16x3w"): word offset of a MIRROR of this whole layout that holds the LO words
+    //                    (lo = T(v - hi)) of h[0..7], hv, enc, dir_pt at the same offsets; 0 = the one-word layout
     size_t total;
 };
-__host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N) {
+__host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N, bool two_word = false) {
     ActLayout3 a{};
     const size_t Pp = pad32(P);
     size_t o = 0;
@@ -270,15 +272,17 @@ __host__ __device__ inline ActLayout3 act_layout3(size_t P, size_t N) {
     o = (o + 3) & ~(size_t)3;
     a.mask = o; o += (size_t)(D + 1) * P * 8;
     o += 2048;          // slack for the weight-gradient staging's reads past a narrow operand's last tile
-    a.total = o;
+    a.lo = two_word ? o : 0;        // (o is a multiple of 4 words: every mirrored region keeps its 16-byte alignment)
+    a.total = two_word ? 2 * o : o;
     return a;
 }
 // graw: tiles of 4 = copy of d_raw (rgb3, sigma).  scale: 4 words, word 0 = the bit pattern of max|d_raw| over the launch
 // (delta_amax_kernel, field_bwd_ring.hip) -- the fp16 split's delta chain runs on s * d_raw, s = delta_scale_of(max) an exact
 // power of two, so that the deltas sit in fp16's range; every stored delta and every partial weight gradient carries the factor
 // s, wgrad_reduce_kernel removes it (both kernels derive s / 1/s from the same word).
-struct DeltaLayout3 { size_t h[D], feat, hv, graw, scale, total; };       // feat: dump region, as in ActLayout3
-__host__ __device__ inline DeltaLayout3 delta_layout3(size_t P) {
+// lo: as ActLayout3::lo -- the mirror holds the lo words of h[0..7], hv, graw; the scale word exists once (hi part)
+struct DeltaLayout3 { size_t h[D], feat, hv, graw, scale, lo, total; };   // feat: dump region, as in ActLayout3
+__host__ __device__ inline DeltaLayout3 delta_layout3(size_t P, bool two_word = false) {
     DeltaLayout3 a{};
     const size_t Pp = pad32(P);
     size_t o = 0;
@@ -288,7 +292,8 @@ __host__ __device__ inline DeltaLayout3 delta_layout3(size_t P) {
     a.graw = o; o += region_words3(Pp, 4);
     o += 2048;          // the weight-gradient staging reads 64 rows of 128 B from a tile of this 4-row region
     a.scale = o; o += 4;
-    a.total = o;
+    a.lo = two_word ? o : 0;
+    a.total = two_word ? 2 * o : o;
     return a;
 }
 // the scaled d_raw's largest magnitude: 2^DELTA_SCALE_TARGET_LOG2 <= s * max|d_raw| < 2 * that.  fp16 overflows at 2^16: a delta may

@@ -24,7 +24,7 @@ struct RenderWs {
     size_t total;
 };
 RenderWs render_ws(int n_rays, int Sc, int Sf, int training, int precision) {
-    const int dp = precision == 0 ? 0 : 1;          // scratch regions sized for the configured datapath (16-bit tiles on the split ones)
+    const int dp = precision == 0 ? 0 : (precision == 5 ? 2 : 1);      // scratch regions sized for the configured datapath (16-bit tiles on the split ones, hi + lo on 5)
     RenderWs w{};
     const size_t N = (size_t)n_rays;
     const int S2 = Sc + Sf;
@@ -63,7 +63,7 @@ __global__ void add_inplace_kernel(float* dst, const float* src, size_t n) {
 }
 
 bool cfg_ok(const NerfRenderCfg* c) {
-    return c && c->n_coarse >= 3 && c->n_fine >= 0 && c->n_coarse + c->n_fine <= 4096 && (c->precision == 0 || c->precision == 1 || c->precision == 3) &&
+    return c && c->n_coarse >= 3 && c->n_fine >= 0 && c->n_coarse + c->n_fine <= 4096 && (c->precision == 0 || c->precision == 1 || c->precision == 3 || c->precision == 5) &&
            c->raw_noise_std >= 0.0f;
 }
 
@@ -73,6 +73,10 @@ hipError_t field_forward(const NerfRenderCfg* c, const float* packed, const floa
     if (c->precision == 0) {
         if (act) tag_record(act, 0, ACT_ROWS_F32, n, S);
         return nerf::launch_field_fwd(packed, rays, stride, z, n, S, raw, act, st);
+    }
+    if (c->precision == 5) {        // fp16 split, two-word saves
+        if (act) tag_record(act, 0, ACT_TILE16_F16X2, n, S);
+        return nerf::launch_field_fwd16r(packed, rays, stride, z, n, S, raw, act, act ? 5 : 1, st);
     }
     if (c->precision == 3) {        // fp16 split: 16-bit (fp16) rows always
         if (act) tag_record(act, 0, ACT_TILE16_F16, n, S);
@@ -87,6 +91,12 @@ hipError_t field_backward(const NerfRenderCfg* c, const float* packed, const flo
                           float* delta, float* partial, float* grad, int accumulate, hipStream_t st) {
     if (c->precision == 0) return nerf::launch_field_bwd(packed, act, d_raw, n, S, delta, partial, grad, accumulate, st);
     hipError_t e;
+    if (c->precision == 5) {
+        e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, 5, st);
+        if (e != hipSuccess) return e;
+        tag_record(delta, 1, DELTA_TILE32_F16X2, n, S);
+        return nerf::launch_field_wgrad(act, delta, d_raw, n, S, partial, grad, accumulate, 6, 7, st, params);
+    }
     if (c->precision == 3) {
         e = nerf::launch_field_dgrad3r(packed, act, d_raw, n, S, delta, 1, st);
         if (e != hipSuccess) return e;
@@ -112,7 +122,7 @@ int nerf_render_rays_fwd(const NerfRenderCfg* cfg, const float* packed_c, const 
                          int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
                          float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
                          float* workspace, int training, void* stream) {
-    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0 / 1 / 3, raw_noise_std >= 0)");
+    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0 / 1 / 3 / 5, raw_noise_std >= 0)");
     REQUIRE(packed_c && rays && rgb && disp && acc && raw && workspace, "null pointer");
     REQUIRE(ray_stride >= 11, "rays must carry view directions (ray_stride >= 11): use_viewdirs=True architecture");
     REQUIRE(n_rays >= 0, "bad size");
@@ -168,7 +178,7 @@ int nerf_render_rays_infer(const NerfRenderCfg* cfg, const float* packed_c, cons
                            int n_rays, const float* t_rand, const float* noise_c, const float* u, const float* noise_f,
                            float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
                            float* workspace, void* stream) {
-    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0 / 1 / 3, raw_noise_std >= 0)");
+    REQUIRE(cfg_ok(cfg), "bad NerfRenderCfg (n_coarse >= 3, n_fine >= 0, precision 0 / 1 / 3 / 5, raw_noise_std >= 0)");
     REQUIRE(nerf_render_infer_supported(cfg), "one-launch inference: a three-term split datapath (precision 1 / 3), 16 * n_coarse and 16 * (n_coarse + n_fine) "
             "multiples of 128, n_coarse + n_fine <= 1024 (use nerf_render_rays_fwd(training = 0) otherwise)");
     REQUIRE(packed_c && rays && rgb && disp && acc && raw && workspace, "null pointer");
@@ -194,7 +204,7 @@ int nerf_render_rays_infer(const NerfRenderCfg* cfg, const float* packed_c, cons
     a.raw_c = fine ? ws + w.raw_c : raw;
     a.rgb_c = fine ? rgb0 : rgb; a.disp_c = fine ? disp0 : disp; a.acc_c = fine ? acc0 : acc;
     a.z_f = ws + w.z_f; a.z_std = z_std; a.raw_f = raw; a.rgb_f = rgb; a.disp_f = disp; a.acc_f = acc;
-    a.split = cfg->precision == 3 ? 1 : 0;
+    a.split = (cfg->precision == 3 || cfg->precision == 5) ? 1 : 0;
     return done(__func__, nerf::launch_render_infer(a, (hipStream_t)stream));
 }
 

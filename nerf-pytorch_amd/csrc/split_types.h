@@ -120,7 +120,7 @@ struct SplitF16 {
 // of both points, the odd lane row R+1, so one dword store carries two values and an instruction writes two full 128-byte lines.
 // Every lane of the wave takes part (DPP) and the stores are UNCONDITIONAL (a per-lane predicate is an exec-mask branch -- and a
 // basic-block boundary for the scheduler -- per store: measured 6 % of the dgrad kernel): the caller passes a tile that exists.
-template <typename SP, int OB0, int NOB, int NV>
+template <typename SP, int OB0, int NOB, int NV, bool LO = false>
 __device__ __forceinline__ void store_tile16_pair(unsigned short* tile_base, int lane, const float (&v)[NV]) {
     const unsigned odd = (unsigned)lane & 1u;
     const unsigned sel = odd ? 0x03020706u : 0x05040100u;
@@ -129,7 +129,11 @@ __device__ __forceinline__ void store_tile16_pair(unsigned short* tile_base, int
     for (int ob = OB0; ob < OB0 + NOB; ++ob)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const unsigned own = SP::cvt_pk(v[16 * ob + r], v[16 * ob + r + 1]);
+            unsigned own;
+            if constexpr (LO) {         // the remainders lo = T(v - hi) of the same pair (two-word saves)
+                unsigned hi;
+                SP::split_pair(v[16 * ob + r], v[16 * ob + r + 1], hi, own);
+            } else own = SP::cvt_pk(v[16 * ob + r], v[16 * ob + r + 1]);
             paired_store(own, sel, [&](unsigned word) __attribute__((always_inline)) { nt_store(base + (32 * ob + (r & 3) + 8 * (r >> 2)) * 16, word); });
         }
 }

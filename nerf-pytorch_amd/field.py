@@ -149,6 +149,7 @@ class NeRF(nn.Module):
     def packed_params(self, precision="fp32"):
         """Fragment repack of the current parameters for the given datapath (cached on the parameters' versions)."""
         flat = self._refresh_packed_cache()
+        precision = hb.PACK_OF.get(precision, precision)        # (e.g. "fp16x3w" reads fp16x3's fragments)
         if precision not in self._packed:
             # fresh tensor each time: a pending backward keeps a reference to the old one
             self._packed[precision] = hb.pack_params(flat, precision=precision)
@@ -192,6 +193,7 @@ class NeRF(nn.Module):
 def packed_params_pair(model_a, model_b, precision):
     """(model_a.packed_params(precision), model_b.packed_params(precision)); when BOTH repacks are stale -- every training step, after
     the optimizer step -- the two networks are repacked in the two launches one takes (hb.pack_params_pair) instead of four."""
+    precision = hb.PACK_OF.get(precision, precision)
     if model_a is model_b or precision not in ("fp16x3", "bf16x3") or not (isinstance(model_a, NeRF) and isinstance(model_b, NeRF)):
         return model_a.packed_params(precision), model_b.packed_params(precision)
     fa, fb = model_a._refresh_packed_cache(), model_b._refresh_packed_cache()

@@ -15,7 +15,7 @@ from . import build as _build
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
-ABI_VERSION = 9        # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
+ABI_VERSION = 10       # NERF_ABI_VERSION of include/nerf_hip.h this binding was written against
 
 
 class NerfHipError(RuntimeError):
@@ -192,6 +192,7 @@ BYTES_ACT3_PER_POINT = BYTES_ACT_PER_POINT - 4 * 256
 BYTES_DELTA3_PER_POINT = BYTES_DELTA_PER_POINT - 4 * 256
 BYTES_ACT3_BF16_PER_POINT = 2 * (8 * 256 + 128 + 64) + 32 * 9 + 16  # bf16 rows + encodings, ReLU bitmasks, raw
 BYTES_DELTA3_BF16_PER_POINT = 2 * (8 * 256 + 128 + 4)
+BYTES_ACT3_LO_PER_POINT = 2 * (8 * 256 + 128 + 64)        # "fp16x3w": the lo words of the saved rows and of the xyz encoding
 # 12 jobs on 16-bit operands (round 5: the alpha head's row rides on the (delta_hv, h7) job -- h7 is not re-read for it): 9,808 B per
 # point (PMC: 9.83 KB)
 BYTES_WGRAD_MIXED_PER_POINT = 0.5 * (BYTES_WGRAD_BIG_PER_POINT + BYTES_WGRAD_SMALL_PER_POINT - 4 * (256 + 256)) - 2 * 256
@@ -233,8 +234,13 @@ def pack_table():
 # "fp16_fp8c" (round 4, INFERENCE class): no_grad rendering with every product of the 256-wide layers as fp16 main term + two fp8
 # correction terms (csrc/field_ring8.h: ~2^-15 per product, 2 instead of 3 MFMA-equivalents; every ray's last sample re-evaluated
 # with the three-term fp16 products); anything that needs gradients runs the fp16x3 datapath unchanged.  Never the bench headline.
-PRECISIONS = ("fp32", "fp16x3", "bf16x3", "fp16_fp8c")
-SPLIT = ("fp16x3", "bf16x3", "fp16_fp8c")       # datapaths on the three-term-split kernels (folded feature layer, tiled saves)
+# "fp16x3w" (round 6): fp16x3 with TWO-WORD operands in the weight-gradient GEMM -- the forward and the delta chain save the lo words
+# next to the hi words and the GEMM contracts d_hi X_hi + d_hi X_lo + d_lo X_hi (the forward's product class, ~2^-22, instead of 11-bit
+# operands) at twice the saved bytes and three times the GEMM's MFMAs.  Forward values are bit-identical to fp16x3's.  Not the default:
+# it is the instrument that prices the one-word operand storage (profiles/r06_*).
+PRECISIONS = ("fp32", "fp16x3", "bf16x3", "fp16_fp8c", "fp16x3w")
+SPLIT = ("fp16x3", "bf16x3", "fp16_fp8c", "fp16x3w")       # datapaths on the three-term-split kernels (folded feature layer, tiled saves)
+PACK_OF = {"fp16x3w": "fp16x3"}                 # datapaths that read another datapath's fragment repack
 
 
 def pack_table3():
@@ -269,6 +275,7 @@ def _small_offset():
 
 def pack_params(flat, out=None, precision="fp32"):
     L = lib()
+    precision = PACK_OF.get(precision, precision)
     if precision == "fp16_fp8c":    # the reduced inference stream (fp16 main + fp8 correction fragments) in the 16-point forward stream's slot
         if out is None:
             out = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat.device)
@@ -293,7 +300,7 @@ def pack_params(flat, out=None, precision="fp32"):
 def pack_params_pair(flat_a, flat_b, precision):
     """the (hi, lo) fragment repack of two networks in the two launches one takes (nerf_pack_params_split_pair; fp16x3 / bf16x3)"""
     L = lib()
-    split = {"bf16x3": 0, "fp16x3": 1}[precision]
+    split = {"bf16x3": 0, "fp16x3": 1}[PACK_OF.get(precision, precision)]
     out_a = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat_a.device)
     out_b = torch.empty(L.nerf_packed3_floats(), dtype=torch.float32, device=flat_a.device)
     _check(L.nerf_pack_params_split_pair(_ptr(flat_a, "params"), _ptr(out_a, "packed"), _ptr(flat_b, "params"), _ptr(out_b, "packed"), 1 | 4, split,
@@ -366,10 +373,10 @@ def sample_ray_batch(H, W, K, pose, image, n_rand, window, key, want_pixels=Fals
 
 
 def _dp(precision):
-    """datapath index of the *_dp size entry points: 0 = fp32 rows, 1 = 16-bit tiles of the split datapaths"""
+    """datapath index of the *_dp size entry points: 0 = fp32 rows, 1 = 16-bit tiles of the split datapaths, 2 = hi + lo tiles"""
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {PRECISIONS}")
-    return 0 if precision == "fp32" else 1
+    return 0 if precision == "fp32" else (2 if precision == "fp16x3w" else 1)
 
 
 def act_floats(n_rays, n_samples, precision=None):
@@ -463,7 +470,7 @@ class NerfRenderCfg(ctypes.Structure):
                 ("raw_noise_std", ctypes.c_float), ("precision", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
-ACT_LAYOUTS = {0: "fp32 rows", 1: "tile32 fp32", 2: "tile32 bf16", 3: "tile16 fp32", 4: "tile16 bf16", 5: "tile16 fp16"}
+ACT_LAYOUTS = {0: "fp32 rows", 1: "tile32 fp32", 2: "tile32 bf16", 3: "tile16 fp32", 4: "tile16 bf16", 5: "tile16 fp16", 6: "tile16 fp16 hi + lo"}
 
 
 def buffer_layout(buf):
@@ -489,13 +496,24 @@ _REGIONS = {**{"h%d" % i: (i, 256) for i in range(8)}, "feat": (8, 256), "hv": (
 
 def buffer_regions(n_rays, n_samples, split, is_delta=False):
     """nerf_debug_layout: region offsets (floats) of a save / delta buffer for n_rays x n_samples points; split = the split
-    datapaths' tiles of 16-bit elements (False: the fp32 datapath's point-major rows)."""
+    datapaths' tiles of 16-bit elements (False: the fp32 datapath's point-major rows; 2: the two-word layout, whose "lo" entry is the
+    offset of the mirror that holds the lo words)."""
     out = (ctypes.c_longlong * 16)()
-    _check(lib().nerf_debug_layout(int(n_rays), int(n_samples), int(bool(split)), int(bool(is_delta)), out), "nerf_debug_layout")
+    _check(lib().nerf_debug_layout(int(n_rays), int(n_samples), int(split), int(bool(is_delta)), out), "nerf_debug_layout")
     keys = [f"h{i}" for i in range(8)] + ["feat", "hv"] + (["graw", "scale"] if is_delta else ["enc", "dir", "dir_pt", "mask"])
     reg = {k: int(out[i]) for i, k in enumerate(keys)}
     reg["total"] = int(out[14])
+    reg["lo"] = int(out[15]) if int(split) == 2 else 0
     return reg
+
+
+def _family(precision):
+    """nerf_debug_layout family of a datapath"""
+    return 0 if precision not in SPLIT else (2 if precision == "fp16x3w" else 1)
+
+
+def _elem16(precision):
+    return torch.bfloat16 if precision == "bf16x3" else torch.float16
 
 
 def _tile32(flat16, Pa, F, P):
@@ -503,20 +521,22 @@ def _tile32(flat16, Pa, F, P):
     return flat16[:Pa * F].float().view(Pa // 32, F, 32).permute(0, 2, 1).reshape(Pa, F)[:P]
 
 
-def saved_rows(buf, n_rays, n_samples, region, precision="fp32"):
+def saved_rows(buf, n_rays, n_samples, region, precision="fp32", part="hi"):
     """Debug / test view of one region of a save buffer as a point-major [P, F] fp32 tensor.  region: "h0".."h7", "hv", "enc", and
     on the fp32 datapath "feat" (the split datapaths fold feature_linear into the view branch and never write it).  fp32 datapath:
     point-major fp32 rows; split datapaths: 16-bit elements (fp16 / bf16 by `precision`), the 256- / 128-wide rows in 16-point tiles
     with the row16h row order, the encoding in 32-point feature-major tiles (csrc/nerf_common.h)."""
     split = precision in SPLIT
     P = n_rays * n_samples
-    reg = buffer_regions(n_rays, n_samples, split)
+    reg = buffer_regions(n_rays, n_samples, _family(precision))
     F = 64 if region == "enc" else _REGIONS[region][1]
-    off = reg[region]
+    off = reg[region] + (reg["lo"] if part == "lo" else 0)      # part="lo" ("fp16x3w" only): the remainders T(v - hi)
+    if part == "lo" and not reg["lo"]:
+        raise NerfHipError("saved_rows(part='lo'): only the two-word layout (\"fp16x3w\") holds lo words")
     if not split:
         return buf[off:off + P * F].view(P, F)
     Pa = (P + 31) // 32 * 32
-    flat = buf[off:off + (Pa * F + 1) // 2].view(torch.bfloat16 if precision == "bf16x3" else torch.float16)
+    flat = buf[off:off + (Pa * F + 1) // 2].view(_elem16(precision))
     if region == "enc":
         return _tile32(flat, Pa, F, P)
     rows = flat[:Pa * F].float().view(Pa // 16, F, 16).permute(0, 2, 1).reshape(Pa, F)[:P]      # [P, row]
@@ -525,7 +545,7 @@ def saved_rows(buf, n_rays, n_samples, region, precision="fp32"):
 
 def saved_dir(buf, n_rays, n_samples, precision="fp32"):
     """the per-ray direction encoding a saving forward wrote: [n_rays, 32] fp32 (27 used)"""
-    off = buffer_regions(n_rays, n_samples, precision in SPLIT)["dir"]
+    off = buffer_regions(n_rays, n_samples, _family(precision))["dir"]
     return buf[off:off + n_rays * 32].view(n_rays, 32)
 
 
@@ -533,28 +553,30 @@ def saved_masks(buf, n_rays, n_samples, precision="fp32"):
     """the ReLU bitmask words of a save buffer as int32 [9, P, 8] (layers 0..7 + view branch; 256 bits per point and layer, in the
     lane order of the datapath's kernels: csrc/nerf_common.h)"""
     P = n_rays * n_samples
-    off = buffer_regions(n_rays, n_samples, precision in SPLIT)["mask"]
+    off = buffer_regions(n_rays, n_samples, _family(precision))["mask"]
     return buf[off:off + 9 * P * 8].view(torch.int32).view(9, P, 8)
 
 
-def delta_rows(buf, n_rays, n_samples, region, precision="fp32"):
+def delta_rows(buf, n_rays, n_samples, region, precision="fp32", part="hi"):
     """Debug / test view of one region of a delta buffer as point-major [P, F] fp32: "h0".."h7", "hv", "feat" (fp32 datapath only),
     "graw" (split datapaths: the tiled 4-wide copy of the scaled d_raw)."""
     split = precision in SPLIT
     P = n_rays * n_samples
-    reg = buffer_regions(n_rays, n_samples, split, is_delta=True)
+    reg = buffer_regions(n_rays, n_samples, _family(precision), is_delta=True)
     F = 4 if region == "graw" else _REGIONS[region][1]
-    off = reg[region]
+    off = reg[region] + (reg["lo"] if part == "lo" else 0)
+    if part == "lo" and not reg["lo"]:
+        raise NerfHipError("delta_rows(part='lo'): only the two-word layout (\"fp16x3w\") holds lo words")
     if not split:
         return buf[off:off + P * F].view(P, F)
     Pa = (P + 31) // 32 * 32
-    flat = buf[off:off + (Pa * F + 1) // 2].view(torch.bfloat16 if precision == "bf16x3" else torch.float16)
+    flat = buf[off:off + (Pa * F + 1) // 2].view(_elem16(precision))
     return _tile32(flat, Pa, F, P)
 
 
 def delta_scale_word(buf, n_rays, n_samples):
     """fp16 split: the bit pattern of the launch's max|d_raw| the dgrad left in its delta buffer (int32 scalar tensor)"""
-    off = buffer_regions(n_rays, n_samples, True, is_delta=True)["scale"]
+    off = buffer_regions(n_rays, n_samples, 1, is_delta=True)["scale"]       # (the same word in the one- and the two-word layout)
     return buf[off:off + 1].view(torch.int32)
 
 
@@ -572,7 +594,7 @@ def render_cfg(n_coarse, n_fine, lindisp, white_bkgd, raw_noise_std, precision):
         raise NerfHipError("render_cfg: the one-call entry points run the fp32 / bf16x3 / fp16x3 datapaths; the reduced inference class "
                            "\"fp16_fp8c\" is a chain of launches with its last-sample guard in between (render._field_pass)")
     return NerfRenderCfg(int(n_coarse), int(n_fine), int(bool(lindisp)), int(bool(white_bkgd)), float(raw_noise_std),
-                         {"fp32": 0, "bf16x3": 1, "fp16x3": 3}[precision], 1)
+                         {"fp32": 0, "bf16x3": 1, "fp16x3": 3, "fp16x3w": 5}[precision], 1)
 
 
 def render_infer_supported(n_coarse, n_fine, precision):
@@ -641,11 +663,12 @@ def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32", guard_pack
                                                         n, S, _ptr(raw), _ptr(nxt, "packed3", True), _ptr(raw_n, "raw", True), S_n,
                                                         _stream()), "nerf_field_fwd_last_sample")
         return raw, act
-    if precision == "fp16x3":
-        with _timed("field_fwd16r_kernel<fp16" + (", save>" if save_act else ">"), FLOP_FWD3_PER_POINT * n * S,
-                    BYTES_ACT3_BF16_PER_POINT * n * S if save_act else nbytes):
+    if precision in ("fp16x3", "fp16x3w"):
+        two = precision == "fp16x3w" and save_act
+        with _timed("field_fwd16r_kernel<fp16" + (", save hi+lo>" if two else ", save>" if save_act else ">"), FLOP_FWD3_PER_POINT * n * S,
+                    (BYTES_ACT3_BF16_PER_POINT + (BYTES_ACT3_LO_PER_POINT if two else 0)) * n * S if save_act else nbytes):
             _check(lib().nerf_field_fwd_split(_ptr(packed, "packed3"), _ptr(rays, "rays"), stride, _ptr(z_vals, "z_vals"),
-                                              n, S, _ptr(raw), _ptr(act, "act", True), 1, _stream()), "nerf_field_fwd_split")
+                                              n, S, _ptr(raw), _ptr(act, "act", True), 5 if two else 1, _stream()), "nerf_field_fwd_split")
         return raw, act
     if precision == "bf16x3":
         with _timed("field_fwd16r_kernel" + ("<save bf16>" if save_act else ""), FLOP_FWD3_PER_POINT * n * S,
@@ -730,7 +753,8 @@ def field_bwd(packed, act, d_raw, grad, accumulate, precision="fp32", params=Non
 
 
 def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partial, n, S, params):
-    split = {"bf16x3": 0, "fp16x3": 1}.get(precision)
+    split = {"bf16x3": 0, "fp16x3": 1, "fp16x3w": 5}.get(precision)
+    two = split == 5
     # what the forward wrote into `act` (the library's own record, nerf_buffer_layout); the weight-gradient call below passes
     # datapath = -1 ("as recorded"), and a mismatched pairing is refused by the library (NERF_E_BADARG)
     kind = buffer_layout(act)[0]
@@ -739,7 +763,8 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
                            "datapaths cannot guess its tiling and element type")
     P = n * S
     if split is not None:
-        with _timed("field_dgrad3r_kernel<fp16>" if split else "field_dgrad3r_kernel<bf16 out>", FLOP_DGRAD3_PER_POINT * P, BYTES_DELTA3_BF16_PER_POINT * P):
+        with _timed("field_dgrad3r_kernel<fp16, hi+lo>" if two else "field_dgrad3r_kernel<fp16>" if split else "field_dgrad3r_kernel<bf16 out>",
+                    FLOP_DGRAD3_PER_POINT * P, BYTES_DELTA3_BF16_PER_POINT * P * (2 if two else 1)):
             _check(L.nerf_field_dgrad_split(_ptr(packed, "packed3"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta), split, _stream()),
                    "nerf_field_dgrad_split")
     else:
@@ -755,7 +780,8 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
         _check(L.nerf_field_wgrad_phase(*args, 7, *tail), "nerf_field_wgrad_phase")
         return grad
     if gemm16:      # all 12 jobs stream 16-bit operands straight into the MFMA
-        with _timed("wgrad1_kernel<fp16>" if split else "wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P, BYTES_WGRAD_MIXED_PER_POINT * P):
+        with _timed("wgrad1_kernel<fp16, 3 terms>" if two else "wgrad1_kernel<fp16>" if split else "wgrad1_kernel", FLOP_WGRAD3_PER_POINT * P,
+                    BYTES_WGRAD_MIXED_PER_POINT * P * (2 if two else 1)):
             _check(L.nerf_field_wgrad_phase(*args, 3, *tail), "nerf_field_wgrad_phase")
     else:
         with _timed("wgrad256_kernel", FLOP_WGRAD_BIG_PER_POINT * P, BYTES_WGRAD_BIG_PER_POINT * P):

@@ -23,6 +23,7 @@ import torch.distributed as dist
 # even when the world is one rank.  A 1-GPU box then executes the RCCL branch as written -- ProcessGroupNCCL, the communicator's
 # stream, the async work objects GradientSync waits on, broadcast, all-gather -- instead of the world-size-1 short cuts.
 FORCE_GROUP = os.environ.get("NERF_FORCE_PROCESS_GROUP") == "1"
+_FORCE_GROUP_ENV = FORCE_GROUP      # what the environment asked for: shutdown() goes back to it
 
 
 def _single(group=None):
@@ -44,7 +45,16 @@ def _free_port():
 def init_distributed(backend=None, force_group=None):
     """Initialise from torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
     Returns (rank, world_size, device).  A single process (no env) is world_size 1 and builds no process group unless
-    force_group / NERF_FORCE_PROCESS_GROUP=1 asks for a one-rank group (FORCE_GROUP above)."""
+    force_group / NERF_FORCE_PROCESS_GROUP=1 asks for a one-rank group (FORCE_GROUP above; shutdown() undoes it).
+
+    Knobs for a node this code has never run on (no multi-GPU node was available to any round; every one of them is an environment
+    variable so that the driver's `bench.py --gpus 8` can be re-run with a different setting without a code change):
+      HSA_ENABLE_IPC_MODE_LEGACY   defaults to 0 here (dmabuf IPC: the only mode the build host's driver supports); a value already in
+                                   the environment wins
+      NERF_DIST_NO_DEVICE_ID=1     do not bind the process group to the device at init (eager communicator creation): the communicator
+                                   is then created lazily by the first collective
+      NERF_DIST_TIMEOUT_S          rendezvous / collective timeout (default 180 s)
+      NERF_ALLOW_SHARED_GPU=1      test rigs with fewer GPUs than ranks (with backend="gloo")"""
     global FORCE_GROUP
     if force_group is not None:
         FORCE_GROUP = bool(force_group)
@@ -60,14 +70,19 @@ def init_distributed(backend=None, force_group=None):
         torch.cuda.set_device(device)
     if (world > 1 or FORCE_GROUP) and not dist.is_initialized():
         import datetime
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500" if world > 1 else str(_free_port()))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this host driver
         kw = {}
         if backend is None:
             backend = "nccl" if use_cuda else "gloo"
-        if backend == "nccl":
+        if backend == "nccl" and os.environ.get("NERF_DIST_NO_DEVICE_ID") != "1":
             kw["device_id"] = device
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+        else:
+            # the forced one-rank group rendezvous on a private TCP store: nothing is written into os.environ (a later subprocess or
+            # spawned worker must not inherit a stale MASTER_PORT)
+            kw["init_method"] = f"tcp://127.0.0.1:{_free_port()}"
         timeout = datetime.timedelta(seconds=float(os.environ.get("NERF_DIST_TIMEOUT_S", "180")))
         try:
             dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout, **kw)
@@ -79,12 +94,35 @@ def init_distributed(backend=None, force_group=None):
                 raise RuntimeError(f"probe all-reduce returned {probe.item()} on a world of {world}")
         except Exception as e:
             env = {k: v for k, v in os.environ.items()
-                   if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_", "ROCR_", "MASTER_", "GLOO_")) or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+                   if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_", "ROCR_", "MASTER_", "GLOO_", "NERF_DIST_")) or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
             raise RuntimeError(
                 f"nerf-pytorch_amd: process group init failed on rank {rank}/{world} (backend {backend}, device {device}, "
                 f"{torch.cuda.device_count() if use_cuda else 0} GPU(s) visible, timeout {timeout.total_seconds():.0f} s): "
                 f"{type(e).__name__}: {e}\nenvironment: {env}") from e
     return rank, world, device
+
+
+def shutdown():
+    """Destroy the process group (if any) and forget a force_group= request: the next init_distributed starts from the environment."""
+    global FORCE_GROUP
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+    FORCE_GROUP = _FORCE_GROUP_ENV
+
+
+def fabric_topology(max_chars=4000):
+    """`rocm-smi --showtopo` (link type / hops / weight between the GPUs of this node: xGMI vs PCIe) as text, or None where the tool is
+    missing -- bench.py puts it into the N > 1 line so that a scaling number can be read against the fabric it was measured on."""
+    import shutil
+    import subprocess
+    if not shutil.which("rocm-smi"):
+        return None
+    try:
+        out = subprocess.run(["rocm-smi", "--showtopo"], capture_output=True, text=True, timeout=30).stdout
+    except Exception:       # noqa: BLE001 (diagnostics only)
+        return None
+    lines = [l.rstrip() for l in out.splitlines() if l.strip() and not set(l.strip()) <= set("=")]
+    return "\n".join(lines)[:max_chars] or None
 
 
 def ranks_seen(group=None):
@@ -138,6 +176,33 @@ def shard_rays(batch_rays, target, rank_=None, world_=None):
     world_ = world_size() if world_ is None else world_
     lo, hi = shard_slice(batch_rays.shape[1], rank_, world_)
     return batch_rays[:, lo:hi], target[lo:hi]
+
+
+def global_randoms(n_global, n_coarse, n_fine, raw_noise_std, generator, device=None):
+    """The random draws of ONE GLOBAL batch of n_global rays, in the reference's order and shapes (t_rand run_nerf.py:371, coarse noise
+    :285, u helpers:208, fine noise :285), from a generator every rank seeds identically.  Each rank keeps its rows
+    (shard_randoms) and hands them to render(..., randoms=...): the G-rank step then computes exactly the one-process step over the
+    same n_global rays (BASELINE configs[3] = 8 shards of 4096 of ONE 32,768-ray batch)."""
+    kw = dict(device=device, generator=generator)
+    r = {"t_rand": torch.rand((n_global, n_coarse), **kw)}
+    if raw_noise_std > 0:
+        r["noise_c"] = torch.randn((n_global, n_coarse), **kw)
+    if n_fine > 0:
+        r["u"] = torch.rand((n_global, n_fine), **kw)
+        if raw_noise_std > 0:
+            r["noise_f"] = torch.randn((n_global, n_coarse + n_fine), **kw)
+    return r
+
+
+def shard_randoms(randoms, rank_=None, world_=None):
+    """this rank's rows of global_randoms() (the same contiguous shard as shard_rays)"""
+    rank_ = rank() if rank_ is None else rank_
+    world_ = world_size() if world_ is None else world_
+    out = {}
+    for k, v in randoms.items():
+        lo, hi = shard_slice(v.shape[0], rank_, world_)
+        out[k] = v[lo:hi].contiguous()
+    return out
 
 
 def frames_of_rank(n_frames, rank_=None, world_=None):
@@ -311,14 +376,48 @@ def broadcast_parameters(models, src=0, group=None):
                 dist.broadcast(p.data, src=src, group=group)
 
 
-def gather_frames(local_frames, frame_ids, n_frames, group=None):
-    """Collect per-rank rendered frames (numpy arrays) on rank 0 in frame order."""
+def gather_frames(local_frames, frame_ids, n_frames, group=None, dst=None):
+    """Collect per-rank rendered frames (numpy arrays, or tuples of them) in frame order: on every rank (dst=None, all_gather_object),
+    or on rank `dst` only (gather_object: the other ranks send, receive nothing and get None)."""
     if _single(group):
         return local_frames
-    gathered = [None] * dist.get_world_size(group)
-    dist.all_gather_object(gathered, (frame_ids, local_frames), group=group)
+    world_ = dist.get_world_size(group)
+    if dst is None:
+        gathered = [None] * world_
+        dist.all_gather_object(gathered, (frame_ids, local_frames), group=group)
+    else:
+        gathered = [None] * world_ if dist.get_rank(group) == dst else None
+        dist.gather_object((frame_ids, local_frames), gathered, dst=dst, group=group)
+        if gathered is None:
+            return None
     out = [None] * n_frames
     for ids, frames in gathered:
         for i, f in zip(ids, frames):
             out[i] = f
     return out
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0, group=None):
+    """Frame-parallel render_path (BASELINE configs[4]; the single-process function is run_nerf.py:137-175 = render.render_path):
+    pose i is rendered by rank i mod G (frames_of_rank), no collective on the data path; every rank writes the PNGs of ITS frames into
+    `savedir` under their global frame numbers (the reference's '{:03d}.png'), and rank 0 returns exactly what render_path returns --
+    (rgbs [F, H, W, 3], disps [F, H, W]) float32 numpy in pose order -- after ONE gather of the finished frames (host arrays: off the
+    rendering path).  The other ranks return (None, None).  One rank (or no process group): plain render_path."""
+    import numpy as np
+    from .render import render_path as render_path_single, _FrameSink, render
+    if _single(group):
+        return render_path_single(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=gt_imgs, savedir=savedir, render_factor=render_factor)
+    H, W, focal = hwf
+    if render_factor != 0:                          # run_nerf.py:141-145
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    n_frames = len(render_poses)
+    mine = frames_of_rank(n_frames, dist.get_rank(group), dist.get_world_size(group))
+    sink = _FrameSink(savedir)
+    for i in mine:
+        rgb, disp, _acc, _extras = render(H, W, K, chunk=chunk, c2w=render_poses[i][:3, :4], **render_kwargs)
+        sink.push(i, rgb, disp)                     # PNG name = the GLOBAL frame number
+    rgbs, disps = sink.close() if mine else (np.zeros((0, H, W, 3), np.float32), np.zeros((0, H, W), np.float32))
+    frames = gather_frames([(rgbs[j], disps[j]) for j in range(len(mine))], mine, n_frames, group=group, dst=0)
+    if frames is None:
+        return None, None
+    return np.stack([f[0] for f in frames], 0), np.stack([f[1] for f in frames], 0)

@@ -322,13 +322,13 @@ def _one_call_step(npa, dev, flat_c, flat_f, rays, rnd, target, precision, lr_st
     n = rays.shape[0]
     s = torch.cuda.current_stream().cuda_stream
     ptr = lambda t: None if t is None else t.data_ptr()
-    prec = {"fp32": 0, "bf16x3": 1, "fp16x3": 3}[precision]
+    prec = {"fp32": 0, "bf16x3": 1, "fp16x3": 3, "fp16x3w": 5}[precision]
     cfg = hb.NerfRenderCfg(64, 128, 0, 1, 1.0 if "noise_c" in rnd else 0.0, prec, 0)
     packed = []
     for flat in (flat_c, flat_f):
         p = torch.empty(L.nerf_packed3_floats() if prec else L.nerf_packed_floats(), device=dev)
         if prec:
-            assert L.nerf_pack_params_split(flat.data_ptr(), p.data_ptr(), 5, int(prec == 3), s) == 0
+            assert L.nerf_pack_params_split(flat.data_ptr(), p.data_ptr(), 5, int(prec in (3, 5)), s) == 0
         else:
             assert L.nerf_pack_params(flat.data_ptr(), p.data_ptr(), s) == 0
         packed.append(p)
@@ -354,7 +354,7 @@ def _one_call_step(npa, dev, flat_c, flat_f, rays, rnd, target, precision, lr_st
     return o, gc, gf
 
 
-@pytest.mark.parametrize("precision,noise", [("fp32", False), ("bf16x3", True), ("fp16x3", True)])
+@pytest.mark.parametrize("precision,noise", [("fp32", False), ("bf16x3", True), ("fp16x3", True), ("fp16x3w", True)])
 def test_one_call_abi_matches_the_binding(npa, dev, nets, precision, noise):
     """nerf_render_rays_fwd / _bwd (one C call per direction, caller-owned workspace) against the in-repo binding's
     render_rays + autograd on the same rays, draws and weights: the same launches in the same order, so outputs and both

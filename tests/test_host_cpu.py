@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/nerf_hip.h but not exported"
     assert declared == set(npa.hip_backend.EXPORTS), declared ^ set(npa.hip_backend.EXPORTS)
     L = npa.hip_backend.lib()
-    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 9 and L.nerf_param_count() == 595844
+    assert L.nerf_abi_version() == npa.hip_backend.ABI_VERSION == 10 and L.nerf_param_count() == 595844
     assert L.nerf_packed_floats() % 4 == 0
 
 
@@ -53,7 +53,10 @@ def test_argument_errors_are_codes_not_crashes():
         assert L.nerf_delta_floats_dp(n, S, 1) == Pp * (8 * 256 + 128 + 4) // 2 + 8192 + 2048 + 4      # + the fp16 split's scale words
         # the two-argument forms: a buffer either datapath may write
         assert L.nerf_act_floats(n, S) == max(a0, a1) and L.nerf_delta_floats(n, S) == max(L.nerf_delta_floats_dp(n, S, 0), L.nerf_delta_floats_dp(n, S, 1))
-        assert L.nerf_act_floats_dp(n, S, 2) == 0 and L.nerf_delta_floats_dp(n, S, -1) == 0
+        # datapath 2 (ABI v10, "fp16x3w"): the same layout twice -- the second copy holds the lo words
+        assert L.nerf_act_floats_dp(n, S, 2) == 2 * a1 and L.nerf_delta_floats_dp(n, S, 2) == 2 * L.nerf_delta_floats_dp(n, S, 1)
+        assert L.nerf_workspace_floats_dp(n, 64, 128, 1, 2) > L.nerf_workspace_floats_dp(n, 64, 128, 1, 1)
+        assert L.nerf_act_floats_dp(n, S, 3) == 0 and L.nerf_delta_floats_dp(n, S, -1) == 0
     assert L.nerf_act_floats_dp(4096, 192, 1) < 0.5 * L.nerf_act_floats_dp(4096, 192, 0)            # 4.8 vs 10.6 KB / point
     assert L.nerf_delta_floats_dp(4096, 192, 1) < 0.5 * L.nerf_delta_floats_dp(4096, 192, 0)
     assert (L.nerf_wgrad_partial_floats(n, S) - (128 * 256 + 128)) % 595844 == 0      # per-chunk partials + fold scratch (G | dbv)
@@ -265,7 +268,7 @@ def test_precision_selection_and_saved_row_views():
     """set_precision accepts the four datapaths and rejects anything else; saved_rows inverts the tile layouts of
     csrc/nerf_common.h: 16-bit elements (bf16 / fp16 by precision), element (p, f) of an F-wide region at (p/32)*F*32 + f*32 + p%32
     (deltas, encodings) or, for the rows the forward saves, in 16-point tiles with the row16h row order."""
-    assert npa.hip_backend.PRECISIONS == ("fp32", "fp16x3", "bf16x3", "fp16_fp8c")
+    assert npa.hip_backend.PRECISIONS == ("fp32", "fp16x3", "bf16x3", "fp16_fp8c", "fp16x3w")
     prev = npa.get_precision()
     try:
         for mode in npa.hip_backend.PRECISIONS:
@@ -305,11 +308,22 @@ def test_precision_selection_and_saved_row_views():
             assert torch.equal(hb.delta_rows(delta, n_rays, S, name, precision), wantd[name]), name
         # regions do not overlap: every region ends before the next one starts (16-bit elements over P rounded up to a tile)
         Pa = (P + 31) // 32 * 32
-        order = sorted((reg[k], k) for k in reg if k not in ("total", "feat"))
+        order = sorted((reg[k], k) for k in reg if k not in ("total", "feat", "lo"))
         sizes = {**{n_: Pa * F // 2 for n_, F in widths}, "dir": n_rays * 32, "mask": 9 * P * 8}
         for (o0, k0), (o1, _k1) in zip(order, order[1:]):
             assert o0 + sizes.get(k0, 0) <= o1, (k0, o0, o1)
         assert order[-1][0] + sizes.get(order[-1][1], 0) <= reg["total"]
+    # the two-word layout ("fp16x3w"): the one-word layout twice; part="lo" reads the same regions of the second copy
+    reg1, reg2 = hb.buffer_regions(n_rays, S, 1), hb.buffer_regions(n_rays, S, 2)
+    assert reg2["lo"] == reg1["total"] and reg2["total"] == 2 * reg1["total"] and all(reg2[k] == reg1[k] for k in reg1 if k not in ("total", "lo"))
+    dreg1, dreg2 = hb.buffer_regions(n_rays, S, 1, is_delta=True), hb.buffer_regions(n_rays, S, 2, is_delta=True)
+    assert dreg2["lo"] == dreg1["total"] and dreg2["total"] == 2 * dreg1["total"] and dreg2["scale"] == dreg1["scale"]
+    both = torch.cat([act, 2 * act])                      # (`act` holds the fp16 case's rows: the last pass of the loop above)
+    assert torch.equal(hb.saved_rows(both, n_rays, S, "h3", "fp16x3w"), want["h3"])
+    lo_view = hb.saved_rows(both, n_rays, S, "h3", "fp16x3w", part="lo")
+    assert lo_view.shape == want["h3"].shape and not torch.equal(lo_view, want["h3"])
+    with pytest.raises(hb.NerfHipError):
+        hb.saved_rows(act, n_rays, S, "h3", "fp16x3", part="lo")
     # one store instruction of that kernel (j fixed, q = 0..3) covers rows {2j, 2j+1} and {8+2j, 8+2j+1}: two full lines
     r16h = npa.hip_backend._row16h
     for r0 in (0, 2):
@@ -483,7 +497,9 @@ def test_buffer_tags_refuse_mismatched_pairings():
 # ---------------------------------------------------------------- build hygiene: no heavy kernel spills
 HEAVY_KERNELS = ["field_fwd16r_kernel<2, nerf::SplitF16, false>", "field_fwd16r_kernel<0, nerf::SplitF16, false>",
                  "field_fwd16r_kernel<0, nerf::SplitF16, true>", "field_fwd16r_last2_kernel<nerf::SplitF16>",
-                 "field_dgrad3r_kernel<nerf::SplitF16>", "wgrad1_kernel<nerf::SplitF16>", "wgrad256_kernel", "wgrad_kernel",
+                 "field_dgrad3r_kernel<nerf::SplitF16, false>", "wgrad1_kernel<nerf::SplitF16, 1>", "wgrad256_kernel", "wgrad_kernel",
+                 # the two-word ("fp16x3w") forms of the three heavy kernels
+                 "field_fwd16r_kernel<3, nerf::SplitF16, false>", "field_dgrad3r_kernel<nerf::SplitF16, true>", "wgrad1_kernel<nerf::SplitF16, 3>",
                  "render_infer_kernel<16, nerf::SplitF16>", "field_fwd_kernel<true>", "field_fwd_kernel<false>", "field_dgrad_kernel"]
 
 
