@@ -60,11 +60,14 @@ DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA products W_hi x_
               "fp16_fp8c": "fp16 main term + fp8 (e4m3) correction terms per product, inference only (gradients: fp16x3)",
               "fp16x3": "fp16x3 (split-fp16 MFMA products W_hi x_hi + W_hi x_lo + W_lo x_hi, hi = fp16(v), lo = fp16(v - hi): ~2^-22 per product, in the "
                         "forward and the delta chain, f32 accumulate / activations / deltas / gradients; the operands of the weight-gradient GEMM are the "
-                        "fp16 hi words (11 significant bits), multiplied exactly, f32 accumulate; deltas scaled by a power of two per launch)"}
+                        "fp16 hi words (11 significant bits), multiplied exactly, f32 accumulate; deltas scaled by a power of two per launch)",
+              "fp16x3w": "fp16x3w (fp16x3 whose weight-gradient GEMM contracts TWO-WORD operands: d_hi X_hi + d_hi X_lo + d_lo X_hi on the hi and lo "
+                         "words the forward and the delta chain save -- the forward's product class in all three heavy kernels; forward values "
+                         "bit-identical to fp16x3's)"}
 
 
 from bench_support import (CONVERGING_PAIRS, LEGO_TXT, PowerSampler, convergence_table, cpu_baseline,  # noqa: E402,F401
-                           rocm_eager_baseline)
+                           gradient_vs_fp64, rocm_eager_baseline)
 
 
 def parse_args(argv=None):
@@ -78,7 +81,7 @@ def parse_args(argv=None):
     ap.add_argument("--rays", type=int, default=N_RAND, help="rays per GPU per step (weak scaling)")
     ap.add_argument("--frame", type=int, default=800, help="render_only: frame side in pixels")
     ap.add_argument("--chunk", type=int, default=1024 * 32)
-    ap.add_argument("--precision", choices=["fp32", "fp16x3", "bf16x3", "fp16_fp8c"], default=os.environ.get("NERF_BENCH_PRECISION", "fp16x3"),
+    ap.add_argument("--precision", choices=["fp32", "fp16x3", "bf16x3", "fp16_fp8c", "fp16x3w"], default=os.environ.get("NERF_BENCH_PRECISION", "fp16x3"),
                     help="headline field datapath.  fp16x3 (default) = three-term split with fp16 parts (3 MFMAs per product, ~2^-22 per product, "
                          "fp32 accumulate / activations / gradients, 11-bit operands for the weight-gradient GEMM); bf16x3 = the same with bf16 parts "
                          "(2^-17, 8-bit operands: rounds 1-3); both admitted by the north-star PSNR criterion, which this run re-measures and "
@@ -145,7 +148,7 @@ def _kernel_class(name):
     if name.startswith(("field_dgrad3_kernel", "field_dgrad3r_kernel")):
         return 3.0, (MAC_DGRAD - MAC_FOLD) / MAC_DGRAD, PEAK_BF16_MFMA_TFLOPS
     if name.startswith("wgrad1_kernel"):
-        return 1.0, (MAC_WGRAD - MAC_FOLD) / MAC_WGRAD, PEAK_BF16_MFMA_TFLOPS
+        return (3.0 if "3 terms" in name else 1.0), (MAC_WGRAD - MAC_FOLD) / MAC_WGRAD, PEAK_BF16_MFMA_TFLOPS
     if name.startswith("wgrad3_256_kernel"):
         return 3.0, (MAC_WGRAD - MAC_FOLD) / MAC_WGRAD, PEAK_BF16_MFMA_TFLOPS
     return 1.0, 1.0, PEAK_FP32_MFMA_TFLOPS
@@ -178,7 +181,8 @@ def _profile_row_matches(timer_name, prof_name):
     """does a kernel row of a rocprofv3 summary (`nerf::field_fwd16r_kernel<2, nerf::SplitF16>`) name the kernel instantiation the
     in-process timer calls `timer_name` (`field_fwd16r_kernel<fp16, save>`)?"""
     base, _, targs = prof_name.replace("void ", "").replace("nerf::", "").strip('"').partition("<")
-    targs = [a.strip() for a in targs.rstrip(">").split(",")] if targs else []
+    targs = targs[:targs.rfind(">")] if ">" in targs else targs        # (drop the argument list of a full signature)
+    targs = [a.strip() for a in targs.split(",")] if targs else []
     key = timer_name.split("<")[0].split("(")[0]
     if base.split("(")[0] != key:
         return False
@@ -187,11 +191,11 @@ def _profile_row_matches(timer_name, prof_name):
         return False
     first = {"false": "0", "true": "1", "": "0"}.get(targs[0] if targs else "", targs[0] if targs else "")
     if key in ("field_fwd3_kernel", "field_fwd16_kernel", "field_fwd16r_kernel", "field_fwd_kernel"):
-        want = "2" if ("<save bf16>" in timer_name or (f16 and "save" in timer_name)) else ("1" if "<save" in timer_name else "0")
+        want = "3" if "hi+lo" in timer_name else "2" if ("<save bf16>" in timer_name or (f16 and "save" in timer_name)) else ("1" if "<save" in timer_name else "0")
         return first == want
-    if key in ("field_dgrad3_kernel", "field_dgrad3r_kernel"):
-        want = "2" if ("<bf16 out>" in timer_name or f16) else "0"
-        return first == want
+    two = "hi+lo" in timer_name or "3 terms" in timer_name          # the two-word forms: <SP, true> / <SP, 3>
+    if key in ("field_dgrad3_kernel", "field_dgrad3r_kernel", "wgrad1_kernel") and len(targs) > 1:
+        return (targs[1] in ("true", "3")) == two
     return True
 
 
@@ -199,8 +203,8 @@ def pmc_traffic(kernel_name, precision):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary of this same command (separate --pmc
     passes; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the
     process, so this is the profile of the same command committed under profiles/ (None if absent)."""
-    tag = {"bf16x3": "bf16x3_", "fp16x3": "fp16x3_"}.get(precision, "")
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    tag = {"bf16x3": "bf16x3_", "fp16x3": "fp16x3_", "fp16x3w": "fp16x3w_"}.get(precision, "")
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}pmc_summary.csv")
         if os.path.exists(path):
             break
@@ -248,6 +252,22 @@ def rccl_version():
         return f"unknown ({type(e).__name__})"
 
 
+def per_rank_ms(seconds, steps, world):
+    """every rank's own ms per step of the timed region (all-gather of one float64 per rank): {"min", "max", "by_rank"} -- `value` is
+    computed from the MAX (the contract); a slow GCD or a rank that waits in the all-reduce shows up here as the spread"""
+    import torch
+    import torch.distributed as dist
+    ms = 1e3 * seconds / max(steps, 1)
+    if world <= 1 or not dist.is_initialized():
+        return {"min": ms, "max": ms, "by_rank": [ms]}
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor([ms], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    vals = [round(float(t.item()), 4) for t in out]
+    return {"min": min(vals), "max": max(vals), "by_rank": vals}
+
+
 # --------------------------------------------------------------------------------------------- main
 def dry_run(args):
     """Launcher / process-group plumbing without GPU work (CPU test of the N > 1 path): rendezvous, sharding arithmetic
@@ -269,9 +289,11 @@ def dry_run(args):
         dist.barrier()
         dist.all_reduce(bucket)
         dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    mine_s = time.perf_counter() - t0
+    el = torch.tensor([mine_s], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    by_rank = per_rank_ms(mine_s, 1, world)
     assert float(bucket[0]) == world * (world + 1) / 2
     seen = parallel.ranks_seen()
     same = parallel.ranks_identical([torch.arange(8.0)])
@@ -286,6 +308,9 @@ def dry_run(args):
                           "scaling": "strong" if args.strong else "weak", "rays_per_rank": hi - lo,
                           "global_batch_rays": n_global, "rays_of_all_ranks": sum(c[0] for c in counts),
                           "frames_of_all_ranks": sum(c[1] for c in counts), "rccl_ranks_seen": seen, "ranks_identical": same,
+                          "ms_per_step_by_rank": by_rank, "fabric_topology": parallel.fabric_topology(),
+                          "dist_env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NERF_DIST_NO_DEVICE_ID", "NERF_DIST_TIMEOUT_S",
+                                                                     "MASTER_ADDR", "MASTER_PORT")},
                           "dry_run": True}))
     if world > 1:
         dist.barrier()
@@ -348,14 +373,9 @@ class Session:
 
     def strong_randoms(self):
         """random draws of the GLOBAL batch in the reference's order from a generator every rank seeds identically;
-        each rank keeps its slice, so the N-GPU step computes exactly the 1-GPU N_rand=32768 step"""
-        torch, cfg, dev, g = self.torch, self.cfg, self.dev, self.strong_gen
-        r = {"t_rand": torch.rand((self.n_global, N_SAMPLES), device=dev, generator=g)}
-        if cfg["raw_noise_std"] > 0:
-            r["noise_c"] = torch.randn((self.n_global, N_SAMPLES), device=dev, generator=g)
-        r["u"] = torch.rand((self.n_global, N_IMPORTANCE), device=dev, generator=g)
-        if cfg["raw_noise_std"] > 0:
-            r["noise_f"] = torch.randn((self.n_global, N_SAMPLES + N_IMPORTANCE), device=dev, generator=g)
+        each rank keeps its slice, so the N-GPU step computes exactly the 1-GPU N_rand=32768 step (SURVEY 8d-4;
+        parallel.global_randoms, covered on 8 gloo ranks by tests/test_parallel_cpu.py)"""
+        r = self.npa.parallel.global_randoms(self.n_global, N_SAMPLES, N_IMPORTANCE, self.cfg["raw_noise_std"], self.strong_gen, self.dev)
         return {k: v[self.lo:self.hi].contiguous() for k, v in r.items()}
 
     def train_step(self, i):
@@ -408,7 +428,7 @@ class Session:
             with torch.no_grad():
                 rgb_g = npa.render(self.H, self.W, self.K, chunk=self.args.chunk, rays=gbatch, **kwargs)[0]
             gate = wl.precision_gate(rgb_g, torch.tensor(gold["rgb_ref"]), torch.tensor(gold["target"]))
-            if with_operands and precision in ("bf16x3", "fp16x3"):
+            if with_operands and precision in ("bf16x3", "fp16x3", "fp16x3w"):
                 # the one place these datapaths store less than fp32: the operands of the weight-gradient GEMM (the stored hi words:
                 # 11 / 8 significant bits).  Gradient of the training loss against the fixture's target, this datapath vs the EXACT-fp32
                 # datapath (the distance also contains the hierarchical sampling's sensitivity to forward rounding; the isolated
@@ -428,6 +448,7 @@ class Session:
                         npa.set_precision(precision)
                 g16, g32 = grads_with(precision), grads_with("fp32")
                 gate["gradient"] = {
+                    **gradient_vs_fp64(dev, precision),
                     "rel_l2_vs_fp32_datapath": float((g16 - g32).norm() / g32.norm()),
                     "cosine_deficit": 1.0 - float((g16 * g32).sum() / (g16.norm() * g32.norm())), "rays": 1024,
                     "what": "training-loss gradient of both networks on the gate fixture, this datapath vs the exact-fp32 datapath"}
@@ -465,6 +486,7 @@ def _guarded(errors, name, fn):
 
 
 T_START = time.perf_counter()
+LAST_LOCAL_SECONDS = [0.0]      # seconds of the last measure() call on THIS rank (before the max over ranks)
 LEG_SECONDS = {}        # wall time of every secondary leg of this run (reported in the line: the default command has a time budget)
 
 
@@ -512,6 +534,7 @@ def main():
             fn(i)
         barrier()
         el = time.perf_counter() - t0
+        LAST_LOCAL_SECONDS[0] = el          # this rank's own clock (the N > 1 line reports the spread over ranks)
         if grouped:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -532,6 +555,7 @@ def main():
     step = ses.step_fn(args.mode)
     rays_per_step = ses.rays_per_step(args.mode)
     elapsed, kern = measure(args.precision, args.steps, args.warmup, step, with_kernels=True)
+    by_rank = per_rank_ms(LAST_LOCAL_SECONDS[0], args.steps, world) if grouped else None
 
     # ---- N > 1: what the exchange costs alone, whether it was overlapped, and whether the ranks still agree
     multi = None
@@ -557,6 +581,11 @@ def main():
                  "rccl_version": rccl_version() if dist.get_backend() == "nccl" else None}
     elif grouped:
         multi = {"rccl_ranks_seen": parallel.ranks_seen()}
+    if multi is not None:
+        multi["ms_per_step_by_rank"] = by_rank
+        multi["fabric_topology"] = parallel.fabric_topology() if rank == 0 else None
+        multi["dist_env"] = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NERF_DIST_NO_DEVICE_ID", "NERF_DIST_TIMEOUT_S",
+                                                            "NCCL_DEBUG", "RCCL_MSCCL_ENABLE", "MASTER_ADDR")}
 
     # ---- secondary numbers of the same run (never the headline)
     other_infer = infer_chain = second = None

@@ -159,6 +159,53 @@ def rocm_eager_baseline(cfg_name, dev, n_rays, steps=5, frame=0, chunk=32768, po
                     f"{cfg_name} workload, torch {torch.__version__}, timed after the product legs (warm GPU)"}
 
 
+def gradient_vs_fp64(dev, precision, n_rays=256, n_samples=192):
+    """What a datapath's BACKWARD arithmetic costs, isolated from the sampler (the checker's role, like the PSNR gate's fixture): one
+    field evaluation of the fine network over n_rays x n_samples points, upstream gradient = the adjoint of raw2outputs for an MSE
+    loss (what a training step produces), parameter gradient through the C ABI on `precision` against fp64 autograd of the oracle's
+    network evaluated ON THIS GPU with the kernel's own ReLU pattern forced (a unit within rounding of zero legitimately takes either
+    side of its kink; a cross-forward comparison would measure sample_pdf's sensitivity instead -- tools/EXPERIMENTS.md, round 4).
+    The reference's own fp32-vs-fp64 gradient noise is 3.5e-5 of max|g|."""
+    import torch
+    import nerf_oracle as orc
+    import nerf_pytorch_amd as npa
+    import workloads as wl
+    hb = npa.hip_backend
+    _Pc, Pf = wl.scene_params()
+    net = npa.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True).to(dev)
+    net.load_state_dict(Pf)
+    g = torch.Generator().manual_seed(11)
+    rays = wl.synthetic_rays(n_rays, seed=29).to(dev)
+    z = torch.sort(torch.rand(n_rays, n_samples, generator=g) * 4.0 + 2.0, -1)[0].to(dev)
+    target = torch.rand(n_rays, 3, generator=g).to(dev)
+    packed = net.packed_params(precision)
+    raw, act = hb.field_fwd(packed, rays, z, save_act=True, precision=precision)
+    rgb, _, _, _, _ = hb.raw2outputs(raw, z, rays, 11, None, 0.0, True, rays_d_offset=3)
+    d_rgb = (2.0 / (3 * n_rays)) * (rgb - target)
+    d_raw = hb.raw2outputs_bwd(raw, z, rays, 11, None, 0.0, True, d_rgb.contiguous(), None, None, rays_d_offset=3)
+    masks = hb.relu_patterns(act, n_rays, n_samples, precision)
+    grad = torch.empty(hb.N_PARAMS, dtype=torch.float32, device=dev)
+    hb.field_bwd(packed, act, d_raw, grad, accumulate=False, precision=precision, params=net.flat_params())
+    hb.WORKSPACE.give(act)
+    P64 = {k: v.to(dev).double().requires_grad_(True) for k, v in Pf.items()}
+    d64 = d_raw.double().reshape(-1, 4)
+    chunk = 64
+    for lo in range(0, n_rays, chunk):
+        r = rays[lo:lo + chunk].double()
+        pts = (r[:, None, 0:3] + r[:, None, 3:6] * z[lo:lo + chunk, :, None].double()).reshape(-1, 3)
+        dirs = r[:, None, 8:11].expand(r.shape[0], n_samples, 3).reshape(-1, 3)
+        feats = torch.cat([orc.posenc(pts, 10), orc.posenc(dirs, 4)], -1)
+        out, _ = orc.field_mlp_forced_relu(P64, feats, [m[lo * n_samples:(lo + chunk) * n_samples] for m in masks])
+        (out * d64[lo * n_samples:(lo + chunk) * n_samples]).sum().backward()
+    ref = torch.cat([P64[nm].grad.reshape(-1) for nm, _, _ in hb.param_table()])
+    err = grad.double() - ref
+    return {"rel_l2_vs_fp64": float(err.norm() / ref.norm()), "max_err_over_max_grad": float(err.abs().max() / ref.abs().max()),
+            "points": n_rays * n_samples,
+            "what": "parameter gradient of ONE field evaluation (fine network, training-loss upstream gradient) through the C ABI vs fp64 autograd "
+                    "of the oracle's network with the kernel's own ReLU pattern forced, fp64 on this GPU: the backward's arithmetic alone "
+                    "(reference fp32 vs fp64: 3.5e-5 of max|g|)"}
+
+
 # --------------------------------------------------------------------------------------------- board power and clocks
 class PowerSampler:
     """Board power and shader clock of GPU 0 sampled from a second thread while a leg runs ("put the roof in the

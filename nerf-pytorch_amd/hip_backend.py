@@ -557,6 +557,31 @@ def saved_masks(buf, n_rays, n_samples, precision="fp32"):
     return buf[off:off + 9 * P * 8].view(torch.int32).view(9, P, 8)
 
 
+def relu_patterns(buf, n_rays, n_samples, precision="fp16x3"):
+    """Debug / test view: the ReLU patterns a split datapath's forward saved (and its delta chain applies), as 9 boolean tensors
+    [P, width] on the buffer's device -- trunk layers 0..7 (256 wide) and the view branch (128).  Word (layer, p, half), bit i <->
+    feature 32*(i>>4) + d32row(i&15, half) (csrc/nerf_common.h).  A checker that forces THIS pattern onto an fp64 autograd of the
+    reference network measures the backward's arithmetic alone (ReLU units within rounding of zero legitimately take either side)."""
+    if precision not in SPLIT:
+        raise NerfHipError("relu_patterns: the split datapaths' bitmask order")
+    P = n_rays * n_samples
+    words = saved_masks(buf, n_rays, n_samples, precision).view(9, P, 2, 4)
+    dev = buf.device
+    i = torch.arange(128, device=dev)
+    shifts = torch.arange(32, device=dev)
+    out = []
+    for layer in range(9):
+        width = 256 if layer < 8 else 128
+        m = torch.zeros(P, width, dtype=torch.bool, device=dev)
+        for half in range(2):
+            feat = 32 * (i >> 4) + ((i & 15) & 3) + 8 * ((i & 15) >> 2) + 4 * half
+            bits = ((words[layer, :, half, :, None] >> shifts) & 1).reshape(P, 128).bool()
+            n = width // 2
+            m[:, feat[:n]] = bits[:, :n]
+        out.append(m)
+    return out
+
+
 def delta_rows(buf, n_rays, n_samples, region, precision="fp32", part="hi"):
     """Debug / test view of one region of a delta buffer as point-major [P, F] fp32: "h0".."h7", "hv", "feat" (fp32 datapath only),
     "graw" (split datapaths: the tiled 4-wide copy of the scaled d_raw)."""

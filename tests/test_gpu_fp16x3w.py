@@ -28,7 +28,7 @@ def test_two_word_forward_saves_hi_and_lo(npa, dev, nets, n_rays, S):
     assert hb.buffer_layout(act1)[0] == 5 and hb.buffer_layout(act2)[0] == 6
     assert act2.numel() >= hb.act_floats(n_rays, S, "fp16x3w") == 2 * hb.act_floats(n_rays, S, "fp16x3")
     assert torch.equal(hb.saved_masks(act1, n_rays, S, "fp16x3"), hb.saved_masks(act2, n_rays, S, "fp16x3w"))
-    assert torch.equal(hb.saved_dir(act1, n_rays, S, "fp16x3"), hb.saved_dir(act2, n_rays, S, "fp16x3w"))
+    assert torch.equal(hb.saved_dir(act1, n_rays, S, "fp16x3")[:, :27], hb.saved_dir(act2, n_rays, S, "fp16x3w")[:, :27])    # (columns 27..31: unused)
     pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None])
     P64 = {k: v.double() for k, v in Pf.items()}
     feats = torch.cat([orc.posenc(pts.reshape(-1, 3).double(), 10), orc.posenc(rays[:, None, 8:11].expand(n_rays, S, 3).reshape(-1, 3).double(), 4)], -1)
@@ -111,8 +111,8 @@ def test_two_word_backward_under_a_random_upstream_gradient(npa, dev, nets, n_ra
     rel1, worst1 = _grad_vs_fp64(npa, dev, nets, "fp16x3", n_rays, S, _random_upstream)
     rel2, worst2 = _grad_vs_fp64(npa, dev, nets, "fp16x3w", n_rays, S, _random_upstream)
     print(f"random upstream gradient, {n_rays} x {S}: whole-gradient rel. L2 vs fp64 -- fp16x3 {rel1:.2e} (worst entry {worst1:.1e}), fp16x3w {rel2:.2e} ({worst2:.1e})")
-    assert rel2 <= 5e-6 and worst2 <= 2e-5, (rel2, worst2)
-    assert rel2 <= rel1 / 20, (rel1, rel2)
+    assert rel2 <= 3e-6 and worst2 <= 1e-5, (rel2, worst2)        # measured 8.0e-7 .. 1.3e-6 (fp16x3: 2.1e-4 .. 3.4e-4)
+    assert rel2 <= rel1 / 50, (rel1, rel2)
 
 
 def test_two_word_backward_under_a_training_losss_upstream_gradient(npa, dev, nets):
@@ -121,8 +121,8 @@ def test_two_word_backward_under_a_training_losss_upstream_gradient(npa, dev, ne
     rel2, worst2 = _grad_vs_fp64(npa, dev, nets, "fp16x3w", 512, 192, _training_upstream(npa))
     print(f"training-loss upstream gradient, 98 k points: whole-gradient rel. L2 vs fp64 -- fp16x3 {rel1:.2e} (worst entry {worst1:.1e}), fp16x3w {rel2:.2e} ({worst2:.1e})")
     assert rel1 <= 5e-5
-    assert rel2 <= 3e-6 and worst2 <= 2e-5, (rel2, worst2)
-    assert rel2 <= rel1 / 5, (rel1, rel2)
+    assert rel2 <= 1.5e-6 and worst2 <= 3e-6, (rel2, worst2)       # measured 4.2e-7 / 5.6e-7 (fp16x3: 1.9e-5 / 3.1e-5)
+    assert rel2 <= rel1 / 10, (rel1, rel2)
 
 
 def test_two_word_deltas_are_the_split_of_the_one_word_chain(npa, dev, nets):

@@ -39,43 +39,14 @@ def test_the_split_forward_is_the_ring_kernel(npa, dev, nets):
 
 # ---------------------------------------------------------------- split-bf16 backward: arithmetic error vs kink flips
 def _decode_masks(npa, act, P, n_rays, precision="bf16x3"):
-    """ReLU bitmasks of a split-bf16 save buffer as 9 boolean tensors [P, width] (layers 0..7: 256, view branch: 128);
-    word (layer, p, half), bit i <-> feature 32*(i>>4) + d32row(i&15, half) (csrc/nerf_common.h)"""
-    words = npa.hip_backend.saved_masks(act, n_rays, P // n_rays, precision).view(9, P, 2, 4).cpu()
-    i = torch.arange(128)
-    out = []
-    for layer in range(9):
-        width = 256 if layer < 8 else 128
-        m = torch.zeros(P, width, dtype=torch.bool)
-        for half in range(2):
-            feat = 32 * (i >> 4) + ((i & 15) & 3) + 8 * ((i & 15) >> 2) + 4 * half
-            bits = ((words[layer, :, half, :, None] >> torch.arange(32)) & 1).reshape(P, 128).bool()
-            n = width // 2
-            m[:, feat[:n]] = bits[:, :n]
-        out.append(m)
-    return out
+    """ReLU patterns of a split datapath's save buffer as 9 boolean tensors [P, width] on the CPU (hip_backend.relu_patterns decodes
+    the kernels' bitmask order)"""
+    return [m.cpu() for m in npa.hip_backend.relu_patterns(act, n_rays, P // n_rays, precision)]
 
 
 def _field_with_forced_relu(P64, feats, masks):
-    """The reference MLP (run_nerf_helpers.py:96-119, oracle.field_mlp) in fp64 with every ReLU replaced by a
-    multiplication with a GIVEN 0/1 pattern: its autograd is the backward of the network for exactly that pattern.
-    Returns (out [M,4], list of the 9 pre-activations)."""
-    lin = torch.nn.functional.linear
-    xyz, dirs = feats[:, :63], feats[:, 63:]
-    h, pres = xyz, []
-    for i in range(8):
-        pre = lin(h, P64[f"pts_linears.{i}.weight"], P64[f"pts_linears.{i}.bias"])
-        pres.append(pre)
-        h = pre * masks[i].to(pre.dtype)
-        if i == 4:
-            h = torch.cat([xyz, h], -1)
-    sigma = lin(h, P64["alpha_linear.weight"], P64["alpha_linear.bias"])
-    feat = lin(h, P64["feature_linear.weight"], P64["feature_linear.bias"])
-    pre = lin(torch.cat([feat, dirs], -1), P64["views_linears.0.weight"], P64["views_linears.0.bias"])
-    pres.append(pre)
-    hv = pre * masks[8].to(pre.dtype)
-    rgb = lin(hv, P64["rgb_linear.weight"], P64["rgb_linear.bias"])
-    return torch.cat([rgb, sigma], -1), pres
+    """The reference MLP in fp64 with every ReLU replaced by a multiplication with a GIVEN 0/1 pattern (oracle.field_mlp_forced_relu)"""
+    return orc.field_mlp_forced_relu(P64, feats, masks)
 
 
 @pytest.mark.parametrize("n_rays,S", [(48, 64), (11, 192), (70, 20)])

@@ -55,12 +55,12 @@ def main():
         z = torch.sort(torch.rand(n, S, device=dev) * 4 + 2, -1)[0]
         d_raw = torch.randn(n, S, 4, device=dev) * 1e-4
         raw = torch.empty(n, S, 4, device=dev)
-        act = torch.empty(hb.act_floats(n, S), device=dev)
-        delta = torch.empty(L.nerf_delta_floats(n, S), device=dev)
+        act = torch.empty(max(hb.act_floats(n, S), hb.act_floats(n, S, prec)), device=dev)
+        delta = torch.empty(max(L.nerf_delta_floats(n, S), hb.delta_floats(n, S, prec)), device=dev)
         partial = torch.empty(L.nerf_wgrad_partial_floats(n, S), device=dev)
         grad = torch.empty(hb.N_PARAMS, device=dev)
         s = torch.cuda.current_stream().cuda_stream
-        split = {"bf16x3": 0, "fp16x3": 1}.get(prec)
+        split = {"bf16x3": 0, "fp16x3": 1, "fp16x3w": 5}.get(prec)       # (5: two-word saves; the inference forward is split 1's)
         flat = net.flat_params()
         if split is None:
             fwd_i = lambda: L.nerf_field_fwd(packed.data_ptr(), rays.data_ptr(), 11, z.data_ptr(), n, S, raw.data_ptr(), None, s)
