@@ -90,6 +90,8 @@ def parse_args(argv=None):
     ap.add_argument("--single-datapath", action="store_true", help="skip the secondary datapath measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="only the CPU baseline on the metric's own shape: one warm-up + one timed 4096-ray training step "
+                                                             "of the oracle port on all host threads (~2 min); prints its record (commit it as profiles/r06_cpu_full_shape.json)")
     ap.add_argument("--no-gate", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other single-GPU configurations")
     ap.add_argument("--sustained-s", type=float, default=6.0,
@@ -497,6 +499,9 @@ def main():
     relaunch_if_needed(args)
     if args.dry_run:
         return dry_run(args)
+    if args.cpu_full:
+        print(json.dumps(cpu_baseline(args.config, n_rays=N_RAND, full_shape=True)))
+        return
 
     import torch
     import torch.distributed as dist

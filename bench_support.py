@@ -38,9 +38,14 @@ half_res = True
 
 
 # --------------------------------------------------------------------------------------------- baselines (reported beside)
-def cpu_baseline(cfg_name, n_rays=256):
+CPU_FULL_SHAPE_FILE = os.path.join(ROOT, "profiles", "r06_cpu_full_shape.json")
+
+
+def cpu_baseline(cfg_name, n_rays=256, full_shape=False):
     """The oracle (bit-identical restatement of the reference, CPU, fp32) timed on this box's host cores on a bounded
-    sample of the same workload: training steps of n_rays rays x (64+128) samples."""
+    sample of the same workload: training steps of n_rays rays x (64+128) samples.  full_shape (bench.py --cpu-full): ONE
+    warm-up and ONE timed step of the metric's own 4096-ray batch on all host threads (~2 minutes); its record is committed under
+    profiles/ and the default line carries it beside the 256-ray sample as `full_shape_rays_per_s`."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as orc
@@ -68,14 +73,24 @@ def cpu_baseline(cfg_name, n_rays=256):
     step()
     t0 = time.perf_counter()
     reps = 0
-    while reps < 2 or (time.perf_counter() - t0 < 8.0 and reps < 20):
+    while reps < (1 if full_shape else 2) or (not full_shape and time.perf_counter() - t0 < 8.0 and reps < 20):
         step()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} training steps of {n_rays} rays x (64+128) samples, {cfg_name} workload (oracle = bit-identical "
-                      f"restatement of the reference, torch CPU fp32, {torch.get_num_threads()} threads of "
-                      f"{os.cpu_count()} host CPUs)"}
+    out = {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{reps} training steps of {n_rays} rays x (64+128) samples, {cfg_name} workload (oracle = bit-identical "
+                     f"restatement of the reference, torch CPU fp32, {torch.get_num_threads()} threads of "
+                     f"{os.cpu_count()} host CPUs)"}
+    if full_shape:
+        model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown") if os.path.exists("/proc/cpuinfo") else "unknown"
+        out.update(seconds_per_step=dt, host_cpus=os.cpu_count(), cpu_model=model, torch=torch.__version__, rays=n_rays)
+    elif os.path.exists(CPU_FULL_SHAPE_FILE):
+        import json
+        rec = json.load(open(CPU_FULL_SHAPE_FILE))
+        out["full_shape_rays_per_s"] = rec.get("value")
+        out["full_shape"] = {k: rec.get(k) for k in ("rays", "seconds_per_step", "cores", "host_cpus", "cpu_model")}
+        out["full_shape"]["source"] = os.path.relpath(CPU_FULL_SHAPE_FILE, ROOT) + " (bench.py --cpu-full on an MI355X box's host; the default run keeps the 256-ray sample)"
+    return out
 
 
 def rocm_eager_baseline(cfg_name, dev, n_rays, steps=5, frame=0, chunk=32768, pose=None):
@@ -201,7 +216,7 @@ def gradient_vs_fp64(dev, precision, n_rays=256, n_samples=192):
     err = grad.double() - ref
     return {"rel_l2_vs_fp64": float(err.norm() / ref.norm()), "max_err_over_max_grad": float(err.abs().max() / ref.abs().max()),
             "points": n_rays * n_samples,
-            "what": "parameter gradient of ONE field evaluation (fine network, training-loss upstream gradient) through the C ABI vs fp64 autograd "
+            "vs_fp64_what": "parameter gradient of ONE field evaluation (fine network, training-loss upstream gradient) through the C ABI vs fp64 autograd "
                     "of the oracle's network with the kernel's own ReLU pattern forced, fp64 on this GPU: the backward's arithmetic alone "
                     "(reference fp32 vs fp64: 3.5e-5 of max|g|)"}
 

@@ -9,7 +9,7 @@ this build); import it as ``nerf_pytorch_amd`` (root-level shim module).
 from .field import Embedder, NeRF, get_embedder  # noqa: F401
 from .render import (batchify, batchify_rays, get_rays, get_rays_np, img2mse, mse2psnr, ndc_rays,  # noqa: F401
                      query_points, raw2outputs, render, render_path, render_rays, run_network, sample_pdf, to8b,
-                     set_precision, get_precision, DEFAULT_PRECISION)
+                     set_precision, get_precision, check_range, DEFAULT_PRECISION)
 from .nerf_setup import config_parser, create_nerf  # noqa: F401
 from . import hip_backend, parallel  # noqa: F401
 from .optim import FlatAdam  # noqa: F401
@@ -17,4 +17,4 @@ from .sampling import sample_ray_batch  # noqa: F401
 
 __all__ = ["Embedder", "NeRF", "get_embedder", "batchify", "batchify_rays", "get_rays", "get_rays_np", "img2mse",
            "mse2psnr", "ndc_rays", "query_points", "raw2outputs", "render", "render_path", "render_rays",
-           "run_network", "sample_pdf", "to8b", "config_parser", "create_nerf", "hip_backend", "parallel", "set_precision", "get_precision", "FlatAdam", "sample_ray_batch", "DEFAULT_PRECISION"]
+           "run_network", "sample_pdf", "to8b", "config_parser", "create_nerf", "hip_backend", "parallel", "set_precision", "get_precision", "FlatAdam", "sample_ray_batch", "DEFAULT_PRECISION", "check_range"]

@@ -400,6 +400,25 @@ int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride
                                                     (hipStream_t)stream));
 }
 
+int nerf_range_scan(const float* act, int n_rays, int n_samples, unsigned* words, void* stream) {
+    REQUIRE(act && words, "null pointer");
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
+    REQUIRE((reinterpret_cast<uintptr_t>(act) & 15) == 0 && (reinterpret_cast<uintptr_t>(words) & 3) == 0, "act must be 16-byte, words 4-byte aligned");
+    BufTag t;
+    REQUIRE(tag_lookup(act, &t) && !t.is_delta && (t.kind == ACT_TILE16_F16 || t.kind == ACT_TILE16_F16X2),
+            "`act` must be a save buffer an fp16 forward of this library wrote (split = 1 / 5): only fp16 rows have a range to check");
+    REQUIRE(t.n_rays == n_rays && t.n_samples == n_samples, "`act` was saved for another ray / sample count");
+    if (n_rays == 0) return 0;
+    const size_t P = (size_t)n_rays * n_samples;
+    const nerf::ActLayout3 al = nerf::act_layout3(P, (size_t)n_rays);       // (the hi part: the same offsets in the two-word layout)
+    const size_t Pp = nerf::pad32(P);
+    // h[0..7] are contiguous; the view branch's rows follow the dump region
+    hipError_t e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(act + al.h[0]), 8 * nerf::region_words3(Pp, nerf::W), words, (hipStream_t)stream);
+    if (e == hipSuccess)
+        e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(act + al.hv), nerf::region_words3(Pp, nerf::WV), words, (hipStream_t)stream);
+    return done(__func__, e);
+}
+
 int nerf_field_fwd_last_sample(const float* packed3, const float* rays, int ray_stride, const float* z_vals, int n_rays,
                                int n_samples, float* raw, const float* packed3_next, float* raw_next, int n_samples_next, void* stream) {
     REQUIRE(packed3 && rays && z_vals && raw, "null pointer");

@@ -13,6 +13,7 @@
 //                        split over point chunks; per-chunk partial gradients are
 //                        written in canonical layout and summed by
 //   wgrad_reduce_kernel (deterministic, no atomics).
+#include <stdlib.h>
 #include <type_traits>
 #include "split_types.h"
 
@@ -910,7 +911,9 @@ hipError_t launch_field_wgrad(const float* act, const float* delta, const float*
     // the alpha head as a job of its own)
     // ... and the kernel's wrap-around arithmetic (a2_off + tile * (a2_tile_bytes - tile_bytes)) wants the graw region BEHIND hv, as
     // delta_layout3 lays them out: a reordered layout falls back to 13 jobs instead of reading the wrong rows
-    const bool merge_alpha = split16 && NERF_WG_MERGE_ALPHA && d_sigma > d_hv &&
+    // (NERF_WG_MERGE_ALPHA=0 in the environment, read per call: the 13-job plan, for the test that pins the merged row against it)
+    const char* merge_env = getenv("NERF_WG_MERGE_ALPHA");
+    const bool merge_alpha = split16 && NERF_WG_MERGE_ALPHA && !(merge_env && merge_env[0] == '0') && d_sigma > d_hv &&
                              reinterpret_cast<const char*>(d_sigma) - reinterpret_cast<const char*>(d_hv) < (1L << 31);
     if (!merge_alpha) add(d_sigma, ld_graw, 1, x_h[D - 1], W, W, 1, cn.wa, W, cn.ba);           // alpha_linear (A = d_sigma, one row)
     // fold: G = delta_hv^T h7 lands in the slot of Wv[:, :256]; wgrad_fold_kernel turns it into dWv[:, :256], dWf, dbf

@@ -250,6 +250,43 @@ __global__ void mse_bwd_kernel(const float* __restrict__ x, const float* __restr
     dx[i] = c * (x[i] - y[i]);
 }
 
+// ---- range check of the fp16 split (nerf_range_scan): largest fp16 bit pattern among packed NON-NEGATIVE halves (post-ReLU rows).  The
+// patterns of non-negative halves order like signed 16-bit integers (NaN above inf above every finite value); a half with the sign bit
+// set (-0.0 cannot occur behind the ReLU; anything else would be a layout error) is a negative integer and loses.
+__global__ __launch_bounds__(256) void range_scan_kernel(const unsigned* __restrict__ rows, size_t n4, size_t n_words, unsigned* __restrict__ words) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned m = 0u;
+    const u32x4* r4 = reinterpret_cast<const u32x4*>(rows);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const u32x4 v = __builtin_nontemporal_load(r4 + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(v[k]));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n_words - 4 * n4)) {       // a tail shorter than 16 bytes (region sizes are multiples of 4 words: none in practice)
+        const unsigned v = rows[4 * n4 + threadIdx.x];
+        asm("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(v));
+    }
+    unsigned top = max(m & 0xffffu, m >> 16);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) top = max(top, (unsigned)__shfl_xor((int)top, o));
+    __shared__ unsigned wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = top;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        top = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        if (top > 0u) atomicMax(words + 1, top);
+        if (top >= 0x7800u) atomicOr(words, 1u);
+    }
+}
+
+hipError_t launch_range_scan(const unsigned* rows, size_t n_words, unsigned* words, hipStream_t stream) {
+    if (n_words == 0) return hipSuccess;
+    const size_t n4 = n_words / 4;
+    const unsigned blocks = (unsigned)min((size_t)4096, (n4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(range_scan_kernel, dim3(blocks), dim3(256), 0, stream, rows, n4, n_words, words);
+    return hipGetLastError();
+}
+
 hipError_t launch_mse_fwd(const float* x, const float* y, long n, float* scratch, float* out, hipStream_t stream) {
     const int nb = (int)min((long)MSE_BLOCKS, (n + 4 * MSE_THREADS - 1) / (4 * MSE_THREADS));
     hipLaunchKernelGGL(mse_fwd_kernel, dim3(nb < 1 ? 1 : nb), dim3(MSE_THREADS), 0, stream, x, y, n, scratch, out);

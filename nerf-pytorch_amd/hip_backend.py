@@ -77,6 +77,7 @@ def _declare(lib):
         "nerf_dense_wgrad_scratch_floats": (sz, [l, i]),
         "nerf_dense_wgrad": (i, [p, i, i, p, i, i, l, p, i, p, p, i, p]),
         "nerf_render_rays_infer": (i, [p, p, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p, p]),
+        "nerf_range_scan": (i, [p, i, i, p, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
@@ -95,7 +96,7 @@ EXPORTS = ["nerf_abi_version", "nerf_last_error", "nerf_param_count", "nerf_para
            "nerf_adam_step",
            "nerf_render_workspace_floats", "nerf_render_rays_fwd", "nerf_render_rays_bwd", "nerf_render_infer_supported",
            "nerf_render_rays_infer", "nerf_mse_scratch_floats", "nerf_mse_fwd", "nerf_mse_bwd", "nerf_build_inputs", "nerf_dense_fwd", "nerf_dense_dgrad", "nerf_dense_wgrad_scratch_floats",
-           "nerf_dense_wgrad"]
+           "nerf_dense_wgrad", "nerf_range_scan"]
 
 
 def lib():
@@ -428,9 +429,10 @@ class Workspace:
         if len(free) > self.MAX_FREE:       # (list.remove would compare tensors elementwise)
             free.pop(min(range(len(free)), key=lambda i: free[i].numel()))
 
-    def idle_bytes(self, device):
-        """bytes of the idle leases on `device` (memory the next take() can re-use instead of allocating)"""
-        return 4 * sum(t.numel() for t in self._free.get(str(device), []))
+    def idle_bytes(self, device, at_least_floats=0):
+        """bytes of the idle leases on `device` that a take() of at_least_floats can re-use instead of allocating (a lease smaller than
+        the request serves nothing; take() also passes over leases more than twice the request)"""
+        return 4 * sum(t.numel() for t in self._free.get(str(device), []) if t.numel() >= at_least_floats)
 
     def clear(self):
         self._free.clear()
@@ -656,6 +658,75 @@ def render_rays_infer(packed_c, packed_f, rays, n_coarse, n_fine, lindisp, white
     if not fine:
         return {"rgb_c": rgb, "disp_c": disp, "acc_c": acc, "raw_c": raw}
     return {"rgb_f": rgb, "disp_f": disp, "acc_f": acc, "raw_f": raw, "rgb_c": rgb0, "disp_c": disp0, "acc_c": acc0, "z_std": z_std}
+
+
+class RangeMonitor:
+    """The guard rail of the fp16 split's range (|activation| < 65520; beyond it `raw` turns NaN): every `every`-th saving forward on
+    fp16x3 / fp16x3w is followed by nerf_range_scan over what it saved, the two result words travel to pinned host memory without a
+    synchronisation, and the NEXT calls poll the copy's event -- when an activation has reached 32768 (half the range) a RuntimeWarning
+    names the way out BEFORE the NaN: set_precision("bf16x3") (fp32's exponent range).  Replaces the reference's DEBUG-gated NaN / Inf
+    check (run_nerf.py:414-416).  every = 0 switches it off; report() is the on-demand form."""
+
+    def __init__(self):
+        self.every = int(os.environ.get("NERF_RANGE_CHECK_EVERY", "64"))
+        self.calls = 0
+        self.words = {}             # device -> int32[2]
+        self.inflight = []          # (pinned int32[2], event)
+        self.max_seen = 0.0         # largest activation any finished scan has seen
+        self.warned_at = 0.0
+        self.warnings = 0
+
+    @staticmethod
+    def _f16(bits):
+        import numpy as np
+        return float(np.array([bits & 0xffff], dtype=np.uint16).view(np.float16)[0])
+
+    def after_forward(self, acts, n_rays):
+        """acts: [(act buffer, n_samples)] of one saving fp16 forward over n_rays rays"""
+        self.poll()
+        if self.every <= 0:
+            return
+        self.calls += 1
+        if (self.calls - 1) % self.every:
+            return
+        dev = acts[0][0].device
+        w = self.words.get(dev)
+        if w is None:
+            w = self.words[dev] = torch.zeros(2, dtype=torch.int32, device=dev)
+        for act, S in acts:
+            _check(lib().nerf_range_scan(act.data_ptr(), int(n_rays), int(S), w.data_ptr(), _stream()), "nerf_range_scan")
+        host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        host.copy_(w, non_blocking=True)
+        w.zero_()                   # (stream-ordered behind the copy: the next scan starts from zero)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.inflight.append((host, ev))
+
+    def poll(self, wait=False):
+        import warnings
+        while self.inflight and (wait or self.inflight[0][1].query()):
+            host, ev = self.inflight.pop(0)
+            ev.synchronize()
+            flag, top = int(host[0]), int(host[1])
+            val = self._f16(top)
+            if val != val:
+                val = float("inf")          # a NaN pattern in the saved rows: the overflow has already happened
+            self.max_seen = max(self.max_seen, val)
+            if flag and val > self.warned_at:       # again only when it got worse
+                self.warned_at = val
+                self.warnings += 1
+                warnings.warn(f"nerf-pytorch_amd: an activation of the fp16x3 datapath reached {val:.4g}; the fp16 split's operands end at 65504 -- beyond "
+                              "that `raw` (and the loss) turn NaN.  Switch to nerf_pytorch_amd.set_precision(\"bf16x3\") (the same kernels with "
+                              "bf16 parts: fp32's exponent range) or to \"fp32\" before it does; weights and optimizer state carry over unchanged.",
+                              RuntimeWarning, stacklevel=3)
+
+    def report(self):
+        """wait for the scans in flight; {"max_activation", "limit", "warnings"}"""
+        self.poll(wait=True)
+        return {"max_activation": self.max_seen, "warn_at": 32768.0, "limit": 65504.0, "warnings": self.warnings, "every": self.every}
+
+
+RANGE_MONITOR = RangeMonitor()
 
 
 def field_fwd(packed, rays, z_vals, save_act=False, precision="fp32", guard_packed=None, raw=None, next_guard=None):

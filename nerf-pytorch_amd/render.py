@@ -44,6 +44,13 @@ def get_precision():
     return _PRECISION
 
 
+def check_range():
+    """The fp16 split's range guard rail on demand (hb.RangeMonitor.report): waits for the scans in flight and returns
+    {"max_activation": largest post-ReLU activation a scanned training forward saved, "warn_at": 32768, "limit": 65504, ...}.
+    hip_backend.RANGE_MONITOR.every (NERF_RANGE_CHECK_EVERY, default 64) = every how many training renders a scan runs; 0 = never."""
+    return hb.RANGE_MONITOR.report()
+
+
 def _linspace01(n, device):
     key = (n, str(device))
     t = _LINSPACE_CACHE.get(key)
@@ -208,12 +215,15 @@ class _RenderRays(torch.autograd.Function):
         if ctx.checkpoint:
             ceil_div = lambda a, b: -(-a // b)
             sub = min(sub, 64 * ceil_div(ceil_div(n, ceil_div(n, sub)), 64))        # equal sub-chunks, multiples of 64 rays
-            # resident sub-chunks only if they fit the budget AND what the device actually has free right now (the pool's own idle
-            # leases count as free: they are re-used); otherwise the forward is recomputed per sub-chunk in the backward
-            # (free = what the driver reports + what torch's caching allocator holds without using + the pool's idle leases)
-            free_now = (torch.cuda.mem_get_info(rays.device)[0] + torch.cuda.memory_reserved(rays.device) - torch.cuda.memory_allocated(rays.device)
-                        + hb.WORKSPACE.idle_bytes(rays.device))
-            if hb.saved_bytes(sub, cfg["N_samples"], n_f, cfg.get("precision", "fp32")) * ceil_div(n, sub) <= min(hb.SAVE_TOTAL_BYTES, int(0.9 * free_now)):
+            # resident sub-chunks only if they fit the budget AND what the device actually has free right now: what the driver reports
+            # + the pool's idle leases LARGE ENOUGH to hold a sub-chunk's saved activations (smaller ones serve nothing) + half of
+            # what torch's caching allocator holds without using (cached blocks are fragmented: only part of them can back a
+            # multi-GB request).  The estimate can still be wrong: the forward below falls back to recomputation on out-of-memory.
+            prec_ = cfg.get("precision", "fp32")
+            lease = min(hb.act_floats(sub, cfg["N_samples"], prec_), hb.act_floats(sub, cfg["N_samples"] + n_f, prec_) if n_f > 0 else 1 << 62)
+            cached = torch.cuda.memory_reserved(rays.device) - torch.cuda.memory_allocated(rays.device)
+            free_now = torch.cuda.mem_get_info(rays.device)[0] + cached // 2 + hb.WORKSPACE.idle_bytes(rays.device, lease)
+            if hb.saved_bytes(sub, cfg["N_samples"], n_f, prec_) * ceil_div(n, sub) <= min(hb.SAVE_TOTAL_BYTES, int(0.9 * free_now)):
                 ctx.checkpoint = False
                 ctx.tiles = [(lo, min(lo + sub, n)) for lo in range(0, n, sub)]
         global LAST_BACKWARD_PLAN
@@ -229,10 +239,31 @@ class _RenderRays(torch.autograd.Function):
             r = _field_pass(cfg, rays, rnd, model_c, model_f, save=need and not ctx.checkpoint)
         else:
             # every sub-chunk keeps its saved activations; the node's outputs are the concatenations (new tensors)
-            parts = [_field_pass(cfg, rays[lo:hi], {k_: v[lo:hi] for k_, v in rnd.items()}, model_c, model_f, save=True)
-                     for lo, hi in ctx.tiles]
-            out_keys = ("rgb_c", "disp_c", "acc_c", "raw_c") if n_f <= 0 else ("rgb_f", "disp_f", "acc_f", "raw_f", "rgb_c", "disp_c", "acc_c", "z_std")
-            r = {k_: torch.cat([p_[k_] for p_ in parts], 0) for k_ in out_keys}
+            parts = []
+            try:
+                for lo, hi in ctx.tiles:
+                    parts.append(_field_pass(cfg, rays[lo:hi], {k_: v[lo:hi] for k_, v in rnd.items()}, model_c, model_f, save=True))
+            except torch.cuda.OutOfMemoryError:
+                # the free-memory estimate was wrong (fragmented cache, another tenant of the device): hand everything back and take
+                # the recompute plan -- forward without saving, the backward re-runs it per sub-chunk (bit-identical)
+                for p_ in parts:
+                    _release(p_)
+                parts = None
+                hb.WORKSPACE.clear()
+                torch.cuda.empty_cache()
+                ctx.tiles, ctx.checkpoint = None, True
+                LAST_BACKWARD_PLAN = ("recompute", n, sub)
+            if parts is None:
+                r = _field_pass(cfg, rays, rnd, model_c, model_f, save=False)
+            else:
+                out_keys = ("rgb_c", "disp_c", "acc_c", "raw_c") if n_f <= 0 else ("rgb_f", "disp_f", "acc_f", "raw_f", "rgb_c", "disp_c", "acc_c", "z_std")
+                r = {k_: torch.cat([p_[k_] for p_ in parts], 0) for k_ in out_keys}
+        if need and not ctx.checkpoint and prec in ("fp16x3", "fp16x3w"):
+            # the fp16 split's range guard rail: every RANGE_MONITOR.every-th training render scans what the forward saved
+            # (hb.RangeMonitor; replaces run_nerf.py:414-416's DEBUG-gated NaN / Inf check)
+            for r_, n_ in ([(r, n)] if ctx.tiles is None else [(p_, hi - lo) for p_, (lo, hi) in zip(parts, ctx.tiles)]):
+                hb.RANGE_MONITOR.after_forward([(r_[k_], s_) for k_, s_ in (("act_c", cfg["N_samples"]), ("act_f", cfg["N_samples"] + n_f))
+                                                if r_.get(k_) is not None], n_)
         ctx.cfg, ctx.model_c, ctx.model_f = cfg, model_c, model_f
         ctx.same_net = model_f is None or model_f is model_c
         ctx.n_params_c = len(_param_slices(model_c))

@@ -389,3 +389,109 @@ def test_one_guard_launch_for_both_passes(npa, dev, nets, perturb, lindisp):
     assert torch.equal(rc1, rc2) and torch.equal(rf1, rf2) and bool(torch.isfinite(rf1).all())
     raw3, _ = hb.field_fwd(p16f, rays, zf1, precision="fp16x3")
     assert torch.equal(rf1[:, -1], raw3[:, -1])
+
+
+def test_range_guard_rail_warns_before_the_nan(npa, dev, nets):
+    """The fp16 split's cliff (|activation| >= 65520 -> NaN in `raw`) has a guard rail (round 6; the reference's DEBUG-gated NaN / Inf
+    check is run_nerf.py:414-416): nerf_range_scan over what a training forward saved, polled without synchronisation.  A network
+    whose last trunk layer is scaled until its activations reach ~45,000 (finite, but past half the range) trains three steps with
+    FINITE outputs and the warning names set_precision("bf16x3"); the healthy network trains silently; a NaN already in the saved rows
+    reports inf."""
+    import warnings
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    n = 96
+    rays = orc.synthetic_rays(n, seed=21).to(dev)
+    target = torch.rand(n, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    # how large is h7 on this scene?  (the saved rows of a forward, through the test view)
+    z = torch.sort(torch.rand(n, 64, generator=torch.Generator().manual_seed(2)) * 4.0 + 2.0, -1)[0].to(dev)
+    _, act = hb.field_fwd(nf.packed_params("fp16x3"), rays, z, save_act=True, precision="fp16x3")
+    m7 = float(hb.saved_rows(act, n, 64, "h7", "fp16x3").max())
+    hb.WORKSPACE.give(act)
+    assert 0.1 < m7 < 1000.0, m7
+    prev_monitor, prev_prec = hb.RANGE_MONITOR, npa.get_precision()
+    npa.set_precision("fp16x3")
+    try:
+        for scale, expect in ((1.0, False), (45000.0 / m7, True)):
+            hb.RANGE_MONITOR = hb.RangeMonitor()
+            hb.RANGE_MONITOR.every = 1
+            ncs, nfs = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
+            ncs.load_state_dict(Pc)
+            nfs.load_state_dict(Pf)
+            with torch.no_grad():
+                for m in (ncs, nfs):
+                    m.pts_linears[7].weight.mul_(scale)
+                    m.pts_linears[7].bias.mul_(scale)
+            opt = npa.FlatAdam(list(ncs.parameters()) + list(nfs.parameters()), lr=5e-4)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                for step in range(3):
+                    opt.zero_grad()
+                    out = npa.render_rays(rays, ncs, None, 64, N_importance=128, network_fine=nfs, white_bkgd=True, perturb=1.0, retraw=True)
+                    loss = npa.img2mse(out["rgb_map"], target) + npa.img2mse(out["rgb0"], target)
+                    loss.backward()
+                    opt.step()
+                    assert bool(torch.isfinite(out["raw"]).all()) and bool(torch.isfinite(loss)), (scale, step)
+                rep = npa.check_range()
+            msgs = [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)]
+            print(f"weights of layer 7 x {scale:.4g}: largest saved activation {rep['max_activation']:.5g}, {len(msgs)} warning(s)")
+            if expect:
+                assert 32768.0 <= rep["max_activation"] < 65504.0 and rep["warnings"] >= 1
+                assert msgs and "bf16x3" in msgs[0] and "set_precision" in msgs[0], msgs
+            else:
+                assert rep["max_activation"] < 32768.0 and rep["warnings"] == 0 and not msgs, (rep, msgs)
+                assert rep["max_activation"] >= 0.9 * m7          # (the scan really read the rows)
+        # a NaN / inf already in the rows (the cliff itself) reports inf
+        hb.RANGE_MONITOR = hb.RangeMonitor()
+        hb.RANGE_MONITOR.every = 1
+        big = npa.NeRF(**kw).to(dev)
+        big.load_state_dict(Pf)
+        with torch.no_grad():
+            big.pts_linears[7].weight.mul_(1e6 / m7)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            out = npa.render_rays(rays, big, None, 64, N_importance=0, white_bkgd=True, retraw=True)
+            out["rgb_map"].sum().backward()
+            rep = npa.check_range()
+        assert rep["max_activation"] == float("inf") and rep["warnings"] >= 1 and not bool(torch.isfinite(out["raw"]).all())
+        # the scan refuses buffers that have no fp16 range to check
+        _, act32 = hb.field_fwd(nf.packed_params("fp32"), rays, z, save_act=True, precision="fp32")
+        w = torch.zeros(2, dtype=torch.int32, device=dev)
+        assert hb.lib().nerf_range_scan(act32.data_ptr(), n, 64, w.data_ptr(), None) == -1
+        hb.WORKSPACE.give(act32)
+    finally:
+        hb.RANGE_MONITOR = prev_monitor
+        npa.set_precision(prev_prec)
+        for m in (nc, nf):
+            m.zero_grad()
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16x3w"])
+def test_merged_alpha_row_equals_the_thirteen_job_plan(npa, dev, nets, precision, monkeypatch):
+    """round 5 moved the alpha head's row onto the view layer's weight-gradient job (12 jobs x 21 chunks instead of
+    13 x 19) and re-recorded the gradient digests in the same round.  The anchor the digests lost: the same launch on the 13-job plan
+    (NERF_WG_MERGE_ALPHA=0, read per call) -- alpha_linear's and views_linears.0's gradients agree to fp32 summation order (the point
+    chunks moved: 21 vs 19 per job), every other tensor likewise."""
+    nc, nf, Pc, Pf = nets
+    hb = npa.hip_backend
+    n, S = 96, 192
+    g = torch.Generator().manual_seed(5)
+    rays = orc.synthetic_rays(n, seed=3).to(dev)
+    z = torch.sort(torch.rand(n, S, generator=g) * 4.0 + 2.0, -1)[0].to(dev)
+    d_raw = (torch.randn(n, S, 4, generator=g) * 1e-5).to(dev)
+    packed = nf.packed_params(precision)
+    grads = {}
+    for merged in ("1", "0"):
+        monkeypatch.setenv("NERF_WG_MERGE_ALPHA", merged)
+        _, act = hb.field_fwd(packed, rays, z, save_act=True, precision=precision)
+        grad = torch.full((595844,), float("nan"), device=dev)
+        hb.field_bwd(packed, act, d_raw, grad, accumulate=False, precision=precision, params=nf.flat_params())
+        hb.WORKSPACE.give(act)
+        grads[merged] = grad.clone()
+    monkeypatch.delenv("NERF_WG_MERGE_ALPHA")
+    assert not torch.equal(grads["1"], grads["0"])              # (different chunking: the switch did something)
+    for nm, off, shape in hb.param_table():
+        a, b = grads["1"][off:off + int(np.prod(shape))], grads["0"][off:off + int(np.prod(shape))]
+        assert bool(torch.isfinite(a).all())
+        assert maxdiff(a, b) <= 3e-6 * float(b.abs().max()) + 1e-30, (nm, maxdiff(a, b) / float(b.abs().max()))

@@ -1205,11 +1205,28 @@ def test_large_chunks_backpropagate_in_subchunks(npa, dev, nets, precision, monk
         monkeypatch.setattr(hb, "field_fwd", lambda *a, **k: (calls.append(k.get("save_act")), real_fwd(*a, **k))[1])
         out_t, gc_t, gf_t = run()
         assert calls == [True] * 6, calls           # 3 sub-chunks (2500 rays -> 3 x 896) x (coarse, fine), all saving, none re-run
+        # (a') the free-memory estimate was too optimistic: the device runs out of memory while the third sub-chunk leases its buffers
+        #  -> everything is handed back and the recompute plan takes over, same results
+        import sys
+        render_mod = sys.modules["nerf_pytorch_amd.render"]
+        real_take, takes = hb.WORKSPACE.take, []
+
+        def failing_take(n_floats, device):
+            takes.append(n_floats)
+            if len(takes) == 5:
+                raise torch.cuda.OutOfMemoryError("simulated: the lease of the third sub-chunk does not fit")
+            return real_take(n_floats, device)
+        monkeypatch.setattr(hb.WORKSPACE, "take", failing_take)
+        del calls[:]
+        out_o, gc_o, gf_o = run()
+        monkeypatch.setattr(hb.WORKSPACE, "take", real_take)
+        assert render_mod.LAST_BACKWARD_PLAN[0] == "recompute" and calls[:5] == [True] * 5 and calls[5:7] == [False, False] and calls[7:] == [True] * 6, calls
         # (b) they do not fit: forward without saving, backward re-runs it sub-chunk by sub-chunk
         monkeypatch.setattr(hb, "SAVE_TOTAL_BYTES", 0)
         del calls[:]
         out_b, gc_b, gf_b = run()
         assert calls == [False, False] + [True] * 6, calls
+        assert torch.equal(gc_o, gc_b) and torch.equal(gf_o, gf_b)
     finally:
         npa.set_precision("fp32")
     for out_x, gc_x, gf_x in ((out_t, gc_t, gf_t), (out_b, gc_b, gf_b)):

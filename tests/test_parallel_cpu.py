@@ -200,3 +200,145 @@ def test_forced_one_rank_group_runs_the_collectives():
     p.join(60)
     assert p.exitcode == 0
     assert ok and seen == [0] and same is True
+
+
+# ---------------------------------------------------------------- 8 ranks, STRONG semantics of BASELINE configs[3]
+N_STRONG, SC_STRONG, SF_STRONG = 64, 8, 8          # the CPU-sized stand-in of 32,768 rays x (64 + 128): 8 rays per rank
+
+
+def _strong_loss_grads(Pc, Pf, rays, target, rnd):
+    """oracle training loss of run_nerf.py:765-771 on (rays, target) with the injected draws; flat gradients of both networks"""
+    Pc_g = {k: v.clone().requires_grad_(True) for k, v in Pc.items()}
+    Pf_g = {k: v.clone().requires_grad_(True) for k, v in Pf.items()}
+    out = orc.trace_rays(rays, Pc_g, Pf_g, SC_STRONG, SF_STRONG, perturb=1.0, white_bkgd=False, raw_noise_std=1.0, **rnd)
+    (orc.mse(out["rgb_map"], target) + orc.mse(out["rgb0"], target)).backward()
+    flat = lambda P: torch.cat([P[k].grad.reshape(-1) for k, _ in orc.param_shapes()])
+    return flat(Pc_g), flat(Pf_g)
+
+
+def _strong_inputs():
+    rays = orc.synthetic_rays(N_STRONG, seed=14)
+    target = torch.rand(N_STRONG, 3, generator=torch.Generator().manual_seed(3))
+    return rays, target
+
+
+def _strong_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import nerf_pytorch_amd as npa
+    from nerf_pytorch_amd import parallel
+    torch.set_num_threads(1)
+    r, w, dev = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    Pc, Pf = orc.scene_params(seed=2)
+    nets = [npa.NeRF(**kw), npa.NeRF(**kw)]
+    if rank == 0:                                       # only rank 0 holds the scene; the others get it by broadcast
+        nets[0].load_state_dict(Pc)
+        nets[1].load_state_dict(Pf)
+    parallel.broadcast_parameters(nets)
+    P = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in nets]
+    rays_all, target_all = _strong_inputs()
+    # what bench.py's Session does for --strong: every rank draws the GLOBAL batch's randoms from an identically seeded generator
+    # and keeps its rows; rays and targets are sliced the same way
+    rnd = parallel.shard_randoms(parallel.global_randoms(N_STRONG, SC_STRONG, SF_STRONG, 1.0, torch.Generator().manual_seed(4242)))
+    lo, hi = parallel.shard_slice(N_STRONG, rank, world)
+    assert all(v.shape[0] == hi - lo for v in rnd.values()) and set(rnd) == {"t_rand", "noise_c", "u", "noise_f"}
+    grads = _strong_loss_grads(P[0], P[1], rays_all[lo:hi], target_all[lo:hi], rnd)
+    table = npa.hip_backend.param_table()
+    sync = parallel.GradientSync(nets)
+    import sys
+    render = sys.modules[parallel.__name__.rsplit(".", 1)[0] + ".render"]
+    for m, flat in zip(nets, grads):                    # the backward reports each bucket final, then autograd installs the views
+        render._grad_ready(m, flat)
+        for nm, off, shape in table:
+            dict(m.named_parameters())[nm].grad = flat[off:off + int(np.prod(shape))].view(shape)
+    assert sync.started == 2
+    sync.finish()
+    sync.close()
+    same = parallel.ranks_identical([m.last_flat_grad for m in nets])
+    q.put((rank, grads[0].numpy().copy(), grads[1].numpy().copy(), bool(same)))
+    dist.barrier()
+    parallel.shutdown()
+    assert not dist.is_initialized() and parallel.FORCE_GROUP is False
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_strong_batch_equals_the_single_process_step():
+    """BASELINE configs[3] as bench.py --gpus 8 --strong runs it, on 8 gloo ranks with the oracle as the per-rank gradient: ONE global
+    batch, its random draws made once per rank from an identically seeded generator and sliced (parallel.global_randoms /
+    shard_randoms), rays and targets sliced with shard_slice, per-rank mean losses, gradients averaged by GradientSync -- equal to the
+    single-process gradient of the whole batch with the whole draws.  (The world-2 test above covers the weak form; this is the control
+    flow the driver's 8-GPU run executes that no GPU of this build has ever run.)"""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=480) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(r[3] for r in res), "ranks hold different averaged gradients"
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+    Pc, Pf = orc.scene_params(seed=2)
+    rays_all, target_all = _strong_inputs()
+    from nerf_pytorch_amd import parallel
+    rnd_all = parallel.global_randoms(N_STRONG, SC_STRONG, SF_STRONG, 1.0, torch.Generator().manual_seed(4242))
+    full_c, full_f = _strong_loss_grads(Pc, Pf, rays_all, target_all, rnd_all)
+    for got, want in ((torch.tensor(res[0][1]), full_c), (torch.tensor(res[0][2]), full_f)):
+        assert float(want.abs().max()) > 0
+        assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-9, float((got - want).abs().max() / want.abs().max())
+
+
+# ---------------------------------------------------------------- frame-parallel render_path (BASELINE configs[4]) on two gloo ranks
+def _frames_worker(rank, world, port, q, savedir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    import nerf_pytorch_amd as npa
+    from nerf_pytorch_amd import parallel
+    parallel.init_distributed(backend="gloo")
+    render = sys.modules[parallel.__name__.rsplit(".", 1)[0] + ".render"]
+    seen = []
+
+    def fake_render(H, W, K, chunk=None, c2w=None, **kw):       # the kernels need a GPU: a frame that encodes its pose
+        seen.append(float(c2w[0, 3]))
+        rgb = torch.full((H, W, 3), float(c2w[0, 3]) / 10.0)
+        return rgb, rgb[..., 0] * 2.0, rgb[..., 0], {}
+    render.render = fake_render
+    poses = torch.stack([torch.eye(4) for _ in range(5)])
+    for i in range(5):
+        poses[i, 0, 3] = float(i)
+    rgbs, disps = parallel.render_path(poses, (6, 8, 10.0), None, 1 << 15, {}, savedir=savedir)
+    q.put((rank, rgbs, disps, seen))
+    dist.barrier()
+    parallel.shutdown()
+
+
+@pytest.mark.timeout(300)
+def test_frame_parallel_render_path_deals_gathers_and_writes(tmp_path):
+    """parallel.render_path (round 6): poses dealt round-robin (frames_of_rank), every rank renders and writes ITS frames under their
+    global numbers, rank 0 returns the stacked arrays in pose order, the others (None, None) -- run_nerf.py:137-175's return value
+    from G processes.  (The same function with the real kernels, bit-compared with the single-process render_path:
+    tests/test_two_ranks_gpu.py.)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frames_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, rgbs, disps, seen0), (_, rgbs1, disps1, seen1) = res
+    files = sorted(os.listdir(tmp_path))
+    assert seen0 == [0.0, 2.0, 4.0] and seen1 == [1.0, 3.0]            # round-robin, every pose exactly once
+    assert rgbs1 is None and disps1 is None
+    assert rgbs.shape == (5, 6, 8, 3) and disps.shape == (5, 6, 8) and rgbs.dtype == np.float32
+    for i in range(5):
+        assert np.all(rgbs[i] == np.float32(i / 10.0)) and np.all(disps[i] == np.float32(i / 10.0) * 2)
+    assert [f for f in files if f.endswith(".png")] == [f"{i:03d}.png" for i in range(5)]

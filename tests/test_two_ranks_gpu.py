@@ -118,3 +118,65 @@ def test_bench_line_with_two_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["config"]["global_batch_rays"] == 2048
     assert line["value"] > 0 and "all-reduce" in line["collective"] and line["scaling"] == "weak"
+    # round 6: every rank's own clock (a slow GCD or a rank stuck in the exchange is visible), the fabric and the knobs of the run
+    by = line["multi_gpu"]["ms_per_step_by_rank"]
+    assert len(by["by_rank"]) == 2 and by["min"] <= by["max"] <= 1.001 * line["ms_per_step"] + 1e-6
+    assert "fabric_topology" in line["multi_gpu"] and line["multi_gpu"]["dist_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _frames_worker(rank, world, port, q, savedir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), NERF_ALLOW_SHARED_GPU="1")
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import nerf_pytorch_amd as npa
+    import workloads as wl
+    from nerf_pytorch_amd import parallel
+    r, w, dev = parallel.init_distributed(backend="gloo")
+    kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    Pc, Pf = wl.scene_params()
+    nc, nf = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
+    nc.load_state_dict(Pc); nf.load_state_dict(Pf)
+    H, W, focal = 20, 24, 30.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    poses = torch.stack([torch.as_tensor(wl.pose_spherical(float(th), -30.0, 4.0), dtype=torch.float32) for th in np.linspace(-180, 180, 5 + 1)[:-1]]).to(dev)
+    rk = dict(network_fn=nc, network_query_fn=None, N_samples=64, N_importance=128, network_fine=nf, perturb=0., white_bkgd=True,
+              raw_noise_std=0., ndc=False, near=2., far=6., use_viewdirs=True)
+    with torch.no_grad():
+        rgbs, disps = parallel.render_path(poses, (H, W, focal), K, 1 << 15, rk, savedir=os.path.join(savedir, "parallel"))
+        single = None
+        if rank == 0:       # the single-process function on the same poses (run_nerf.py:137-175)
+            single = npa.render_path(poses, (H, W, focal), K, 1 << 15, rk, savedir=os.path.join(savedir, "single"))
+    q.put((rank, rgbs, disps, single, parallel.frames_of_rank(5)))
+    dist.barrier()
+    parallel.shutdown()
+
+
+@pytest.mark.timeout(600)
+def test_frame_parallel_render_path_equals_the_single_process_one(tmp_path):
+    """BASELINE configs[4] as a PATH (round 6): parallel.render_path deals the poses round-robin over two ranks sharing this GPU, each
+    renders and writes ITS frames, rank 0 gathers -- arrays and PNG files bit-identical to render_path's on one rank; the other rank
+    returns (None, None); no collective on the rendering path."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    for d in ("parallel", "single"):
+        os.makedirs(tmp_path / d)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frames_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=480) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, rgbs, disps, single, fr0), (_, rgbs1, disps1, _, fr1) = res
+    assert rgbs1 is None and disps1 is None and fr0 == [0, 2, 4] and fr1 == [1, 3]
+    assert rgbs.shape == (5, 20, 24, 3) and disps.shape == (5, 20, 24) and rgbs.dtype == np.float32
+    assert np.array_equal(rgbs, single[0]) and np.array_equal(disps, single[1], equal_nan=True)
+    for i in range(5):
+        a, b = open(tmp_path / "parallel" / f"{i:03d}.png", "rb").read(), open(tmp_path / "single" / f"{i:03d}.png", "rb").read()
+        assert a == b and a[:8] == b"\x89PNG\r\n\x1a\n", i
