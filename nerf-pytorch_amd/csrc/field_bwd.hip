@@ -460,10 +460,11 @@ __device__ inline void dma_1k_s(const void* sbase, unsigned voff, unsigned lds_d
 // SP: element type of the stored operands (split_types.h: bf16, or fp16 = the hi words of the fp16 split -- then every delta
 // carries the launch's power-of-two scale, which wgrad_reduce_kernel removes)
 // TERMS = 1: the operands are the stored hi words (11 / 8 significant bits).  TERMS = 3 (round 6, "fp16x3w"): TWO-WORD operands --
-// dW = d_hi^T X_hi + d_hi^T X_lo + d_lo^T X_hi, the same three-term product as the forward's, as a contraction over 3 x the points:
-// the stage sequence of a chunk is (tile 0: hi.hi, hi.lo, lo.hi), (tile 1: ...), ...; only the DMA source of a stage changes (the lo
-// words live at a_lo_bytes / b_lo_bytes from the hi words), the ring, the fragment reads and the MFMAs are the one-word kernel's.
-// An operand's hi tile is fetched for two consecutive (A) / alternate (B) stages: the second fetch comes out of L2.
+// dW = d_hi^T X_hi + d_hi^T X_lo + d_lo^T X_hi, the same three-term product as the forward's.  A stage is then one 32-point tile of
+// FOUR operand blocks [d_hi | X_hi | d_lo | X_lo] = 64 KiB (the lo words live at a_lo_bytes / b_lo_bytes from the hi words), two stages
+// in the same 128 KiB of LDS, every word fetched from HBM once; a k-step reads 12 fragments and issues 24 MFMAs.  (First form, measured:
+// three 32-KiB stages per tile -- hi.hi, hi.lo, lo.hi -- re-fetching the hi tiles: 3.05x the one-word kernel's time, i.e. bound by its
+// 3x DMA traffic, which L2 does not absorb; this form moves 2x the bytes.)
 template <typename SP, int TERMS = 1>
 __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm1[];
@@ -476,7 +477,9 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     const long p_end = min(p_begin + (long)a.chunk_pts, a.P);
     const int nrows = (int)(p_end - p_begin);
     const int n_tiles = (nrows + WG1_STAGE_PTS - 1) / WG1_STAGE_PTS;
-    const int n_st = n_tiles * TERMS;                            // stages: TERMS per 32-point tile
+    const int n_st = n_tiles;                                    // one stage per 32-point tile
+    constexpr int STAGE_BYTES = TERMS == 3 ? 2 * WG1_STAGE_BYTES : WG1_STAGE_BYTES;      // 64 KiB: [d_hi | X_hi | d_lo | X_lo]
+    constexpr int STAGES = TERMS == 3 ? WG1_LDS_BYTES / STAGE_BYTES : WG1_STAGES;        // 2 (one in flight) / 4 (three in flight)
 
     // DMA role: waves 0-3 copy delta (A), waves 4-7 the input (B); instruction u of a wave copies LDS pieces
     // [64*m, 64*m + 64) of its operand, m = 4*(wave&3) + u; LDS piece 4*f + jj holds points 8*(jj ^ swz(f))..+7 of
@@ -513,13 +516,14 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     const unsigned lds0 = lds_addr(sm1) + (unsigned)(sop * WG1_OP_BYTES + (wave & 3) * 4096);
     const long lo_bytes = TERMS == 3 ? (sop == 0 ? a.a_lo_bytes : a.b_lo_bytes) : 0;     // this wave's operand: hi -> lo words
     auto issue = [&](int st) {
-        const int tl = TERMS == 3 ? st / 3 : st;                                 // 32-point tile of this stage
-        const int term = TERMS == 3 ? st - 3 * tl : 0;                          // 0: hi.hi, 1: d_hi.X_lo, 2: d_lo.X_hi
-        const long part = (TERMS == 3 && term == (sop == 0 ? 2 : 1)) ? lo_bytes : 0;
-        const char* src = (ray_tiles > 0 ? rbase + (size_t)((tile0 + tl) / ray_tiles) * (size_t)(16 * sld) : cbase + (size_t)tl * tile_bytes) + part;
-        const unsigned dst = lds0 + (unsigned)(st % WG1_STAGES) * WG1_STAGE_BYTES;
+        const char* src = ray_tiles > 0 ? rbase + (size_t)((tile0 + st) / ray_tiles) * (size_t)(16 * sld) : cbase + (size_t)st * tile_bytes;
+        const unsigned dst = lds0 + (unsigned)(st % STAGES) * STAGE_BYTES;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dma_1k_s(src, doff[u] + (unsigned)tl * dstep[u], dst + 1024u * u);
+        for (int u = 0; u < 4; ++u) dma_1k_s(src, doff[u] + (unsigned)st * dstep[u], dst + 1024u * u);
+        if constexpr (TERMS == 3) {             // the lo words of the same pieces, behind the hi blocks of the stage
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dma_1k_s(src + lo_bytes, doff[u] + (unsigned)st * dstep[u], dst + WG1_STAGE_BYTES + 1024u * u);
+        }
     };
 
     f32x16 acc[4][2];
@@ -550,23 +554,33 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     };
     auto compute = [&](int st) {
         if (!wave_has_work) return;
-        const unsigned char* stage = sm1 + (st % WG1_STAGES) * WG1_STAGE_BYTES;
+        const unsigned char* stage = sm1 + (st % STAGES) * STAGE_BYTES;
         const unsigned char* sa = stage + (wave_n * 128) * 64;
         const unsigned char* sb = stage + WG1_OP_BYTES + (wave_k * 64) * 64;
-        const int left = nrows - (st / TERMS) * WG1_STAGE_PTS;
-        const bool bias_stage = want_bias && (TERMS == 1 || st % TERMS != 1);     // db = sum (d_hi + d_lo): the hi words count once
+        const int left = nrows - st * WG1_STAGE_PTS;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            u32x4 bf[2];
+            u32x4 bf[2], bl[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = fragment(sb + j * 32 * 64, t, left);
+            for (int j = 0; j < 2; ++j) {
+                bf[j] = fragment(sb + j * 32 * 64, t, left);
+                if constexpr (TERMS == 3) bl[j] = fragment(sb + WG1_STAGE_BYTES + j * 32 * 64, t, left);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i >= ni) break;
                 const u32x4 af = fragment(sa + i * 32 * 64, t, left);
-                if (bias_stage) rowsum[i] += SP::sum8(af);
+                if (want_bias) rowsum[i] += SP::sum8(af);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(af, bf[j], acc[i][j]);
+                if constexpr (TERMS == 3) {     // + d_hi X_lo + d_lo X_hi;  db = sum (d_hi + d_lo)
+                    const u32x4 al = fragment(sa + WG1_STAGE_BYTES + i * 32 * 64, t, left);
+                    if (want_bias) rowsum[i] += SP::sum8(al);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(af, bl[j], acc[i][j]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(al, bf[j], acc[i][j]);
+                }
             }
         }
     };
@@ -576,12 +590,9 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
     // fragment whether its rows exist, whether the stage is ragged and whether bias sums are wanted: a branch, i.e. a
     // scheduling barrier, between every pair of MFMAs, each pair waiting for its own ds_read_b128.)
     auto compute_full = [&](int st, auto with_bias) {
-        const unsigned char* stage = sm1 + (st % WG1_STAGES) * WG1_STAGE_BYTES;
+        const unsigned char* stage = sm1 + (st % STAGES) * STAGE_BYTES;
         const unsigned char* sa = stage + (wave_n * 128) * 64;
         const unsigned char* sb = stage + WG1_OP_BYTES + (wave_k * 64) * 64;
-        // two-word operands: the delta hi words of a tile pass twice (stages 3 t and 3 t + 1); db = sum (d_hi + d_lo) counts them once
-        // (a multiplication by exactly 1 or 0 instead of a branch between the MFMAs)
-        const float bias_w = (TERMS == 3 && st % 3 == 1) ? 0.0f : 1.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {           // six reads, then eight MFMAs, per k-step (all twelve reads up front spill)
             u32x4 bf[2], af[4];
@@ -591,27 +602,49 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(WgradArgs a) {
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(sa + i * 32 * 64 + frag[t]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (decltype(with_bias)::value) rowsum[i] += TERMS == 3 ? bias_w * SP::sum8(af[i]) : SP::sum8(af[i]);
+                if (decltype(with_bias)::value) rowsum[i] += SP::sum8(af[i]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(af[i], bf[j], acc[i][j]);
+            }
+            if constexpr (TERMS == 3) {
+                // + d_hi X_lo (two more reads, eight MFMAs), + d_lo X_hi (four more reads, eight MFMAs): at most ten fragments live
+                u32x4 bl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bl[j] = *reinterpret_cast<const u32x4*>(sb + WG1_STAGE_BYTES + j * 32 * 64 + frag[t]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(af[i], bl[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(sa + WG1_STAGE_BYTES + i * 32 * 64 + frag[t]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (decltype(with_bias)::value) rowsum[i] += SP::sum8(af[i]);       // db = sum (d_hi + d_lo)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = SP::mfma(af[i], bf[j], acc[i][j]);
+                }
             }
         }
     };
     const bool full_tile = wave_has_work && ni == 4 && nj == 2;                 // wave-uniform
-    const int n_full = ((nrows % WG1_STAGE_PTS == 0) ? n_tiles : n_tiles - 1) * TERMS;     // stages whose 32 points all exist
+    const int n_full = (nrows % WG1_STAGE_PTS == 0) ? n_tiles : n_tiles - 1;     // stages whose 32 points all exist
 
     // ring: stages st+1 .. st+3 are in flight while st is consumed.  vmcnt retires in order: "at most 4 * (younger
-    // stages in flight) outstanding" = this wave's pieces of st have landed
+    // stages in flight) outstanding" = this wave's pieces of st have landed.  (Two-word form: two 64-KiB stages, st+1 in flight.)
 #pragma unroll
-    for (int st = 0; st < WG1_STAGES - 1; ++st)
+    for (int st = 0; st < STAGES - 1; ++st)
         if (st < n_st) issue(st);
     auto enter = [&](int st) {
-        if (WG1_STAGES >= 5 && st + 3 < n_st) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (st + 2 < n_st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (st + 1 < n_st) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (TERMS == 3) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stage st is the only one in flight here
+        } else {
+            if (WG1_STAGES >= 5 && st + 3 < n_st) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (st + 2 < n_st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (st + 1 < n_st) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();        // every wave's pieces landed; everybody is done with stage st-1, whose slot is reused now
-        if (st + WG1_STAGES - 1 < n_st) issue(st + WG1_STAGES - 1);
+        if (st + STAGES - 1 < n_st) issue(st + STAGES - 1);
     };
     // one loop per variant (wave-uniform choice): both bodies inside one loop cost 116 spilled VGPRs
     int st = 0;
