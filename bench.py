@@ -620,10 +620,21 @@ def main():
         tab2 = kernel_table(kern2)
         second = {"dtype": DTYPE_NAME[p2].split(" ")[0], "value": n * world * k2 / el2, "unit": "rays/s",
                   "steps": k2, "ms_per_step": 1e3 * el2 / k2, "roofline": roofline_of(tab2), "kernels": _brief(tab2)}
+    errors = {}
+    two_word = None
+    if not args.single_datapath and args.mode == "train" and args.precision == "fp16x3" and world == 1:
+        # the price of fp32-class GRADIENTS on this datapath: fp16x3w = the same forward, two-word operands in the weight-gradient GEMM
+        # (the instrument behind "the 11-bit operand storage costs training nothing detectable")
+        def _tw():
+            kt = max(5, args.steps // 2)
+            elt, kernt = measure("fp16x3w", kt, 2, step, with_kernels=True)
+            return {"dtype": DTYPE_NAME["fp16x3w"].split(" ")[0], "value": n * world * kt / elt, "unit": "rays/s", "steps": kt, "ms_per_step": 1e3 * elt / kt,
+                    "kernels": _brief(kernel_table(kernt)), "gradient_vs_fp64": gradient_vs_fp64(dev, "fp16x3w"),
+                    "headline_gradient_vs_fp64": gradient_vs_fp64(dev, "fp16x3")}
+        two_word = _guarded(errors, "two_word_datapath", _tw)
     npa.set_precision(args.precision)
     default_run = (world == 1 and args.mode == "train" and args.config == "lego" and not args.strong and not args.no_configs
                    and args.rays == N_RAND)
-    errors = {}
 
     # ---- the headline leg again, for seconds instead of 0.15 s, with board power and clock sampled meanwhile: the loop `value`
     # stands for runs 200 k iterations (run_nerf.py:711), and the roof of the MFMA-bound kernels is the power cap
@@ -929,6 +940,8 @@ def main():
                                              "vs sample_coarse -> field forward -> composite -> sample_fine -> field forward -> composite"}
         if second is not None:
             line["other_datapath"] = second
+        if two_word is not None:
+            line["two_word_datapath"] = two_word
         if bf16x3_leg is not None:
             line["bf16x3_datapath"] = bf16x3_leg
         if reduced_infer is not None:

@@ -16,8 +16,14 @@ tests of this logic.
 """
 import os
 
-import torch
-import torch.distributed as dist
+# The host driver of the MI355X boxes supports dmabuf IPC only: without this, RCCL (and CUDA-tensor sharing across processes) fails with
+# `hipIpcGetMemHandle: invalid argument`.  The HSA runtime reads it when the FIRST HIP call of the process initialises it, so it is
+# set at import time -- init_distributed() would be too late (torch.cuda.is_available() has run by then); a value already in the
+# environment wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 # NERF_FORCE_PROCESS_GROUP=1 (or init_distributed(force_group=True)): build the process group and run EVERY collective of this module
 # even when the world is one rank.  A 1-GPU box then executes the RCCL branch as written -- ProcessGroupNCCL, the communicator's
@@ -49,8 +55,8 @@ def init_distributed(backend=None, force_group=None):
 
     Knobs for a node this code has never run on (no multi-GPU node was available to any round; every one of them is an environment
     variable so that the driver's `bench.py --gpus 8` can be re-run with a different setting without a code change):
-      HSA_ENABLE_IPC_MODE_LEGACY   defaults to 0 here (dmabuf IPC: the only mode the build host's driver supports); a value already in
-                                   the environment wins
+      HSA_ENABLE_IPC_MODE_LEGACY   defaults to 0 (dmabuf IPC: the only mode the build host's driver supports), set when this module
+                                   is imported -- before the process's first HIP call; a value already in the environment wins
       NERF_DIST_NO_DEVICE_ID=1     do not bind the process group to the device at init (eager communicator creation): the communicator
                                    is then created lazily by the first collective
       NERF_DIST_TIMEOUT_S          rendezvous / collective timeout (default 180 s)
@@ -70,7 +76,6 @@ def init_distributed(backend=None, force_group=None):
         torch.cuda.set_device(device)
     if (world > 1 or FORCE_GROUP) and not dist.is_initialized():
         import datetime
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this host driver
         kw = {}
         if backend is None:
             backend = "nccl" if use_cuda else "gloo"
