@@ -192,14 +192,15 @@ int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride
 int nerf_field_dgrad_split(const float* packed3, const float* act, const float* d_raw, int n_rays, int n_samples,
                            float* delta, int split, void* stream);
 /* Range check of the fp16 split (ABI v10; replaces the reference's DEBUG-gated NaN / Inf check, run_nerf.py:414-416, with a warning
- * that can come BEFORE the NaN).  Scans what a SAVING fp16 forward (nerf_field_fwd_split(split = 1 / 5) with act) left in `act` -- the
- * post-ReLU rows of the eight trunk layers and of the view branch, i.e. every value that enters a contraction as an fp16 operand -- and
- * merges into two caller-owned 32-bit device words: words[1] = max(words[1], largest fp16 bit pattern seen) (NaN patterns included),
- * words[0] |= 1 when that pattern is >= 0x7800 (|activation| >= 32768: half way to the 65520 beyond which `raw` turns NaN).  One
- * streaming read of the rows (4.2 KB per point at HBM rate: 0.6 ms for 786 k points); the forward kernels themselves carry no monitor
- * (a running maximum costs the saving forward the 6 registers it has left: measured, spills).  The host code scans every
- * NERF_RANGE_CHECK_EVERY-th training render (default 64: 0.1 % of the step time) and reads the words without synchronising. */
-int nerf_range_scan(const float* act, int n_rays, int n_samples, unsigned* words, void* stream);
+ * that can come BEFORE the NaN).  buf = what a SAVING fp16 forward left in `act` (nerf_field_fwd_split(split = 1 / 5) with act: the
+ * post-ReLU rows of the eight trunk layers and of the view branch, i.e. every value that enters a contraction as an fp16 operand), or
+ * what an fp16 delta chain left in `delta` (nerf_field_dgrad_split(split = 1 / 5): the scaled deltas of the same layers, by magnitude).
+ * Merges into FOUR caller-owned 32-bit device words: rows -> words[1] = max(words[1], largest fp16 bit pattern), words[0] |= 1 when that
+ * pattern is >= 0x7800 (32768: half way to the 65520 beyond which `raw` / the gradient turn NaN); deltas -> words[3], words[2] likewise
+ * (NaN patterns compare above inf).  One streaming read (4.2 KB per point at HBM rate: 0.6 ms for 786 k points); the hot kernels carry no
+ * monitor (a running maximum costs the saving forward the 6 registers it has left: measured, spills).  The host code scans every
+ * NERF_RANGE_CHECK_EVERY-th training render (default 64: 0.2 % of the step time) and reads the words without synchronising. */
+int nerf_range_scan(const float* buf, int n_rays, int n_samples, unsigned* words, void* stream);
 /* test hooks (host only): gather tables of the fragment streams -- out_host[e] for every 16-bit element e: 2 * canonical_index +
  * is_low_part, or -1 for zero padding (nerf_debug_pack3_table: the (hi, lo) streams incl. the transposed ones, declared below;
  * nerf_debug_pack16_table: the 16-point forward stream). */

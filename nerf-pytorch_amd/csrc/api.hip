@@ -400,22 +400,25 @@ int nerf_field_fwd_split(const float* packed3, const float* rays, int ray_stride
                                                     (hipStream_t)stream));
 }
 
-int nerf_range_scan(const float* act, int n_rays, int n_samples, unsigned* words, void* stream) {
-    REQUIRE(act && words, "null pointer");
+int nerf_range_scan(const float* buf, int n_rays, int n_samples, unsigned* words, void* stream) {
+    REQUIRE(buf && words, "null pointer");
     REQUIRE(n_rays >= 0 && n_samples >= 1, "bad size");
-    REQUIRE((reinterpret_cast<uintptr_t>(act) & 15) == 0 && (reinterpret_cast<uintptr_t>(words) & 3) == 0, "act must be 16-byte, words 4-byte aligned");
+    REQUIRE((reinterpret_cast<uintptr_t>(buf) & 15) == 0 && (reinterpret_cast<uintptr_t>(words) & 3) == 0, "buf must be 16-byte, words 4-byte aligned");
     BufTag t;
-    REQUIRE(tag_lookup(act, &t) && !t.is_delta && (t.kind == ACT_TILE16_F16 || t.kind == ACT_TILE16_F16X2),
-            "`act` must be a save buffer an fp16 forward of this library wrote (split = 1 / 5): only fp16 rows have a range to check");
-    REQUIRE(t.n_rays == n_rays && t.n_samples == n_samples, "`act` was saved for another ray / sample count");
+    REQUIRE(tag_lookup(buf, &t) && (t.is_delta ? (t.kind == DELTA_TILE32_F16 || t.kind == DELTA_TILE32_F16X2) : (t.kind == ACT_TILE16_F16 || t.kind == ACT_TILE16_F16X2)),
+            "`buf` must be a save buffer an fp16 forward (split = 1 / 5) or a delta buffer an fp16 dgrad of this library wrote: only fp16 "
+            "rows and deltas have a range to check");
+    REQUIRE(t.n_rays == n_rays && t.n_samples == n_samples, "`buf` was written for another ray / sample count");
     if (n_rays == 0) return 0;
-    const size_t P = (size_t)n_rays * n_samples;
-    const nerf::ActLayout3 al = nerf::act_layout3(P, (size_t)n_rays);       // (the hi part: the same offsets in the two-word layout)
-    const size_t Pp = nerf::pad32(P);
-    // h[0..7] are contiguous; the view branch's rows follow the dump region
-    hipError_t e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(act + al.h[0]), 8 * nerf::region_words3(Pp, nerf::W), words, (hipStream_t)stream);
+    const size_t P = (size_t)n_rays * n_samples, Pp = nerf::pad32(P);
+    // (the hi part: the same offsets in the two-word layouts)  h[0..7] are contiguous; the view branch's region follows the dump region
+    size_t h0, hv;
+    if (t.is_delta) { const nerf::DeltaLayout3 dl = nerf::delta_layout3(P); h0 = dl.h[0]; hv = dl.hv; }
+    else { const nerf::ActLayout3 al = nerf::act_layout3(P, (size_t)n_rays); h0 = al.h[0]; hv = al.hv; }
+    unsigned* out = words + (t.is_delta ? 2 : 0);
+    hipError_t e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(buf + h0), 8 * nerf::region_words3(Pp, nerf::W), out, t.is_delta, (hipStream_t)stream);
     if (e == hipSuccess)
-        e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(act + al.hv), nerf::region_words3(Pp, nerf::WV), words, (hipStream_t)stream);
+        e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(buf + hv), nerf::region_words3(Pp, nerf::WV), out, t.is_delta, (hipStream_t)stream);
     return done(__func__, e);
 }
 

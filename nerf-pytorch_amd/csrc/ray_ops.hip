@@ -253,6 +253,8 @@ __global__ void mse_bwd_kernel(const float* __restrict__ x, const float* __restr
 // ---- range check of the fp16 split (nerf_range_scan): largest fp16 bit pattern among packed NON-NEGATIVE halves (post-ReLU rows).  The
 // patterns of non-negative halves order like signed 16-bit integers (NaN above inf above every finite value); a half with the sign bit
 // set (-0.0 cannot occur behind the ReLU; anything else would be a layout error) is a negative integer and loses.
+// ABS (the signed deltas): the sign bits are cleared first -- |half| as a pattern.
+template <bool ABS>
 __global__ __launch_bounds__(256) void range_scan_kernel(const unsigned* __restrict__ rows, size_t n4, size_t n_words, unsigned* __restrict__ words) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned m = 0u;
@@ -260,10 +262,13 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const unsigned* __restr
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const u32x4 v = __builtin_nontemporal_load(r4 + i);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) asm("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(v[k]));
+        for (int k = 0; k < 4; ++k) {
+            const unsigned w = ABS ? v[k] & 0x7fff7fffu : v[k];
+            asm("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(w));
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n_words - 4 * n4)) {       // a tail shorter than 16 bytes (region sizes are multiples of 4 words: none in practice)
-        const unsigned v = rows[4 * n4 + threadIdx.x];
+        const unsigned v = ABS ? rows[4 * n4 + threadIdx.x] & 0x7fff7fffu : rows[4 * n4 + threadIdx.x];
         asm("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(v));
     }
     unsigned top = max(m & 0xffffu, m >> 16);
@@ -279,11 +284,12 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const unsigned* __restr
     }
 }
 
-hipError_t launch_range_scan(const unsigned* rows, size_t n_words, unsigned* words, hipStream_t stream) {
+hipError_t launch_range_scan(const unsigned* rows, size_t n_words, unsigned* words, int abs_values, hipStream_t stream) {
     if (n_words == 0) return hipSuccess;
     const size_t n4 = n_words / 4;
     const unsigned blocks = (unsigned)min((size_t)4096, (n4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(range_scan_kernel, dim3(blocks), dim3(256), 0, stream, rows, n4, n_words, words);
+    if (abs_values) hipLaunchKernelGGL(range_scan_kernel<true>, dim3(blocks), dim3(256), 0, stream, rows, n4, n_words, words);
+    else hipLaunchKernelGGL(range_scan_kernel<false>, dim3(blocks), dim3(256), 0, stream, rows, n4, n_words, words);
     return hipGetLastError();
 }
 

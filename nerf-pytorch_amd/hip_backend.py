@@ -661,25 +661,43 @@ def render_rays_infer(packed_c, packed_f, rays, n_coarse, n_fine, lindisp, white
 
 
 class RangeMonitor:
-    """The guard rail of the fp16 split's range (|activation| < 65520; beyond it `raw` turns NaN): every `every`-th saving forward on
-    fp16x3 / fp16x3w is followed by nerf_range_scan over what it saved, the two result words travel to pinned host memory without a
-    synchronisation, and the NEXT calls poll the copy's event -- when an activation has reached 32768 (half the range) a RuntimeWarning
-    names the way out BEFORE the NaN: set_precision("bf16x3") (fp32's exponent range).  Replaces the reference's DEBUG-gated NaN / Inf
-    check (run_nerf.py:414-416).  every = 0 switches it off; report() is the on-demand form."""
+    """The guard rail of the fp16 split's range (|activation| and |scaled delta| < 65520; beyond it `raw` / the gradient turn NaN): every
+    `every`-th saving forward on fp16x3 / fp16x3w is followed by nerf_range_scan over what it saved, the delta chains of the same step
+    by a scan of their deltas, the result words travel to pinned host memory without a synchronisation, and the NEXT calls poll the
+    copies' events -- when a value has reached 32768 (half the range) a RuntimeWarning names the way out BEFORE the NaN:
+    set_precision("bf16x3") (fp32's exponent range).  Replaces the reference's DEBUG-gated NaN / Inf check (run_nerf.py:414-416).
+    every = 0 switches it off; report() is the on-demand form."""
 
     def __init__(self):
         self.every = int(os.environ.get("NERF_RANGE_CHECK_EVERY", "64"))
         self.calls = 0
-        self.words = {}             # device -> int32[2]
-        self.inflight = []          # (pinned int32[2], event)
+        self.words = {}             # device -> int32[4]: (flag, max pattern) of the rows, (flag, max pattern) of the deltas
+        self.inflight = []          # (pinned int32[4], event)
         self.max_seen = 0.0         # largest activation any finished scan has seen
-        self.warned_at = 0.0
+        self.max_delta = 0.0        # largest |scaled delta| (the chain runs on s * d_raw with max|s d_raw| in [16, 32))
+        self.warned_at = {"activation": 0.0, "scaled delta": 0.0}
         self.warnings = 0
+        self.delta_scans_due = 0    # delta chains of the current step still to be scanned
 
     @staticmethod
     def _f16(bits):
         import numpy as np
-        return float(np.array([bits & 0xffff], dtype=np.uint16).view(np.float16)[0])
+        v = float(np.array([bits & 0xffff], dtype=np.uint16).view(np.float16)[0])
+        return float("inf") if v != v else v       # a NaN pattern in the buffer: the overflow has already happened
+
+    def _scan(self, bufs, n_rays):
+        dev = bufs[0][0].device
+        w = self.words.get(dev)
+        if w is None:
+            w = self.words[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
+        for buf, S in bufs:
+            _check(lib().nerf_range_scan(buf.data_ptr(), int(n_rays), int(S), w.data_ptr(), _stream()), "nerf_range_scan")
+        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host.copy_(w, non_blocking=True)
+        w.zero_()                   # (stream-ordered behind the copy: the next scan starts from zero)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.inflight.append((host, ev))
 
     def after_forward(self, acts, n_rays):
         """acts: [(act buffer, n_samples)] of one saving fp16 forward over n_rays rays"""
@@ -689,41 +707,40 @@ class RangeMonitor:
         self.calls += 1
         if (self.calls - 1) % self.every:
             return
-        dev = acts[0][0].device
-        w = self.words.get(dev)
-        if w is None:
-            w = self.words[dev] = torch.zeros(2, dtype=torch.int32, device=dev)
-        for act, S in acts:
-            _check(lib().nerf_range_scan(act.data_ptr(), int(n_rays), int(S), w.data_ptr(), _stream()), "nerf_range_scan")
-        host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-        host.copy_(w, non_blocking=True)
-        w.zero_()                   # (stream-ordered behind the copy: the next scan starts from zero)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.inflight.append((host, ev))
+        self._scan(acts, n_rays)
+        self.delta_scans_due = len(acts)        # ... and the delta chains of this step's backward
+
+    def after_dgrad(self, delta, n_rays, n_samples):
+        """called by field_bwd between the delta chain and the weight-gradient GEMM"""
+        if self.delta_scans_due > 0:
+            self.delta_scans_due -= 1
+            self._scan([(delta, n_samples)], n_rays)
 
     def poll(self, wait=False):
         import warnings
         while self.inflight and (wait or self.inflight[0][1].query()):
             host, ev = self.inflight.pop(0)
             ev.synchronize()
-            flag, top = int(host[0]), int(host[1])
-            val = self._f16(top)
-            if val != val:
-                val = float("inf")          # a NaN pattern in the saved rows: the overflow has already happened
-            self.max_seen = max(self.max_seen, val)
-            if flag and val > self.warned_at:       # again only when it got worse
-                self.warned_at = val
-                self.warnings += 1
-                warnings.warn(f"nerf-pytorch_amd: an activation of the fp16x3 datapath reached {val:.4g}; the fp16 split's operands end at 65504 -- beyond "
-                              "that `raw` (and the loss) turn NaN.  Switch to nerf_pytorch_amd.set_precision(\"bf16x3\") (the same kernels with "
-                              "bf16 parts: fp32's exponent range) or to \"fp32\" before it does; weights and optimizer state carry over unchanged.",
-                              RuntimeWarning, stacklevel=3)
+            for what, flag, top in (("activation", int(host[0]), int(host[1])), ("scaled delta", int(host[2]), int(host[3]))):
+                val = self._f16(top)
+                if what == "activation":
+                    self.max_seen = max(self.max_seen, val)
+                else:
+                    self.max_delta = max(self.max_delta, val)
+                if flag and val > self.warned_at[what]:       # again only when it got worse
+                    self.warned_at[what] = val
+                    self.warnings += 1
+                    where = ("`raw` (and the loss) turn" if what == "activation" else "the parameter gradients turn")
+                    warnings.warn(f"nerf-pytorch_amd: {'an' if what == 'activation' else 'a'} {what} of the fp16x3 datapath reached {val:.4g}; the fp16 split's "
+                                  f"operands end at 65504 -- beyond that {where} NaN.  Switch to nerf_pytorch_amd.set_precision(\"bf16x3\") (the same "
+                                  "kernels with bf16 parts: fp32's exponent range) or to \"fp32\" before it does; weights and optimizer state carry over "
+                                  "unchanged.", RuntimeWarning, stacklevel=3)
 
     def report(self):
-        """wait for the scans in flight; {"max_activation", "limit", "warnings"}"""
+        """wait for the scans in flight; {"max_activation", "max_scaled_delta", "limit", "warnings"}"""
         self.poll(wait=True)
-        return {"max_activation": self.max_seen, "warn_at": 32768.0, "limit": 65504.0, "warnings": self.warnings, "every": self.every}
+        return {"max_activation": self.max_seen, "max_scaled_delta": self.max_delta, "warn_at": 32768.0, "limit": 65504.0,
+                "warnings": self.warnings, "every": self.every}
 
 
 RANGE_MONITOR = RangeMonitor()
@@ -867,6 +884,8 @@ def _field_bwd(L, packed, act, d_raw, grad, accumulate, precision, delta, partia
         with _timed("field_dgrad_kernel", FLOP_DGRAD_PER_POINT * P, BYTES_DELTA_PER_POINT * P):
             _check(L.nerf_field_dgrad(_ptr(packed, "packed"), _ptr(act, "act"), _ptr(d_raw, "d_raw"), n, S, _ptr(delta),
                                       _stream()), "nerf_field_dgrad")
+    if split in (1, 5):
+        RANGE_MONITOR.after_dgrad(delta, n, S)      # (scans the deltas on the steps whose forward was scanned; nothing otherwise)
     gemm16 = split is not None          # 16-bit operands streamed straight into the MFMA (wgrad1_kernel)
     datapath = -1
     args = (_ptr(act, "act"), _ptr(delta), _ptr(d_raw, "d_raw"), n, S, _ptr(partial), _ptr(grad, "grad"),

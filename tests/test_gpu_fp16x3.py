@@ -394,9 +394,10 @@ def test_one_guard_launch_for_both_passes(npa, dev, nets, perturb, lindisp):
 def test_range_guard_rail_warns_before_the_nan(npa, dev, nets):
     """The fp16 split's cliff (|activation| >= 65520 -> NaN in `raw`) has a guard rail (round 6; the reference's DEBUG-gated NaN / Inf
     check is run_nerf.py:414-416): nerf_range_scan over what a training forward saved, polled without synchronisation.  A network
-    whose last trunk layer is scaled until its activations reach ~40,000 (finite, but past half the range) trains three (small) steps with
-    FINITE outputs and the warning names set_precision("bf16x3"); the healthy network trains silently; a NaN already in the saved rows
-    reports inf."""
+    whose layer 6 is scaled until its activations reach ~40,000 (finite, but past half the range; layer 7's weights are scaled down by the
+    same factor, so the function and the deltas' range are unchanged -- scaling a layer alone overflows the DELTA chain first, which the
+    monitor reports as well) trains three (small) steps with FINITE outputs and the warning names set_precision("bf16x3"); the healthy
+    network trains silently; a NaN already in the saved rows reports inf."""
     import warnings
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
@@ -410,10 +411,11 @@ def test_range_guard_rail_warns_before_the_nan(npa, dev, nets):
         ncs, nfs = npa.NeRF(**kw).to(dev), npa.NeRF(**kw).to(dev)
         ncs.load_state_dict(Pc)
         nfs.load_state_dict(Pf)
-        with torch.no_grad():
+        with torch.no_grad():       # h6 -> scale * h6 (ReLU is positively homogeneous), everything behind it unchanged
             for m in (ncs, nfs):
-                m.pts_linears[7].weight.mul_(scale)
-                m.pts_linears[7].bias.mul_(scale)
+                m.pts_linears[6].weight.mul_(scale)
+                m.pts_linears[6].bias.mul_(scale)
+                m.pts_linears[7].weight.mul_(1.0 / scale)
         return ncs, nfs
 
     def largest_activation(scale):
@@ -429,14 +431,14 @@ def test_range_guard_rail_warns_before_the_nan(npa, dev, nets):
     prev_monitor, prev_prec = hb.RANGE_MONITOR, npa.get_precision()
     npa.set_precision("fp16x3")
     try:
-        # the scale that puts layer 7's largest activation at 40,000: h7 is positive-homogeneous in layer 7's weights and bias, so
-        # two readings fix it (the first scale keeps h7 below 40,000 whatever layer holds the healthy maximum)
+        # the scale that puts layer 6's largest activation at 40,000: h6 is positive-homogeneous in layer 6's weights and bias, so
+        # two readings fix it (the first scale keeps h6 below 40,000 whatever layer holds the healthy maximum)
         m_all = largest_activation(1.0)
         assert 0.1 < m_all < 1000.0, m_all
         s0 = 40000.0 / m_all
         m1 = largest_activation(s0)
         assert m_all < m1 <= 40000.0 * 1.001, (m_all, m1)         # (perturb = 0: the same sample points in every render of this test)
-        m7 = m1 / s0                                                # largest h7 of the healthy networks on these rays
+        m7 = m1 / s0                                                # largest h6 of the healthy networks on these rays
         for scale, expect in ((1.0, False), (40000.0 / m7, True)):
             hb.RANGE_MONITOR = hb.RangeMonitor()
             hb.RANGE_MONITOR.every = 1
@@ -456,12 +458,27 @@ def test_range_guard_rail_warns_before_the_nan(npa, dev, nets):
                 rep = npa.check_range()
             msgs = [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)]
             print(f"weights of layer 7 x {scale:.4g}: largest saved activation {rep['max_activation']:.5g}, {len(msgs)} warning(s)")
+            assert 0.0 < rep["max_scaled_delta"] < 32768.0, rep         # the delta chains of the scanned steps were scanned too
             if expect:
                 assert 32768.0 <= rep["max_activation"] < 65504.0 and rep["warnings"] >= 1
-                assert msgs and "bf16x3" in msgs[0] and "set_precision" in msgs[0], msgs
+                assert msgs and "bf16x3" in msgs[0] and "set_precision" in msgs[0] and "activation" in msgs[0], msgs
             else:
                 assert rep["max_activation"] < 32768.0 and rep["warnings"] == 0 and not msgs, (rep, msgs)
                 assert rep["max_activation"] >= 0.9 * m_all       # (the scan really read the rows)
+        # a layer scaled ALONE overflows the delta chain before the forward: the monitor names the deltas
+        hb.RANGE_MONITOR = hb.RangeMonitor()
+        hb.RANGE_MONITOR.every = 1
+        lone = npa.NeRF(**kw).to(dev)
+        lone.load_state_dict(Pf)
+        with torch.no_grad():
+            lone.pts_linears[7].weight.mul_(3000.0)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            out = npa.render_rays(rays, lone, None, 64, N_importance=0, white_bkgd=True, perturb=0., retraw=True)
+            npa.img2mse(out["rgb_map"], target).backward()
+            rep = npa.check_range()
+        print(f"layer 7's weights alone x 3000: largest activation {rep['max_activation']:.5g}, largest scaled delta {rep['max_scaled_delta']:.5g}")
+        assert rep["max_scaled_delta"] >= 32768.0 and any("scaled delta" in str(w.message) for w in caught), rep
         # a NaN / inf already in the rows (the cliff itself) reports inf
         hb.RANGE_MONITOR = hb.RangeMonitor()
         hb.RANGE_MONITOR.every = 1
