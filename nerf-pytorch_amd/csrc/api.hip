@@ -416,9 +416,9 @@ int nerf_range_scan(const float* buf, int n_rays, int n_samples, unsigned* words
     if (t.is_delta) { const nerf::DeltaLayout3 dl = nerf::delta_layout3(P); h0 = dl.h[0]; hv = dl.hv; }
     else { const nerf::ActLayout3 al = nerf::act_layout3(P, (size_t)n_rays); h0 = al.h[0]; hv = al.hv; }
     unsigned* out = words + (t.is_delta ? 2 : 0);
-    hipError_t e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(buf + h0), 8 * nerf::region_words3(Pp, nerf::W), out, t.is_delta, (hipStream_t)stream);
+    hipError_t e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(buf + h0), 8 * nerf::region_words3(Pp, nerf::W), out, (hipStream_t)stream);
     if (e == hipSuccess)
-        e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(buf + hv), nerf::region_words3(Pp, nerf::WV), out, t.is_delta, (hipStream_t)stream);
+        e = nerf::launch_range_scan(reinterpret_cast<const unsigned*>(buf + hv), nerf::region_words3(Pp, nerf::WV), out, (hipStream_t)stream);
     return done(__func__, e);
 }
 

@@ -60,9 +60,8 @@ hipError_t launch_pack(const float* canon_params, float* packed, hipStream_t str
 hipError_t launch_sample_coarse(const float* rays, int ray_stride, int n_rays, const float* t_vals, int S,
                                 int lindisp, const float* t_rand, float* z_out, hipStream_t stream);
 constexpr int MSE_SCRATCH_FLOATS = 256 + 1;      // per-block partial sums + the ticket word of mse_fwd_kernel
-// max over packed fp16 words (range check of the fp16 split's saved rows / deltas; abs_values: the signed deltas): words[1] = max
-// pattern, words[0] |= (>= 0x7800)
-hipError_t launch_range_scan(const unsigned* rows, size_t n_words, unsigned* words, int abs_values, hipStream_t stream);
+// max |fp16| pattern over packed words (range check of the fp16 split's saved rows / deltas): words[1] = max pattern, words[0] |= (>= 0x7800)
+hipError_t launch_range_scan(const unsigned* rows, size_t n_words, unsigned* words, hipStream_t stream);
 hipError_t launch_mse_fwd(const float* x, const float* y, long n, float* scratch, float* out, hipStream_t stream);
 hipError_t launch_mse_bwd(const float* x, const float* y, long n, const float* g, float* dx, hipStream_t stream);
 hipError_t launch_embed(const float* x, long n_pts, int n_freqs, float* out, hipStream_t stream);

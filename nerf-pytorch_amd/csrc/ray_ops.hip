@@ -250,11 +250,9 @@ __global__ void mse_bwd_kernel(const float* __restrict__ x, const float* __restr
     dx[i] = c * (x[i] - y[i]);
 }
 
-// ---- range check of the fp16 split (nerf_range_scan): largest fp16 bit pattern among packed NON-NEGATIVE halves (post-ReLU rows).  The
-// patterns of non-negative halves order like signed 16-bit integers (NaN above inf above every finite value); a half with the sign bit
-// set (-0.0 cannot occur behind the ReLU; anything else would be a layout error) is a negative integer and loses.
-// ABS (the signed deltas): the sign bits are cleared first -- |half| as a pattern.
-template <bool ABS>
+// ---- range check of the fp16 split (nerf_range_scan): largest |fp16| bit pattern among packed halves -- the post-ReLU rows a forward
+// saved (non-negative, or NaN of either sign once the overflow has happened) or the signed deltas of a delta chain.  With the sign bits
+// cleared the patterns order like integers: NaN above inf above every finite magnitude.
 __global__ __launch_bounds__(256) void range_scan_kernel(const unsigned* __restrict__ rows, size_t n4, size_t n_words, unsigned* __restrict__ words) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned m = 0u;
@@ -263,13 +261,13 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const unsigned* __restr
         const u32x4 v = __builtin_nontemporal_load(r4 + i);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned w = ABS ? v[k] & 0x7fff7fffu : v[k];
-            asm("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(w));
+            const unsigned w = v[k] & 0x7fff7fffu;
+            asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(w));
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n_words - 4 * n4)) {       // a tail shorter than 16 bytes (region sizes are multiples of 4 words: none in practice)
-        const unsigned v = ABS ? rows[4 * n4 + threadIdx.x] & 0x7fff7fffu : rows[4 * n4 + threadIdx.x];
-        asm("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(v));
+        const unsigned v = rows[4 * n4 + threadIdx.x] & 0x7fff7fffu;
+        asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v));
     }
     unsigned top = max(m & 0xffffu, m >> 16);
 #pragma unroll
@@ -284,12 +282,11 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const unsigned* __restr
     }
 }
 
-hipError_t launch_range_scan(const unsigned* rows, size_t n_words, unsigned* words, int abs_values, hipStream_t stream) {
+hipError_t launch_range_scan(const unsigned* rows, size_t n_words, unsigned* words, hipStream_t stream) {
     if (n_words == 0) return hipSuccess;
     const size_t n4 = n_words / 4;
     const unsigned blocks = (unsigned)min((size_t)4096, (n4 + 255) / 256 + 1);
-    if (abs_values) hipLaunchKernelGGL(range_scan_kernel<true>, dim3(blocks), dim3(256), 0, stream, rows, n4, n_words, words);
-    else hipLaunchKernelGGL(range_scan_kernel<false>, dim3(blocks), dim3(256), 0, stream, rows, n4, n_words, words);
+    hipLaunchKernelGGL(range_scan_kernel, dim3(blocks), dim3(256), 0, stream, rows, n4, n_words, words);
     return hipGetLastError();
 }
 
