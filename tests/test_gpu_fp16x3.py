@@ -457,7 +457,7 @@ def test_range_guard_rail_warns_before_the_nan(npa, dev, nets):
                     assert bool(torch.isfinite(out["raw"]).all()) and bool(torch.isfinite(loss)), (scale, step)
                 rep = npa.check_range()
             msgs = [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)]
-            print(f"weights of layer 7 x {scale:.4g}: largest saved activation {rep['max_activation']:.5g}, {len(msgs)} warning(s)")
+            print(f"layer 6 x {scale:.4g} (layer 7 / the same): largest saved activation {rep['max_activation']:.5g}, {len(msgs)} warning(s)")
             assert 0.0 < rep["max_scaled_delta"] < 32768.0, rep         # the delta chains of the scanned steps were scanned too
             if expect:
                 assert 32768.0 <= rep["max_activation"] < 65504.0 and rep["warnings"] >= 1
