@@ -576,3 +576,43 @@ def test_network_query_fn_selects_the_fused_or_the_hooked_path(monkeypatch):
     monkeypatch.setattr(render, "_render_rays_hooked", lambda *a_, **k_: went.append(a_[3]) or {"rgb_map": None})
     rays = torch.zeros(4, 11)
     assert render.render_rays(rays, tr["network_fn"], mine, 8) == {"rgb_map": None} and went == [mine]
+
+
+def test_range_monitor_reads_the_words_and_warns_once_per_worsening():
+    """hip_backend.RangeMonitor.poll() on fabricated result words (the scan itself needs a GPU: tests/test_gpu_fp16x3.py): fp16 patterns
+    -> values, a warning at >= 32768 naming set_precision("bf16x3"), again only when it got worse, NaN patterns -> inf, the deltas' words
+    reported separately."""
+    import warnings
+    hb = npa.hip_backend
+
+    class Done:
+        def query(self):
+            return True
+
+        def synchronize(self):
+            pass
+    m = hb.RangeMonitor()
+    words = lambda *w: torch.tensor(list(w), dtype=torch.int32)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        m.inflight.append((words(0, 0x4300, 0, 0x4c00), Done()))          # 3.5 and 16: healthy
+        m.poll()
+        assert not caught and m.max_seen == 3.5 and m.max_delta == 16.0
+        m.inflight.append((words(1, 0x7900, 0, 0x4c00), Done()))          # an activation of 40960
+        m.poll()
+        assert len(caught) == 1 and "activation" in str(caught[0].message) and 'set_precision("bf16x3")' in str(caught[0].message)
+        m.inflight.append((words(1, 0x7900, 0, 0x4c00), Done()))          # the same again: no second warning
+        m.poll()
+        assert len(caught) == 1
+        m.inflight.append((words(1, 0x7a00, 1, 0x7c00), Done()))          # worse, and a delta at inf
+        m.poll()
+        assert len(caught) == 3 and "scaled delta" in str(caught[2].message)
+        m.inflight.append((words(1, 0x7e00, 0, 0), Done()))               # a NaN pattern among the rows: the cliff itself
+        m.poll()
+    rep = m.report()
+    assert rep["max_activation"] == float("inf") and rep["max_scaled_delta"] == float("inf") and rep["warnings"] == 4
+    assert rep["warn_at"] == 32768.0 and rep["limit"] == 65504.0
+    off = hb.RangeMonitor()
+    off.every = 0
+    off.after_forward([], 0)                                               # switched off: nothing is scanned, nothing is counted
+    assert off.calls == 0 and not off.inflight
