@@ -68,10 +68,12 @@ def _write_at_exit():
         json.dump(old, open(WRITE, "w"), indent=0, sort_keys=True)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3", "fp16x3w"])
 @pytest.mark.parametrize("n_rays,S", SHAPES)
 def test_field_kernels_are_bit_stable(npa, dev, nets, precision, n_rays, S):
-    """forward (inference == saving), every saved region, the delta chain's every region, the weight gradients"""
+    """forward (inference == saving), every saved region, the delta chain's every region, the weight gradients.  fp16x3w (round 6): the
+    hi words of everything are fp16x3's RECORDED digests (the same forward and delta chain), the lo words and the gradients of the
+    three-term GEMM have digests of their own (recorded in round 6 from the build whose gradients sit at 4e-7 of fp64 autograd)."""
     nc, nf, Pc, Pf = nets
     hb = npa.hip_backend
     g = torch.Generator().manual_seed(1000 * n_rays + S)
@@ -89,21 +91,38 @@ def test_field_kernels_are_bit_stable(npa, dev, nets, precision, n_rays, S):
         got["act." + r] = digest(rows[:, :63] if r == "enc" else rows)
     got["act.dir"] = digest(hb.saved_dir(act, n_rays, S, precision)[:, :27])
     got["act.mask"] = digest(hb.saved_masks(act, n_rays, S, precision))
+    two = precision == "fp16x3w"
+    lo = {}
+    if two:
+        for r in regions:
+            rows = hb.saved_rows(act, n_rays, S, r, precision, part="lo")
+            lo["act." + r + ".lo"] = digest(rows[:, :63] if r == "enc" else rows)
     # the delta chain and the weight gradients, through the binding's own sequence (hb.field_bwd) on a scratch we can look at
     L = hb.lib()
-    delta = torch.zeros(L.nerf_delta_floats(n_rays, S), device=dev)
+    delta = torch.zeros(max(L.nerf_delta_floats(n_rays, S), hb.delta_floats(n_rays, S, precision)), device=dev)
     partial = torch.zeros(L.nerf_wgrad_partial_floats(n_rays, S), device=dev)
     grad = torch.full((hb.N_PARAMS,), float("nan"), device=dev)
     hb._field_bwd(L, packed, act, d_raw, grad, False, precision, delta, partial, n_rays, S, nf.flat_params())
     for r in [f"h{i}" for i in range(8)] + ["hv"] + (["feat"] if precision == "fp32" else ["graw"]):
         got["delta." + r] = digest(hb.delta_rows(delta, n_rays, S, r, precision))
-    if precision == "fp16x3":
+        if two:
+            lo["delta." + r + ".lo"] = digest(hb.delta_rows(delta, n_rays, S, r, precision, part="lo"))
+    if precision in ("fp16x3", "fp16x3w"):
         got["delta.scale"] = digest(hb.delta_scale_word(delta, n_rays, S))
-    got["grad"] = digest(grad)
     grad2 = grad.clone()
     hb._field_bwd(L, packed, act, d_raw, grad2, True, precision, delta, partial, n_rays, S, nf.flat_params())
-    got["grad.accumulated"] = digest(grad2)
     hb.WORKSPACE.give(act)
+    if two:
+        # everything but the gradients is the one-word datapath's, digest for digest ...
+        want = json.load(open(FIXTURE)).get(f"field[fp16x3,{n_rays}x{S}]")
+        assert want is not None
+        diff = sorted(k for k in got if want.get(k) != got[k])
+        assert not diff, f"fp16x3w hi words differ from fp16x3's recorded digests: {diff[:12]}"
+        # ... the lo words and the two-word GEMM's gradients are its own
+        check(f"field[{precision},{n_rays}x{S}]", dict(lo, **{"grad": digest(grad), "grad.accumulated": digest(grad2)}))
+        return
+    got["grad"] = digest(grad)
+    got["grad.accumulated"] = digest(grad2)
     check(f"field[{precision},{n_rays}x{S}]", got)
 
 
