@@ -11,7 +11,8 @@ checkpoint.  Output: one JSON (per run, per checkpoint) + the decision rule eval
           checkpoints from 2,000 steps on                                     [the extra gradient noise is not amplified without bound];
     otherwise fp16x3w becomes the default and the headline is re-quoted on it.
 
-usage: python tools/exp_equivalence_long.py [--steps 10000] [--twins 4] [--pairs 0,1] [--out gpurun_out/r06_equivalence.json]"""
+usage: python tools/exp_equivalence_long.py [--steps 10000] [--twins 4] [--pairs 0,1] [--out gpurun_out/r06_equivalence.json]
+       [--twin-range a:b]  (more runs of the same families; tools/merge_equivalence.py pools the files)"""
 import argparse
 import json
 import math
@@ -28,7 +29,7 @@ import workloads as wl  # noqa: E402
 from bench_support import CONVERGING_PAIRS  # noqa: E402
 
 
-def run_family(dev, pair_index, steps, checkpoints, n_batch, precisions, twins, log):
+def run_family(dev, pair_index, steps, checkpoints, n_batch, precisions, twins, log, twin_range=None):
     kind, a, b = CONVERGING_PAIRS[pair_index]
     kw = dict(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
 
@@ -57,7 +58,7 @@ def run_family(dev, pair_index, steps, checkpoints, n_batch, precisions, twins, 
         return -10 * math.log10(mse) if (mse > 0 and math.isfinite(mse)) else float("nan")
     results = {}
     for prec in precisions:
-        for twin in range(0, twins + 1):
+        for twin in (range(0, twins + 1) if twin_range is None else range(*twin_range)):
             name = prec if twin == 0 else f"{prec}_twin{twin}"
             torch.manual_seed(seed)
             nc, nf = net(Sc), net(Sf)
@@ -123,6 +124,8 @@ def main():
     ap.add_argument("--pairs", default="0")
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--precisions", default="fp32,fp16x3,fp16x3w")
+    ap.add_argument("--twin-range", default="", help="a:b = only the runs with perturbation numbers a .. b-1 (0 = the unperturbed run): more runs of the "
+                                                     "same families from another process / call; merge with tools/merge_equivalence.py")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_equivalence.json"))
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -137,7 +140,8 @@ def main():
         logf.flush()
     per_pair = {}
     for pi in [int(x) for x in args.pairs.split(",")]:
-        per_pair[pi] = run_family(dev, pi, args.steps, cps, args.rays, precisions, args.twins, log)
+        tr = tuple(int(x) for x in args.twin_range.split(":")) if args.twin_range else None
+        per_pair[pi] = run_family(dev, pi, args.steps, cps, args.rays, precisions, args.twins, log, twin_range=tr)
         table, keep = decide(per_pair, cps, precisions)
         with open(args.out, "w") as f:          # (rewritten after every pair: a call cut short keeps what finished)
             json.dump({"steps": args.steps, "checkpoints": cps, "rays_per_step": args.rays, "runs_per_family": 1 + args.twins,
