@@ -1443,7 +1443,7 @@ def test_user_network_query_fn_is_called_for_every_pass(npa, dev, nets, datapath
     assert calls == [((n, 64, 3), (n, 3), nc), ((n, 192, 3), (n, 3), nf)]
     assert set(hooked) == set(fused)
     for k in fused:        # the points o + d z are formed by torch here and inside the kernel there: the same fp32 operations
-        assert maxdiff(hooked[k], fused[k]) <= 1e-6 * max(1.0, float(fused[k].abs().nan_to_num().max())), k
+        assert maxdiff(hooked[k], fused[k]) <= 1e-6 * max(1.0, float(fused[k].detach().abs().nan_to_num().max())), k
     for a, b in zip(g_hook, g_fused):
         assert maxdiff(a, b) <= 1e-4 * float(b.abs().max()) + 1e-12
     # ... and it is live: a hook that changes raw changes the image (here: a density floor on raw[..., 3])
