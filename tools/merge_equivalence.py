@@ -45,7 +45,18 @@ def main():
             a["sd_over_fp32_sd"] = round(a["sd_db"] / max(b["sd_db"], 1e-4), 3)
         table.append(row)
         print(json.dumps(row))
-    out = {"pair": args.pair, "steps": steps, "checkpoints": cps, "files": args.files, "runs": {p: sorted(fam(p)) for p in precisions},
+    rule = None
+    if "fp16x3" in precisions:
+        last = table[-1]
+        ratios = [(r["steps"], r["fp16x3"]["sd_over_fp32_sd"]) for r in table]
+        late = [x for c, x in ratios if c >= 2000] or [x for _c, x in ratios]
+        rule = {"a_no_systematic_deficit": abs(last["fp16x3"]["mean_minus_fp32_db"]) <= 2 * last["fp32"]["sd_db"],
+                "b_sd_ratio_not_growing": ratios[-1][1] <= 1.5 * statistics.median(late),
+                "sd_ratio_by_checkpoint": ratios, "median_sd_ratio_from_2000_steps": statistics.median(late),
+                "what": "the decision rule of tools/exp_equivalence_long.py evaluated on the POOLED families"}
+        rule["fp16x3_stays_default"] = rule["a_no_systematic_deficit"] and rule["b_sd_ratio_not_growing"]
+        print(json.dumps(rule))
+    out = {"pair": args.pair, "decision": rule, "steps": steps, "checkpoints": cps, "files": args.files, "runs": {p: sorted(fam(p)) for p in precisions},
            "family_table": table, "held_out_psnr_db": runs,
            "what": "pooled families of tools/exp_equivalence_long.py runs (1024 rays per step, fused Adam lr 5e-4, held-out PSNR of 2048 rays on the "
                    "fp32 datapath); mean_minus_fp32_db with its Welch standard error: |z| < 2 = no detectable difference of the family means"}
