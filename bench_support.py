@@ -1,7 +1,9 @@
 """Secondary measurements of bench.py, kept out of the contract file: the two reference baselines timed beside the product (the
 oracle on the host cores, the reference's algorithm as eager PyTorch-ROCm ops on the same GPU), the board-power sampler of the
 sustained leg, the training-equivalence table, and the text of the reference's lego config for the `train_loop` leg.  Nothing here is
-on the product path; `oracle/` is imported by the two baseline functions only (as the thing measured BESIDE the product)."""
+on the product path; `oracle/` is imported by the two baseline functions (as the thing measured BESIDE the product) and by
+`gradient_vs_fp64` (as the CHECKER of the gate's gradient: its fp64 network with the kernel's own ReLU pattern forced) -- never by
+anything that produces `value`."""
 import os
 import sys
 import time
