@@ -60,6 +60,12 @@ def test_argument_errors_are_codes_not_crashes():
     assert L.nerf_act_floats_dp(4096, 192, 1) < 0.5 * L.nerf_act_floats_dp(4096, 192, 0)            # 4.8 vs 10.6 KB / point
     assert L.nerf_delta_floats_dp(4096, 192, 1) < 0.5 * L.nerf_delta_floats_dp(4096, 192, 0)
     assert (L.nerf_wgrad_partial_floats(n, S) - (128 * 256 + 128)) % 595844 == 0      # per-chunk partials + fold scratch (G | dbv)
+    # round 6: the range scan takes only buffers the library's own fp16 forward / delta chain wrote; the two-word splits are checked
+    assert L.nerf_range_scan(None, 4, 4, None, None) == -1 and b"null pointer" in L.nerf_last_error()
+    assert L.nerf_range_scan(0x100000, 4, 4, 0x200000, None) == -1 and b"fp16" in L.nerf_last_error()      # an unknown buffer
+    assert L.nerf_field_fwd_split(0x1000, 0x2000, 11, 0x3000, 4, 4, 0x4000, None, 4, None) == -1             # split 4 does not exist
+    assert L.nerf_field_dgrad_split(0x1000, 0x2000, 0x3000, 4, 4, 0x4000, 2, None) == -1
+    assert L.nerf_field_wgrad_phase(0x1000, 0x2000, 0x3000, 4, 4, 0x4000, 0x5000, 0, 7, 7, 0x6000, None) == -1   # datapath 7 does not exist
 
 
 def test_missing_library_fails_loudly(monkeypatch):
