@@ -8,19 +8,19 @@ import pytest
 import torch
 
 import nerf_oracle as orc
-from test_gpu_parity import GOLD, GOLD_TOL, PARITY_DATAPATHS, _check_golden, _check_golden_forward_reduced, dev, nets, npa  # noqa: F401  (fixtures)
+from test_gpu_parity import GOLD, GOLD_TOL, GOLDEN_CFG_DATAPATHS, PARITY_DATAPATHS, _check_golden, _check_golden_forward_reduced, dev, nets, npa  # noqa: F401  (fixtures)
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+@pytest.mark.parametrize("precision", GOLDEN_CFG_DATAPATHS)
 def test_golden_cfg2_lego_4096_ray_training_step(npa, dev, nets, precision):
     """BASELINE.json configs[1] (run_nerf.py:760-772 with configs/lego.txt: perturb = 1, white background, 64 + 128)"""
     _check_golden(npa, dev, nets, "lego_cfg2_train", dict(perturb=1.0), 1234, precision, render=(orc.LEGO, orc.lego_batch(4096, seed=17)),
                   n=4096, target_seed=98, raw_ray_stride=16)
 
 
-@pytest.mark.parametrize("precision", PARITY_DATAPATHS)
+@pytest.mark.parametrize("precision", GOLDEN_CFG_DATAPATHS)
 def test_golden_cfg3_fern_ndc_4096_ray_training_step(npa, dev, nets, precision):
     """BASELINE.json configs[2] (configs/fern.txt through render(ndc=True): raw_noise_std = 1, no white background).  bf16x3: among
     4096 fern rays a handful have a LAST sample whose density sits within the split-bf16 products' 2^-17 of zero; dists[-1] = 1e10

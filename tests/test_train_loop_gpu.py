@@ -61,7 +61,7 @@ def _oracle_params_from(model):
     return {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3", "fp16x3w"])
 def test_train_shaped_loop_matches_the_oracle_loop(npa, dev, precision):
     """400 iterations of the reference's training loop shape through the drop-in surface, and the same 400 iterations
     (same initial weights, same ray batches, same random draws, torch.optim.Adam, same lr schedule) by the oracle:
