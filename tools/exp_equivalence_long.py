@@ -92,6 +92,8 @@ def family_stats(results, prec, k):
 
 
 def decide(per_pair, checkpoints, precisions):
+    if "fp32" not in precisions:        # more runs of one family only (--twin-range): pooled and judged by tools/merge_equivalence.py
+        return [], None
     table, keep = [], True
     for pi, results in per_pair.items():
         ratios = []
